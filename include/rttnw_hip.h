@@ -1,0 +1,248 @@
+/*
+ * rttnw_hip.h — C ABI of the MI355X-native path tracer that drops in behind
+ * luliic2/rttnw's `scenes.rs` / `main.rs::render`.
+ *
+ * The reference has no FFI; the seam that exists is the Rust-level surface between
+ * `src/scenes.rs` + `src/main.rs` (callers) and `src/math/` (the tracing core).  Every entry
+ * point below replaces one constructor / method of that surface; the reference item is cited
+ * next to it as `file:line` relative to the reference repo root.  `dyn Hittable` objects expose
+ * only `hit`/`bounding_box`, so they cannot be lowered after the fact: a host describes the scene
+ * through these calls instead of (or next to) building trait objects.  INTEGRATION.md shows the
+ * Rust `extern "C"` block and the `scenes.rs`-shaped wrapper a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, POD only, no callbacks; doubles on the boundary (the reference is f64 throughout,
+ *     src/math/vec3.rs:12); the library narrows to f32 itself when `precision == RTTNW_F32`.
+ *   - objects (textures, materials, hittables) are `rttnw_id` handles owned by their scene; a
+ *     negative id is an error code.  Handles may be shared (Arc semantics, e.g. one material on
+ *     many spheres, scenes.rs:317-324).
+ *   - functions returning `int` return RTTNW_OK (0) or a negative RTTNW_ERR_*;
+ *     `rttnw_last_error()` returns a thread-local message for the last failure.
+ *   - a scene is mutable until `rttnw_scene_commit`, immutable afterwards (the reference shares
+ *     `&world` immutably across rayon workers, main.rs:216); one render in flight per scene.
+ *   - there is NO CPU fallback: every render entry point fails with RTTNW_ERR_HIP when no gfx950
+ *     device is usable.
+ */
+#ifndef RTTNW_HIP_H
+#define RTTNW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTTNW_ABI_VERSION 1
+
+typedef struct rttnw_scene rttnw_scene; /* opaque */
+typedef int32_t rttnw_id;
+
+enum rttnw_status {
+    RTTNW_OK = 0,
+    RTTNW_ERR_INVALID = -1,     /* bad argument / unknown id / wrong object kind */
+    RTTNW_ERR_STATE = -2,       /* call not allowed in this scene state (e.g. edit after commit) */
+    RTTNW_ERR_UNSUPPORTED = -3, /* scene graph shape the lowering does not handle */
+    RTTNW_ERR_HIP = -4,         /* HIP runtime error or no usable device */
+    RTTNW_ERR_NOMEM = -5
+};
+
+/* Plane selector of `Rectangle<M,P>`: (axis0, axis1, k) — hittable.rs:450-488. */
+enum rttnw_plane { RTTNW_XY = 0, RTTNW_XZ = 1, RTTNW_YZ = 2 };
+
+/* Arithmetic type of the render kernels.  F64 = the reference's type (vec3.rs:12). */
+enum rttnw_precision { RTTNW_F64 = 0, RTTNW_F32 = 1 };
+
+/* Bit flags for `rttnw_params.quirks`. */
+#define RTTNW_QUIRK_YROTATE_BACKROT 1u /* Q1: hittable.rs:700-705 reuses the overwritten x */
+#define RTTNW_QUIRKS_REFERENCE RTTNW_QUIRK_YROTATE_BACKROT
+
+/* ---------------------------------------------------------------- lifecycle ---------------- */
+
+/* `scene_seed` feeds the library-side scene randomness the reference draws from `thread_rng()`
+ * while constructing objects: Perlin tables (noise.rs:15-29,40-47).  Generator spec: DESIGN.md. */
+int rttnw_scene_create(uint64_t scene_seed, rttnw_scene** out);
+void rttnw_scene_destroy(rttnw_scene* scene);
+
+/* ---------------------------------------------------------------- textures (texture.rs) ---- */
+
+/* `impl Texture for Vec3f<Color>` — texture.rs:9-13 */
+rttnw_id rttnw_tex_solid(rttnw_scene* s, double r, double g, double b);
+/* `CheckerTexture { odd, even }` — texture.rs:15-30 */
+rttnw_id rttnw_tex_checker(rttnw_scene* s, rttnw_id odd, rttnw_id even);
+/* `NoiseTexture::scaled(scale)` (owns a fresh `Perlin::new()`) — texture.rs:45-59, noise.rs:40-47 */
+rttnw_id rttnw_tex_noise(rttnw_scene* s, double scale);
+/* `ImageTexture::new(path)` — texture.rs:64-107.  The host decodes the file; the library copies
+ * `w*h*4` bytes (RGBA8, row-major, top row first; alpha ignored).  `rgba == NULL` reproduces the
+ * load-failure behaviour: constant cyan (texture.rs:102-105). */
+rttnw_id rttnw_tex_image_rgba8(rttnw_scene* s, const uint8_t* rgba, uint32_t w, uint32_t h);
+
+/* ---------------------------------------------------------------- materials (material.rs) -- */
+
+/* `Lambertian::arc/boxed(texture_or_colour)` — material.rs:25-100 */
+rttnw_id rttnw_mat_lambertian(rttnw_scene* s, rttnw_id tex);
+/* `Metal::arc(albedo, fuzz)`; fuzz is clamped to <= 1 like material.rs:114,122,129 — :103-149 */
+rttnw_id rttnw_mat_metal(rttnw_scene* s, double r, double g, double b, double fuzz);
+/* `Dielectric::arc(refraction_index)` — material.rs:152-204 */
+rttnw_id rttnw_mat_dielectric(rttnw_scene* s, double refraction_index);
+/* `DiffuseLight::arc(texture)` — material.rs:206-250 */
+rttnw_id rttnw_mat_diffuse_light(rttnw_scene* s, rttnw_id tex);
+/* `Isotropic { albedo }` — material.rs:252-266 (also created implicitly by constant_medium) */
+rttnw_id rttnw_mat_isotropic(rttnw_scene* s, rttnw_id tex);
+
+/* ---------------------------------------------------------------- hittables (hittable.rs) -- */
+
+/* `Sphere { center, radius, material }` — hittable.rs:69-131 */
+rttnw_id rttnw_sphere(rttnw_scene* s, const double center[3], double radius, rttnw_id mat);
+/* `MovingSphere { center: c0..c1, time: t0..t1, radius, material }` — hittable.rs:179-245 */
+rttnw_id rttnw_moving_sphere(rttnw_scene* s, const double center0[3], const double center1[3],
+                             double time0, double time1, double radius, rttnw_id mat);
+/* `XY|XZ|YZ::rectangle(material, a0..a1, b0..b1, k)` — hittable.rs:401-411,434-547 */
+rttnw_id rttnw_rectangle(rttnw_scene* s, int plane, double a0, double a1, double b0, double b1,
+                         double k, rttnw_id mat);
+/* `Cube::new(box_min, box_max, material)` (six rectangles in a List) — hittable.rs:549-592 */
+rttnw_id rttnw_cube(rttnw_scene* s, const double box_min[3], const double box_max[3], rttnw_id mat);
+/* `List::new()` / `List::push(item)` — hittable.rs:134-177 */
+rttnw_id rttnw_list(rttnw_scene* s);
+int rttnw_list_push(rttnw_scene* s, rttnw_id list, rttnw_id item);
+/* `BvhTree::from(list)` — hittable.rs:248-373.  Closest-hit results do not depend on the tree's
+ * topology, so this is a grouping hint: the library builds its own flat BVH. */
+rttnw_id rttnw_bvh_tree(rttnw_scene* s, rttnw_id list);
+/* `Hittable::translate(offset)` — hittable.rs:51-59,594-629 */
+rttnw_id rttnw_translate(rttnw_scene* s, rttnw_id item, const double offset[3]);
+/* `Hittable::rotate_y(angle_degrees)` — hittable.rs:60-65,631-722 */
+rttnw_id rttnw_rotate_y(rttnw_scene* s, rttnw_id item, double angle_degrees);
+/* `ConstantMedium::new(boundary, density, phase_texture)` — hittable.rs:724-801 */
+rttnw_id rttnw_constant_medium(rttnw_scene* s, rttnw_id boundary, double density, rttnw_id tex);
+
+/* The `world: List` handed to `color()` — main.rs:47-55,216. */
+int rttnw_scene_set_world(rttnw_scene* s, rttnw_id world_list);
+/* Flatten the graph, build the flat BVHs, upload to the current HIP device.  Idempotent. */
+int rttnw_scene_commit(rttnw_scene* s);
+
+/* ---------------------------------------------------------------- render (main.rs, camera.rs) */
+
+/* `CameraDescriptor` — camera.rs:5-15 (15 doubles, same field order). */
+typedef struct rttnw_camera_desc {
+    double lookfrom[3];
+    double lookat[3];
+    double view_up[3];
+    double vertical_fov; /* degrees */
+    double aspect_ratio;
+    double aperture;
+    double focus_distance;
+    double open_time;
+    double close_time;
+} rttnw_camera_desc;
+
+/* What `render()` hard-codes or takes as arguments — main.rs:58,184-197,216,33. */
+typedef struct rttnw_params {
+    uint32_t width;
+    uint32_t height;
+    uint32_t spp;        /* `samples` — main.rs:211 */
+    uint32_t max_depth;  /* 50 — main.rs:216 */
+    double t_min;        /* 0.001 — main.rs:33 */
+    double background[3];/* main.rs:43 */
+    uint64_t seed;       /* render seed of the keyed sample RNG (DESIGN.md "RNG") */
+    uint32_t precision;  /* enum rttnw_precision */
+    uint32_t quirks;     /* RTTNW_QUIRK_* bits; RTTNW_QUIRKS_REFERENCE reproduces the reference */
+    uint32_t spp_chunk;  /* samples folded sequentially per work item; 0 = library default.  The
+                            per-pixel sum is chunk sums added in chunk order (deterministic). */
+    uint32_t tile_rank;  /* this GPU's rank in the tile partition (0 for a single GPU) */
+    uint32_t tile_world; /* number of GPUs sharing the framebuffer (>= 1) */
+    uint32_t collect_counters; /* 1: run the counting kernel variant and fill rttnw_stats */
+} rttnw_params;
+
+typedef struct rttnw_stats {
+    uint64_t samples;        /* camera paths traced by this call */
+    uint64_t rays;           /* world.hit() calls (main.rs:33) */
+    uint64_t nodes_visited;  /* BVH node records read */
+    uint64_t prims_tested;   /* primitive records read (incl. medium boundaries) */
+    uint64_t texel_fetches;  /* image-texture texel reads */
+    double kernel_ms;        /* device time of the trace kernel(s), hipEvent-measured */
+    uint32_t n_nodes;        /* flat scene size */
+    uint32_t n_prims;
+    uint32_t scene_bytes;    /* bytes of node+primitive arrays resident on the device */
+    uint32_t reserved;
+} rttnw_stats;
+
+/* Framebuffer partition: 8x8-pixel tiles, tile t owned by rank
+ * `rttnw_tile_owner(t) = permuted(t) % world`; each rank stores its tiles contiguously
+ * ("packed" order, 64 pixels per tile, row-major inside the tile), padded to
+ * `tiles_per_rank` tiles so a flat gather has a uniform count. */
+typedef struct rttnw_tile_layout {
+    uint32_t tiles_x, tiles_y, n_tiles;
+    uint32_t tiles_per_rank; /* ceil(n_tiles / world) */
+    uint32_t pixels_per_rank;/* tiles_per_rank * 64 */
+} rttnw_tile_layout;
+int rttnw_tile_layout_get(uint32_t width, uint32_t height, uint32_t world, rttnw_tile_layout* out);
+
+/* `render()` for one GPU: host outputs, blocking.  Row-major, TOP ROW FIRST like main.rs:202-205.
+ * `out_linear_rgb` (optional): width*height*3 doubles, the per-pixel mean radiance before gamma
+ * (main.rs:217).  `out_rgba8` (optional): width*height*4 bytes after sqrt/clamp/quantise
+ * (main.rs:219-225).  Requires tile_world == 1. */
+int rttnw_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p,
+                 double* out_linear_rgb, uint8_t* out_rgba8, rttnw_stats* stats);
+
+/* Device-resident form, asynchronous on `hip_stream` (a hipStream_t; NULL = default stream).
+ * Traces the tiles owned by (tile_rank, tile_world) and writes them in packed order:
+ *   d_packed_linear: pixels_per_rank * 4 floats (linear r,g,b,1) — F32 and F64 kernels alike
+ *   d_packed_linear64 (optional, F64 kernels only): pixels_per_rank * 3 doubles
+ * Pad tiles are zero-filled. */
+int rttnw_render_tiles_device(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p,
+                              float* d_packed_linear, double* d_packed_linear64, void* hip_stream,
+                              rttnw_stats* stats);
+
+/* After the gather: scatter `world * pixels_per_rank` packed pixels (rank-major) into the
+ * row-major top-first framebuffer and apply main.rs:219-225 (sqrt, clamp 0.999, *256, as u8,
+ * alpha 255).  Either output may be NULL.  Asynchronous on `hip_stream`. */
+int rttnw_untile_device(uint32_t width, uint32_t height, uint32_t world, const float* d_gathered,
+                        float* d_linear_rgb /* w*h*3 */, uint8_t* d_rgba8 /* w*h*4 */,
+                        void* hip_stream);
+
+/* ---------------------------------------------------------------- introspection ------------ */
+
+int rttnw_abi_version(void);
+int rttnw_device_count(void);
+const char* rttnw_last_error(void);
+
+/* Debug/inspection: sizes of the lowered scene (valid after commit). */
+int rttnw_scene_info(rttnw_scene* s, rttnw_stats* out);
+
+/* ---------------------------------------------------------------- entry-point table -------- */
+
+/* Scene-building entry points as a table, so one host-side scene catalogue (the `scenes.rs`
+ * mirror in rttnw_amd/host/scenes.cpp) can drive any implementation of this boundary. */
+typedef struct rttnw_builder_api {
+    int (*scene_create)(uint64_t, rttnw_scene**);
+    void (*scene_destroy)(rttnw_scene*);
+    rttnw_id (*tex_solid)(rttnw_scene*, double, double, double);
+    rttnw_id (*tex_checker)(rttnw_scene*, rttnw_id, rttnw_id);
+    rttnw_id (*tex_noise)(rttnw_scene*, double);
+    rttnw_id (*tex_image_rgba8)(rttnw_scene*, const uint8_t*, uint32_t, uint32_t);
+    rttnw_id (*mat_lambertian)(rttnw_scene*, rttnw_id);
+    rttnw_id (*mat_metal)(rttnw_scene*, double, double, double, double);
+    rttnw_id (*mat_dielectric)(rttnw_scene*, double);
+    rttnw_id (*mat_diffuse_light)(rttnw_scene*, rttnw_id);
+    rttnw_id (*mat_isotropic)(rttnw_scene*, rttnw_id);
+    rttnw_id (*sphere)(rttnw_scene*, const double*, double, rttnw_id);
+    rttnw_id (*moving_sphere)(rttnw_scene*, const double*, const double*, double, double, double,
+                              rttnw_id);
+    rttnw_id (*rectangle)(rttnw_scene*, int, double, double, double, double, double, rttnw_id);
+    rttnw_id (*cube)(rttnw_scene*, const double*, const double*, rttnw_id);
+    rttnw_id (*list)(rttnw_scene*);
+    int (*list_push)(rttnw_scene*, rttnw_id, rttnw_id);
+    rttnw_id (*bvh_tree)(rttnw_scene*, rttnw_id);
+    rttnw_id (*translate)(rttnw_scene*, rttnw_id, const double*);
+    rttnw_id (*rotate_y)(rttnw_scene*, rttnw_id, double);
+    rttnw_id (*constant_medium)(rttnw_scene*, rttnw_id, double, rttnw_id);
+    int (*scene_set_world)(rttnw_scene*, rttnw_id);
+    int (*scene_commit)(rttnw_scene*);
+    const char* (*last_error)(void);
+} rttnw_builder_api;
+
+const rttnw_builder_api* rttnw_builder(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTTNW_HIP_H */

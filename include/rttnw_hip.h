@@ -184,19 +184,19 @@ int rttnw_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_param
                  double* out_linear_rgb, uint8_t* out_rgba8, rttnw_stats* stats);
 
 /* Device-resident form, asynchronous on `hip_stream` (a hipStream_t; NULL = default stream).
- * Traces the tiles owned by (tile_rank, tile_world) and writes them in packed order:
- *   d_packed_linear: pixels_per_rank * 4 floats (linear r,g,b,1) — F32 and F64 kernels alike
- *   d_packed_linear64 (optional, F64 kernels only): pixels_per_rank * 3 doubles
- * Pad tiles are zero-filled. */
+ * Traces the tiles owned by (tile_rank, tile_world) and writes them in packed order into
+ * `d_packed`: pixels_per_rank pixel records of 4 reals (mean r, g, b, 1) of the kernel's
+ * arithmetic type — float for RTTNW_F32, double for RTTNW_F64.  Pad tiles are zero-filled.
+ * With `stats != NULL` the call synchronises the stream to fill the device time / counters. */
 int rttnw_render_tiles_device(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p,
-                              float* d_packed_linear, double* d_packed_linear64, void* hip_stream,
-                              rttnw_stats* stats);
+                              void* d_packed, void* hip_stream, rttnw_stats* stats);
 
-/* After the gather: scatter `world * pixels_per_rank` packed pixels (rank-major) into the
- * row-major top-first framebuffer and apply main.rs:219-225 (sqrt, clamp 0.999, *256, as u8,
- * alpha 255).  Either output may be NULL.  Asynchronous on `hip_stream`. */
-int rttnw_untile_device(uint32_t width, uint32_t height, uint32_t world, const float* d_gathered,
-                        float* d_linear_rgb /* w*h*3 */, uint8_t* d_rgba8 /* w*h*4 */,
+/* After the gather: scatter `world * pixels_per_rank` packed pixel records (rank-major, reals of
+ * `precision`) into the row-major top-first framebuffer: `d_linear_rgb` = w*h*3 reals of
+ * `precision` (main.rs:217), `d_rgba8` = w*h*4 bytes after main.rs:219-225 (sqrt, clamp 0.999,
+ * *256, as u8, alpha 255).  Either output may be NULL.  Asynchronous on `hip_stream`. */
+int rttnw_untile_device(uint32_t width, uint32_t height, uint32_t world, uint32_t precision,
+                        const void* d_gathered, void* d_linear_rgb, uint8_t* d_rgba8,
                         void* hip_stream);
 
 /* ---------------------------------------------------------------- introspection ------------ */

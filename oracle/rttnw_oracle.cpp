@@ -1184,4 +1184,31 @@ int rto_probe_sample(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     return RTTNW_OK;
 }
 
+// Per-bounce trace of one sample: out[b*8 + (0..7)] = t, p(3), normal(3), material id; returns #hits.
+int rto_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
+                   uint32_t sample, double* out, uint32_t max_out) {
+    if (!s || !s->world || !cam || !p || !out) return fail(RTTNW_ERR_INVALID, "probe_path: bad arguments");
+    Camera camera(*cam);
+    uint64_t pixel = uint64_t(row) * p->width + px;
+    uint32_t j = p->height - 1 - row;
+    PathCtx ctx; ctx.key = sample_key(p->seed, pixel, sample); ctx.quirks = p->quirks;
+    double u = (double(px) + keyed_uniform(ctx.key, ctr_of(0, SLOT_JITTER_U))) / double(p->width);
+    double v = (double(j) + keyed_uniform(ctx.key, ctr_of(0, SLOT_JITTER_V))) / double(p->height);
+    Ray ray = camera.ray(u, v, ctx.key);
+    uint32_t n = 0;
+    for (uint32_t depth = p->max_depth; depth > 0 && n < max_out; --depth) {
+        HitRecord rec;
+        if (!s->world->hit(ray, p->t_min, std::numeric_limits<double>::max(), ctx, rec)) break;
+        double* o = out + size_t(n) * 8;
+        o[0] = rec.t; o[1] = rec.p.x; o[2] = rec.p.y; o[3] = rec.p.z; o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z;
+        o[7] = double(rec.material->id);
+        ++n;
+        V3 att; Ray sc;
+        if (!rec.material->scatter(ray, rec, ctx, att, sc)) break;
+        ray = sc;
+        ctx.bounce += 1;
+    }
+    return int(n);
+}
+
 } // extern "C"

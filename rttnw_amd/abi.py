@@ -89,9 +89,9 @@ PRODUCT_FUNCS = [
     ("render", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_void_p, C.c_void_p,
                          C.POINTER(Stats)]),
     ("render_tiles_device", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
-    ("untile_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p]),
+                                      C.c_void_p, C.POINTER(Stats)]),
+    ("untile_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
     ("abi_version", C.c_int, []),
     ("device_count", C.c_int, []),
     ("scene_info", C.c_int, [scene_p, C.POINTER(Stats)]),

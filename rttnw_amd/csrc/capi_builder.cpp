@@ -1,0 +1,215 @@
+// capi_builder.cpp — the scene-description half of include/rttnw_hip.h: each call records one node
+// of the graph the reference would have built out of Box/Arc<dyn ...> objects (src/scenes.rs is
+// the model caller).  Nothing is evaluated here; rttnw_scene_commit lowers and uploads.
+#include "../../include/rttnw_hip.h"
+#include "scene_handle.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace {
+thread_local std::string g_last_error;
+
+int fail(int code, const char* msg) {
+    g_last_error = msg;
+    return code;
+}
+using rt::GraphObj;
+
+int check_open(rttnw_scene* s) {
+    if (!s) return fail(RTTNW_ERR_INVALID, "scene is NULL");
+    if (s->committed) return fail(RTTNW_ERR_STATE, "scene is committed and immutable");
+    return RTTNW_OK;
+}
+rttnw_id push(rttnw_scene* s, GraphObj&& o) {
+    s->graph.objs.push_back(std::move(o));
+    return rttnw_id(s->graph.objs.size() - 1);
+}
+} // namespace
+
+namespace rt {
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+} // namespace rt
+
+extern "C" {
+
+int rttnw_abi_version(void) { return RTTNW_ABI_VERSION; }
+const char* rttnw_last_error(void) { return g_last_error.c_str(); }
+
+int rttnw_scene_create(uint64_t scene_seed, rttnw_scene** out) {
+    if (!out) return fail(RTTNW_ERR_INVALID, "out is NULL");
+    rttnw_scene* s = new (std::nothrow) rttnw_scene();
+    if (!s) return fail(RTTNW_ERR_NOMEM, "out of memory");
+    s->graph.seed = scene_seed;
+    *out = s;
+    return RTTNW_OK;
+}
+
+void rttnw_scene_destroy(rttnw_scene* s) {
+    if (!s) return;
+    if (s->device) rt::device_release(s->device);
+    delete s;
+}
+
+// ---- textures
+rttnw_id rttnw_tex_solid(rttnw_scene* s, double r, double g, double b) {
+    if (int rc = check_open(s)) return rc;
+    GraphObj o; o.kind = GraphObj::TEX_SOLID_K; o.v[0] = r; o.v[1] = g; o.v[2] = b;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_tex_checker(rttnw_scene* s, rttnw_id odd, rttnw_id even) {
+    if (int rc = check_open(s)) return rc;
+    if (!s->graph.is_texture(odd) || !s->graph.is_texture(even)) return fail(RTTNW_ERR_INVALID, "tex_checker: bad texture id");
+    GraphObj o; o.kind = GraphObj::TEX_CHECKER_K; o.a = odd; o.b = even;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_tex_noise(rttnw_scene* s, double scale) {
+    if (int rc = check_open(s)) return rc;
+    GraphObj o; o.kind = GraphObj::TEX_NOISE_K; o.v[0] = scale; o.a = int32_t(s->graph.n_noise++);
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_tex_image_rgba8(rttnw_scene* s, const uint8_t* rgba, uint32_t w, uint32_t h) {
+    if (int rc = check_open(s)) return rc;
+    GraphObj o; o.kind = GraphObj::TEX_IMAGE_K; o.a = -1;
+    if (rgba && w && h) {
+        s->graph.image_data.emplace_back(rgba, rgba + size_t(w) * h * 4);
+        s->graph.image_w.push_back(w);
+        s->graph.image_h.push_back(h);
+        o.a = int32_t(s->graph.image_data.size() - 1);
+    }
+    return push(s, std::move(o));
+}
+
+// ---- materials
+static rttnw_id push_material(rttnw_scene* s, int type, rttnw_id tex, double r, double g, double b, double param) {
+    GraphObj o; o.kind = GraphObj::MAT_K; o.c = type; o.a = tex;
+    o.v[0] = r; o.v[1] = g; o.v[2] = b; o.v[3] = param;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_mat_lambertian(rttnw_scene* s, rttnw_id tex) {
+    if (int rc = check_open(s)) return rc;
+    if (!s->graph.is_texture(tex)) return fail(RTTNW_ERR_INVALID, "mat_lambertian: bad texture id");
+    return push_material(s, rt::MAT_LAMBERTIAN, tex, 0, 0, 0, 0);
+}
+rttnw_id rttnw_mat_metal(rttnw_scene* s, double r, double g, double b, double fuzz) {
+    if (int rc = check_open(s)) return rc;
+    return push_material(s, rt::MAT_METAL, -1, r, g, b, std::fmin(fuzz, 1.0)); // material.rs:129
+}
+rttnw_id rttnw_mat_dielectric(rttnw_scene* s, double ri) {
+    if (int rc = check_open(s)) return rc;
+    return push_material(s, rt::MAT_DIELECTRIC, -1, 0, 0, 0, ri);
+}
+rttnw_id rttnw_mat_diffuse_light(rttnw_scene* s, rttnw_id tex) {
+    if (int rc = check_open(s)) return rc;
+    if (!s->graph.is_texture(tex)) return fail(RTTNW_ERR_INVALID, "mat_diffuse_light: bad texture id");
+    return push_material(s, rt::MAT_DIFFUSE_LIGHT, tex, 0, 0, 0, 0);
+}
+rttnw_id rttnw_mat_isotropic(rttnw_scene* s, rttnw_id tex) {
+    if (int rc = check_open(s)) return rc;
+    if (!s->graph.is_texture(tex)) return fail(RTTNW_ERR_INVALID, "mat_isotropic: bad texture id");
+    return push_material(s, rt::MAT_ISOTROPIC, tex, 0, 0, 0, 0);
+}
+
+// ---- hittables
+rttnw_id rttnw_sphere(rttnw_scene* s, const double c[3], double radius, rttnw_id mat) {
+    if (int rc = check_open(s)) return rc;
+    if (!c || !s->graph.is_material(mat)) return fail(RTTNW_ERR_INVALID, "sphere: bad material id");
+    GraphObj o; o.kind = GraphObj::SPHERE_K; o.v[0] = c[0]; o.v[1] = c[1]; o.v[2] = c[2]; o.v[3] = radius; o.a = mat;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_moving_sphere(rttnw_scene* s, const double c0[3], const double c1[3], double t0, double t1, double radius,
+                             rttnw_id mat) {
+    if (int rc = check_open(s)) return rc;
+    if (!c0 || !c1 || !s->graph.is_material(mat)) return fail(RTTNW_ERR_INVALID, "moving_sphere: bad material id");
+    GraphObj o; o.kind = GraphObj::MOVING_K;
+    for (int k = 0; k < 3; ++k) { o.v[k] = c0[k]; o.v[3 + k] = c1[k]; }
+    o.v[6] = t0; o.v[7] = t1; o.v[8] = radius; o.a = mat;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_rectangle(rttnw_scene* s, int plane, double a0, double a1, double b0, double b1, double k, rttnw_id mat) {
+    if (int rc = check_open(s)) return rc;
+    if (plane < 0 || plane > 2 || !s->graph.is_material(mat)) return fail(RTTNW_ERR_INVALID, "rectangle: bad plane or material id");
+    GraphObj o; o.kind = GraphObj::RECT_K; o.v[0] = a0; o.v[1] = a1; o.v[2] = b0; o.v[3] = b1; o.v[4] = k; o.c = plane; o.a = mat;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_cube(rttnw_scene* s, const double mn[3], const double mx[3], rttnw_id mat) {
+    if (int rc = check_open(s)) return rc;
+    if (!mn || !mx || !s->graph.is_material(mat)) return fail(RTTNW_ERR_INVALID, "cube: bad material id");
+    GraphObj o; o.kind = GraphObj::CUBE_K;
+    for (int k = 0; k < 3; ++k) { o.v[k] = mn[k]; o.v[3 + k] = mx[k]; }
+    o.a = mat;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_list(rttnw_scene* s) {
+    if (int rc = check_open(s)) return rc;
+    GraphObj o; o.kind = GraphObj::LIST_K;
+    return push(s, std::move(o));
+}
+int rttnw_list_push(rttnw_scene* s, rttnw_id list, rttnw_id item) {
+    if (int rc = check_open(s)) return rc;
+    auto& g = s->graph;
+    if (!g.is_hittable(list) || g.objs[list].kind != GraphObj::LIST_K) return fail(RTTNW_ERR_INVALID, "list_push: bad list id");
+    if (!g.is_hittable(item) || item == list) return fail(RTTNW_ERR_INVALID, "list_push: bad item id");
+    g.objs[list].items.push_back(item);
+    return RTTNW_OK;
+}
+rttnw_id rttnw_bvh_tree(rttnw_scene* s, rttnw_id list) {
+    if (int rc = check_open(s)) return rc;
+    auto& g = s->graph;
+    if (!g.is_hittable(list) || g.objs[list].kind != GraphObj::LIST_K) return fail(RTTNW_ERR_INVALID, "bvh_tree: bad list id");
+    if (g.objs[list].items.empty()) return fail(RTTNW_ERR_INVALID, "bvh_tree: empty list");
+    GraphObj o; o.kind = GraphObj::BVH_K; o.items = g.objs[list].items;
+    g.objs[list].consumed = true; // BvhTree::from(list) takes the list by value — hittable.rs:254-258
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_translate(rttnw_scene* s, rttnw_id item, const double off[3]) {
+    if (int rc = check_open(s)) return rc;
+    if (!off || !s->graph.is_hittable(item)) return fail(RTTNW_ERR_INVALID, "translate: bad item id");
+    GraphObj o; o.kind = GraphObj::TRANSLATE_K; o.a = item; o.v[0] = off[0]; o.v[1] = off[1]; o.v[2] = off[2];
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_rotate_y(rttnw_scene* s, rttnw_id item, double deg) {
+    if (int rc = check_open(s)) return rc;
+    if (!s->graph.is_hittable(item)) return fail(RTTNW_ERR_INVALID, "rotate_y: bad item id");
+    GraphObj o; o.kind = GraphObj::ROTATE_K; o.a = item; o.v[0] = deg;
+    return push(s, std::move(o));
+}
+rttnw_id rttnw_constant_medium(rttnw_scene* s, rttnw_id boundary, double density, rttnw_id tex) {
+    if (int rc = check_open(s)) return rc;
+    if (!s->graph.is_hittable(boundary) || !s->graph.is_texture(tex)) return fail(RTTNW_ERR_INVALID, "constant_medium: bad boundary or texture id");
+    // phase_function: Isotropic { albedo } — hittable.rs:733
+    rttnw_id iso = push_material(s, rt::MAT_ISOTROPIC, tex, 0, 0, 0, 0);
+    GraphObj o; o.kind = GraphObj::MEDIUM_K; o.a = boundary; o.b = iso; o.v[0] = density; o.c = int32_t(s->n_media++);
+    return push(s, std::move(o));
+}
+int rttnw_scene_set_world(rttnw_scene* s, rttnw_id world) {
+    if (int rc = check_open(s)) return rc;
+    auto& g = s->graph;
+    if (!g.is_hittable(world) || g.objs[world].kind != GraphObj::LIST_K) return fail(RTTNW_ERR_INVALID, "set_world: bad list id");
+    g.world = world;
+    return RTTNW_OK;
+}
+int rttnw_scene_commit(rttnw_scene* s) {
+    if (!s) return fail(RTTNW_ERR_INVALID, "scene is NULL");
+    if (s->committed) return RTTNW_OK; // idempotent
+    std::string err;
+    int rc = rt::lower_scene(s->graph, s->flat, err);
+    if (rc) return fail(rc, err.c_str());
+    rc = rt::device_commit(s, err);
+    if (rc) return fail(rc, err.c_str());
+    s->committed = true;
+    return RTTNW_OK;
+}
+
+const rttnw_builder_api* rttnw_builder(void) {
+    static const rttnw_builder_api api = {
+        rttnw_scene_create, rttnw_scene_destroy, rttnw_tex_solid, rttnw_tex_checker, rttnw_tex_noise,
+        rttnw_tex_image_rgba8, rttnw_mat_lambertian, rttnw_mat_metal, rttnw_mat_dielectric,
+        rttnw_mat_diffuse_light, rttnw_mat_isotropic, rttnw_sphere, rttnw_moving_sphere, rttnw_rectangle,
+        rttnw_cube, rttnw_list, rttnw_list_push, rttnw_bvh_tree, rttnw_translate, rttnw_rotate_y,
+        rttnw_constant_medium, rttnw_scene_set_world, rttnw_scene_commit, rttnw_last_error};
+    return &api;
+}
+
+} // extern "C"

@@ -1,0 +1,730 @@
+// rt_core.hpp — the per-lane tracing core: one path per lane, written as branch-flattened
+// __host__ __device__ inline functions over the flat scene of rt_types.hpp.
+//
+// What the reference does by recursion over trait objects (color() main.rs:26-45 -> List::hit ->
+// BvhTree::hit -> Sphere/Rectangle/Cube/Translate/YRotate/ConstantMedium::hit -> Material::scatter
+// -> Texture::value), a lane does here as: stack-driven flat-BVH walk that only tracks
+// (t, primitive, instance) -> one hit-record reconstruction for the winner -> media -> shade.
+// Arithmetic follows the reference's formulas (cited per function) so that the f64 instantiation
+// agrees with the oracle to rounding; R = float is the throughput instantiation.
+#pragma once
+#include "rt_types.hpp"
+#include <math.h>
+
+namespace rt {
+
+// ---------------------------------------------------------------- math wrappers
+RT_HD float rt_sqrt(float x) { return sqrtf(x); }
+RT_HD double rt_sqrt(double x) { return sqrt(x); }
+RT_HD float rt_sin(float x) { return sinf(x); }
+RT_HD double rt_sin(double x) { return sin(x); }
+RT_HD float rt_log(float x) { return logf(x); }
+RT_HD double rt_log(double x) { return log(x); }
+RT_HD float rt_acos(float x) { return acosf(x); }
+RT_HD double rt_acos(double x) { return acos(x); }
+RT_HD float rt_atan2(float y, float x) { return atan2f(y, x); }
+RT_HD double rt_atan2(double y, double x) { return atan2(y, x); }
+RT_HD float rt_floor(float x) { return floorf(x); }
+RT_HD double rt_floor(double x) { return floor(x); }
+RT_HD float rt_fabs(float x) { return fabsf(x); }
+RT_HD double rt_fabs(double x) { return fabs(x); }
+// IEEE minNum/maxNum: return the non-NaN operand, like Rust's f64::min/max (bound.rs:25-26)
+RT_HD float rt_min(float a, float b) { return fminf(a, b); }
+RT_HD double rt_min(double a, double b) { return fmin(a, b); }
+RT_HD float rt_max(float a, float b) { return fmaxf(a, b); }
+RT_HD double rt_max(double a, double b) { return fmax(a, b); }
+
+template <typename R> struct Lim;
+template <> struct Lim<float> {
+    static RT_HD float inf() { return __builtin_huge_valf(); }
+    static RT_HD float max() { return 3.402823466e+38f; }
+};
+template <> struct Lim<double> {
+    static RT_HD double inf() { return __builtin_huge_val(); }
+    static RT_HD double max() { return 1.7976931348623157e+308; }
+};
+
+// ---------------------------------------------------------------- Vec3f (vec3.rs:27-262)
+template <typename R> struct V3 {
+    R x, y, z;
+    RT_HD V3() : x(0), y(0), z(0) {}
+    RT_HD V3(R a, R b, R c) : x(a), y(b), z(c) {}
+    RT_HD explicit V3(const R* p) : x(p[0]), y(p[1]), z(p[2]) {}
+    RT_HD R get(int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+template <typename R> RT_HD V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename R> RT_HD V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename R> RT_HD V3<R> operator*(V3<R> a, V3<R> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+template <typename R> RT_HD V3<R> operator*(V3<R> a, R k) { return {a.x * k, a.y * k, a.z * k}; }
+template <typename R> RT_HD V3<R> operator*(R k, V3<R> a) { return {a.x * k, a.y * k, a.z * k}; }
+template <typename R> RT_HD V3<R> operator/(V3<R> a, R k) { return {a.x / k, a.y / k, a.z / k}; }
+template <typename R> RT_HD V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+template <typename R> RT_HD R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // vec3.rs:77
+template <typename R> RT_HD R squared_length(V3<R> a) { return a.x * a.x + a.y * a.y + a.z * a.z; } // vec3.rs:93
+template <typename R> RT_HD R magnitude(V3<R> a) { return rt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); } // vec3.rs:90
+template <typename R> RT_HD V3<R> unit(V3<R> a) { R k = R(1) / magnitude(a); return a * k; }          // vec3.rs:97
+template <typename R> RT_HD V3<R> reflect(V3<R> v, V3<R> n) { return v - R(2) * dot(v, n) * n; }      // vec3.rs:112
+template <typename R> RT_HD V3<R> refract(V3<R> v, V3<R> n, R eta) {                                  // vec3.rs:116-121
+    R cos_theta = rt_min(dot(-v, n), R(1));
+    V3<R> perp = eta * (v + cos_theta * n);
+    V3<R> par = -rt_sqrt(rt_fabs(R(1) - squared_length(perp))) * n;
+    return perp + par;
+}
+
+template <typename R> struct Ray { // ray.rs:9-27
+    V3<R> o, d;
+    R time;
+    RT_HD V3<R> at(R t) const { return o + t * d; }
+};
+
+// ---------------------------------------------------------------- keyed RNG (DESIGN.md "RNG")
+// U = mix64(key + (ctr+1)*GAMMA) with key = f(seed, pixel, sample): every draw is addressed by
+// (pixel, sample, bounce, slot), so results do not depend on traversal order, lane assignment,
+// work stealing or GPU count.  f64 uniform = top 53 bits, f32 uniform = top 24 bits of the SAME word.
+constexpr uint64_t RNG_GAMMA = 0x9E3779B97F4A7C15ull;
+RT_HD uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+RT_HD uint64_t sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
+    uint64_t k0 = mix64(seed + RNG_GAMMA);
+    uint64_t k1 = mix64(k0 + pixel * 0xD1B54A32D192ED03ull);
+    return mix64(k1 + sample * 0x8CB92BA72F3D8DD7ull);
+}
+RT_HD uint64_t rng_word(uint64_t key, uint32_t ctr) { return mix64(key + (uint64_t(ctr) + 1) * RNG_GAMMA); }
+template <typename R> RT_HD R uniform01(uint64_t key, uint32_t ctr);
+template <> RT_HD double uniform01<double>(uint64_t key, uint32_t ctr) {
+    return double(rng_word(key, ctr) >> 11) * (1.0 / 9007199254740992.0);
+}
+template <> RT_HD float uniform01<float>(uint64_t key, uint32_t ctr) {
+    return float(uint32_t(rng_word(key, ctr) >> 40)) * (1.0f / 16777216.0f);
+}
+// counter = block * 1024 + slot; block 0 = camera, block b+1 = b-th world.hit() of the path
+enum : uint32_t { SLOT_JITTER_U = 0, SLOT_JITTER_V = 1, SLOT_TIME = 2, SLOT_LENS = 8,
+                  SLOT_MEDIUM = 0, SLOT_DIELECTRIC = 16, SLOT_SCATTER = 32 };
+RT_HD uint32_t rng_ctr(uint32_t block, uint32_t slot) { return block * 1024u + slot; }
+
+// Vec3f::random_in_unit_space — vec3.rs:149-160: rejection sampling of the unit BALL
+template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bounce) {
+    uint32_t c = rng_ctr(bounce + 1, SLOT_SCATTER);
+    for (;;) {
+        V3<R> r(uniform01<R>(key, c), uniform01<R>(key, c + 1), uniform01<R>(key, c + 2));
+        V3<R> v = R(2) * r - V3<R>(R(1), R(1), R(1));
+        if (squared_length(v) < R(1)) return v;
+        c += 3;
+    }
+}
+
+// ---------------------------------------------------------------- counters (instrumentation)
+struct NoCounters {
+    RT_HD void ray() {}
+    RT_HD void node() {}
+    RT_HD void prim() {}
+    RT_HD void texel() {}
+};
+struct LaneCounters {
+    uint32_t rays = 0, nodes = 0, prims = 0, texels = 0;
+    RT_HD void ray() { ++rays; }
+    RT_HD void node() { ++nodes; }
+    RT_HD void prim() { ++prims; }
+    RT_HD void texel() { ++texels; }
+};
+
+// ---------------------------------------------------------------- camera (camera.rs:63-84)
+template <typename R>
+RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key) {
+    // random_in_unit_disk runs even when lens_radius == 0 (Q15); with a zero radius its value
+    // cannot matter, so the loop is skipped then — the draws are keyed, nothing shifts.
+    R px = 0, py = 0;
+    if (cam.lens_radius != R(0)) {
+        uint32_t c = rng_ctr(0, SLOT_LENS);
+        for (;;) {
+            px = R(2) * uniform01<R>(key, c) - R(1);
+            py = R(2) * uniform01<R>(key, c + 1) - R(1);
+            if (px * px + py * py + R(0) < R(1)) break;
+            c += 2;
+        }
+    }
+    R rdx = cam.lens_radius * px, rdy = cam.lens_radius * py;
+    V3<R> offset = V3<R>(cam.u) * rdx + V3<R>(cam.v) * rdy;
+    Ray<R> r;
+    r.o = V3<R>(cam.origin) + offset;
+    r.d = V3<R>(cam.lower_left_corner) + s * V3<R>(cam.horizontal) + t * V3<R>(cam.vertical) - V3<R>(cam.origin) - offset;
+    r.time = cam.open_time + (cam.close_time - cam.open_time) * uniform01<R>(key, rng_ctr(0, SLOT_TIME));
+    return r;
+}
+
+// ---------------------------------------------------------------- AABB slab test (bound.rs:13-32)
+// The three per-axis early-outs of the reference collapse into one comparison: tmin only grows and
+// tmax only shrinks, so `tmax < tmin` at the end <=> it held at some axis.
+template <typename R> struct SlabSlack { static RT_HD R widen(R tmax) { return tmax; } };
+template <> struct SlabSlack<float> { // f32: absorb rounding of (bound - o) * inv (boxes are already padded)
+    static RT_HD float widen(float tmax) { return tmax > 0.f ? tmax * 1.0000005f : tmax; }
+};
+template <typename R>
+RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, V3<R> inv, R tmin, R tmax, R& t_enter) {
+    R t0x = (R(lo[0]) - o.x) * inv.x, t1x = (R(hi[0]) - o.x) * inv.x;
+    R t0y = (R(lo[1]) - o.y) * inv.y, t1y = (R(hi[1]) - o.y) * inv.y;
+    R t0z = (R(lo[2]) - o.z) * inv.z, t1z = (R(hi[2]) - o.z) * inv.z;
+    R nx = inv.x < R(0) ? t1x : t0x, fx = inv.x < R(0) ? t0x : t1x;
+    R ny = inv.y < R(0) ? t1y : t0y, fy = inv.y < R(0) ? t0y : t1y;
+    R nz = inv.z < R(0) ? t1z : t0z, fz = inv.z < R(0) ? t0z : t1z;
+    tmin = rt_max(nz, rt_max(ny, rt_max(nx, tmin)));
+    tmax = rt_min(fz, rt_min(fy, rt_min(fx, tmax)));
+    t_enter = tmin;
+    return !(SlabSlack<R>::widen(tmax) < tmin);
+}
+
+// ---------------------------------------------------------------- primitive tests: t only
+// Sphere::hit — hittable.rs:87-109 (bounds inclusive: only `<` / `>` reject, Q10)
+template <typename R>
+RT_HD bool sphere_t(V3<R> center, R radius, const Ray<R>& ray, R t_min, R t_max, R& t_out) {
+    V3<R> oc = ray.o - center;
+    R a = dot(ray.d, ray.d);
+    R half_b = dot(oc, ray.d);
+    R c = dot(oc, oc) - radius * radius;
+    R disc = half_b * half_b - a * c;
+    if (disc < R(0)) return false;
+    R sqrtd = rt_sqrt(disc);
+    R root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    t_out = root;
+    return true;
+}
+// MovingSphere::center — hittable.rs:187-191
+template <typename R> RT_HD V3<R> moving_center(const MovingSphereRec<R>& m, R time) {
+    return V3<R>(m.c0) + ((time - m.t0) / (m.t1 - m.t0)) * (V3<R>(m.c1) - V3<R>(m.c0));
+}
+// Rectangle::hit — hittable.rs:503-513 (half-open extents, Q9).  plane: 0 XY, 1 XZ, 2 YZ.
+template <typename R>
+RT_HD bool rect_t(int plane, R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, R t_min, R t_max, R& t_out, R& a_out, R& b_out) {
+    // (axis0, axis1, k-axis): XY -> (x,y,z); XZ -> (x,z,y); YZ -> (y,z,x) — hittable.rs:450-488
+    R ok = plane == 0 ? ray.o.z : (plane == 1 ? ray.o.y : ray.o.x);
+    R dk = plane == 0 ? ray.d.z : (plane == 1 ? ray.d.y : ray.d.x);
+    R oa = plane == 2 ? ray.o.y : ray.o.x, da = plane == 2 ? ray.d.y : ray.d.x;
+    R ob = plane == 0 ? ray.o.y : ray.o.z, db = plane == 0 ? ray.d.y : ray.d.z;
+    R t = (k - ok) / dk;
+    if (t < t_min || t > t_max) return false;
+    R a = oa + t * da;
+    R b = ob + t * db;
+    if (!(a0 <= a && a < a1) || !(b0 <= b && b < b1)) return false;
+    t_out = t; a_out = a; b_out = b;
+    return true;
+}
+// Cube::hit = List::hit over its six rectangles in the order xy@min.z, xy@max.z, xz@min.y, xz@max.y,
+// yz@min.x, yz@max.x with a shrinking `closest` (hittable.rs:560-569,153-163).  Returns the winning
+// face index in `face` (later face wins exact ties, like the List).
+template <typename R>
+RT_HD bool box_t(const BoxRec<R>& bx, const Ray<R>& ray, R t_min, R t_max, R& t_out, int& face, R& a_out, R& b_out) {
+    bool any = false;
+    R closest = t_max;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const int plane = f >> 1; // 0 XY, 1 XZ, 2 YZ
+        R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
+        R b0 = plane == 0 ? bx.mn[1] : bx.mn[2], b1 = plane == 0 ? bx.mx[1] : bx.mx[2];
+        const int kaxis = plane == 0 ? 2 : (plane == 1 ? 1 : 0);
+        R k = (f & 1) ? bx.mx[kaxis] : bx.mn[kaxis];
+        R t, a, b;
+        if (rect_t(plane, a0, a1, b0, b1, k, ray, t_min, closest, t, a, b)) {
+            closest = t; face = f; a_out = a; b_out = b; any = true;
+        }
+    }
+    t_out = closest;
+    return any;
+}
+
+// Ray -> object space through an instance's ops (Translate::hit :600-604, YRotate::hit :687-697)
+template <typename R> RT_HD Ray<R> to_object(const InstanceRec<R>& in, Ray<R> ray) {
+#pragma unroll
+    for (int i = 0; i < MAX_INSTANCE_OPS; ++i) {
+        if (i < in.n_ops) {
+            if (in.ops[i].type == OP_TRANSLATE) {
+                ray.o = ray.o - V3<R>(in.ops[i].v);
+            } else {
+                R s = in.ops[i].v[0], c = in.ops[i].v[1];
+                R ox = c * ray.o.x - s * ray.o.z, oz = s * ray.o.x + c * ray.o.z;
+                R dx = c * ray.d.x - s * ray.d.z, dz = s * ray.d.x + c * ray.d.z;
+                ray.o.x = ox; ray.o.z = oz; ray.d.x = dx; ray.d.z = dz;
+            }
+        }
+    }
+    return ray;
+}
+
+// Rectangle hit coordinates at parameter t, no range checks (used to rebuild the winner's record).
+template <typename R> RT_HD void rect_ab(int plane, const Ray<R>& ray, R t, R& a, R& b) {
+    R oa = plane == 2 ? ray.o.y : ray.o.x, da = plane == 2 ? ray.d.y : ray.d.x;
+    R ob = plane == 0 ? ray.o.y : ray.o.z, db = plane == 0 ? ray.d.y : ray.d.z;
+    a = oa + t * da;
+    b = ob + t * db;
+}
+
+// One primitive, t only (+ `aux`: the winning face of a box).  `ray` is in the primitive's space.
+template <typename R>
+RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray<R>& ray, R t_min, R t_max, R& t, int& aux) {
+    if (kind == PRIM_SPHERE) {
+        SphereRec<R> s = sc.spheres[idx];
+        return sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, ray, t_min, t_max, t);
+    } else if (kind == PRIM_BOX) {
+        R a, b;
+        return box_t(sc.boxes[idx], ray, t_min, t_max, t, aux, a, b);
+    } else if (kind == PRIM_RECT) {
+        const RectRec<R>& r = sc.rects[idx];
+        R a, b;
+        return rect_t(r.plane, r.a0, r.a1, r.b0, r.b1, r.k, ray, t_min, t_max, t, a, b);
+    } else if (kind == PRIM_MOVING_SPHERE) {
+        const MovingSphereRec<R>& m = sc.moving[idx];
+        return sphere_t(moving_center(m, ray.time), m.r, ray, t_min, t_max, t);
+    }
+    return false;
+}
+
+// Sequence number of a primitive record (tie-break only; see rt_types.hpp).
+template <typename R> RT_HD int32_t prim_seq(const SceneView<R>& sc, uint32_t kind, uint32_t idx) {
+    if (kind == PRIM_SPHERE) return sc.sphere_seq[idx];
+    if (kind == PRIM_BOX) return sc.boxes[idx].seq;
+    if (kind == PRIM_RECT) return sc.rects[idx].seq;
+    return sc.moving[idx].seq;
+}
+
+struct HitRef {
+    int32_t prim; // make_ref(kind, index); kind PRIM_NONE = miss
+    int32_t inst; // enclosing instance or -1
+    int32_t aux;  // box: winning face 0..5
+};
+
+// ---------------------------------------------------------------- closest solid hit
+// Flat-BVH walk with a per-lane stack (LDS on the device).  Semantics of the reference's
+// List::hit / BvhTree::hit: closest t in [t_min, t_max], a candidate with t == closest replaces
+// the incumbent (hittable.rs:157-159,366-367).  Only (t, primitive, instance) are tracked here;
+// the hit record is rebuilt once for the winner (Q11: same result, far fewer acos/atan2).
+template <typename R, typename Stack, typename Cnt>
+RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R& closest, HitRef& best, Stack& stack, Cnt& cnt) {
+    Ray<R> ray = wray;
+    V3<R> inv(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
+    int sp = 0;
+    int32_t node = sc.top_root;
+    int32_t cur_inst = -1;
+    bool found = false;
+    for (;;) {
+        if (node >= 0) {
+            const BvhNode nd = sc.nodes[node];
+            cnt.node();
+            R e0, e1;
+            bool h0 = slab_hit(nd.lo0, nd.hi0, ray.o, inv, t_min, closest, e0);
+            bool h1 = slab_hit(nd.lo1, nd.hi1, ray.o, inv, t_min, closest, e1);
+            if (h0 && h1) {
+                bool swap = e1 < e0; // nearer child first
+                stack.set(sp++, swap ? nd.child0 : nd.child1);
+                node = swap ? nd.child1 : nd.child0;
+                continue;
+            }
+            if (h0) { node = nd.child0; continue; }
+            if (h1) { node = nd.child1; continue; }
+        } else if (node != CHILD_EMPTY) {
+            uint32_t kind = leaf_kind(node), count = leaf_count(node), first = leaf_first(node);
+            if (kind == PRIM_INSTANCE) {
+                cnt.prim();
+                const InstanceRec<R>& in = sc.insts[first];
+                stack.set(sp++, STACK_SENTINEL);
+                ray = to_object(in, wray);
+                inv = V3<R>(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
+                cur_inst = int32_t(first);
+                node = in.root;
+                continue;
+            }
+            for (uint32_t k = 0; k < count; ++k) {
+                R t;
+                int aux = 0;
+                cnt.prim();
+                if (prim_t(sc, kind, first + k, ray, t_min, closest, t, aux)) {
+                    // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
+                    if (found && t == closest &&
+                        prim_seq(sc, kind, first + k) < prim_seq(sc, ref_kind(best.prim), ref_index(best.prim)))
+                        continue;
+                    closest = t;
+                    best.prim = make_ref(kind, first + k);
+                    best.inst = cur_inst;
+                    best.aux = aux;
+                    found = true;
+                }
+            }
+        }
+        if (sp == 0) break;
+        node = stack.get(--sp);
+        if (node == STACK_SENTINEL) {
+            ray = wray;
+            inv = V3<R>(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
+            cur_inst = -1;
+            if (sp == 0) break;
+            node = stack.get(--sp);
+        }
+    }
+    return found;
+}
+
+// ---------------------------------------------------------------- hit record of the winner
+template <typename R> struct HitRecord { // hittable.rs:15-27
+    R t;
+    V3<R> p, normal;
+    R u, v;
+    int32_t mat;
+    bool front_face;
+};
+template <typename R> RT_HD void face_normal(V3<R> dir, V3<R> outward, V3<R>& normal, bool& front) { // hittable.rs:30-44
+    front = dot(dir, outward) < R(0);
+    normal = front ? outward : -outward;
+}
+template <typename R> RT_HD void sphere_uv(V3<R> p, R& u, R& v) { // hittable.rs:77-83
+    const R pi = R(3.14159265358979323846264338327950288);
+    R theta = rt_acos(-p.y);
+    R phi = rt_atan2(-p.z, p.x) + pi;
+    u = phi / (R(2) * pi);
+    v = theta / pi;
+}
+
+template <typename R>
+RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
+    const uint32_t kind = ref_kind(ref.prim), idx = ref_index(ref.prim);
+    Ray<R> ray = wray;
+    if (ref.inst >= 0) ray = to_object(sc.insts[ref.inst], wray);
+    rec.t = t;
+    V3<R> outward;
+    if (kind == PRIM_SPHERE) { // hittable.rs:109-113
+        SphereRec<R> s = sc.spheres[idx];
+        V3<R> c(s.cx, s.cy, s.cz);
+        rec.p = ray.at(t);
+        outward = (rec.p - c) / s.r;
+        sphere_uv(outward, rec.u, rec.v);
+        rec.mat = sc.sphere_mat[idx];
+    } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
+        const MovingSphereRec<R>& m = sc.moving[idx];
+        rec.p = ray.at(t);
+        outward = (rec.p - moving_center(m, ray.time)) / m.r;
+        rec.u = R(0); rec.v = R(0);
+        rec.mat = m.mat;
+    } else if (kind == PRIM_RECT) { // hittable.rs:515-519
+        const RectRec<R>& r = sc.rects[idx];
+        R a, b;
+        rect_ab(r.plane, ray, t, a, b);
+        rec.u = (a - r.a0) / (r.a1 - r.a0);
+        rec.v = (b - r.b0) / (r.b1 - r.b0);
+        outward = V3<R>(r.plane == 2 ? R(1) : R(0), r.plane == 1 ? R(1) : R(0), r.plane == 0 ? R(1) : R(0));
+        rec.p = ray.at(t);
+        rec.mat = r.mat;
+    } else { // PRIM_BOX: the winning face's rectangle record
+        const BoxRec<R>& bx = sc.boxes[idx];
+        const int plane = ref.aux >> 1;
+        R a, b;
+        rect_ab(plane, ray, t, a, b);
+        R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
+        R b0 = plane == 0 ? bx.mn[1] : bx.mn[2], b1 = plane == 0 ? bx.mx[1] : bx.mx[2];
+        rec.u = (a - a0) / (a1 - a0);
+        rec.v = (b - b0) / (b1 - b0);
+        outward = V3<R>(plane == 2 ? R(1) : R(0), plane == 1 ? R(1) : R(0), plane == 0 ? R(1) : R(0));
+        rec.p = ray.at(t);
+        rec.mat = bx.mat;
+    }
+    face_normal(ray.d, outward, rec.normal, rec.front_face);
+
+    if (ref.inst >= 0) {
+        // Unwind the wrappers innermost-first.  Level i's face_normal uses the ray as it was AFTER
+        // ops[0..i] were applied (Translate: `moved_ray` :607; YRotate: the rotated `ray` :706).
+        const InstanceRec<R>& in = sc.insts[ref.inst];
+        V3<R> dirs[MAX_INSTANCE_OPS];
+        {
+            Ray<R> r = wray;
+#pragma unroll
+            for (int i = 0; i < MAX_INSTANCE_OPS; ++i) {
+                if (i < in.n_ops) {
+                    if (in.ops[i].type == OP_ROTATE_Y) {
+                        R s = in.ops[i].v[0], c = in.ops[i].v[1];
+                        R dx = c * r.d.x - s * r.d.z, dz = s * r.d.x + c * r.d.z;
+                        r.d.x = dx; r.d.z = dz;
+                    }
+                }
+                dirs[i] = r.d;
+            }
+        }
+#pragma unroll
+        for (int i = MAX_INSTANCE_OPS - 1; i >= 0; --i) {
+            if (i < in.n_ops) {
+                if (in.ops[i].type == OP_ROTATE_Y) { // hittable.rs:700-706
+                    R s = in.ops[i].v[0], c = in.ops[i].v[1];
+                    R px = c * rec.p.x + s * rec.p.z;
+                    R nx = c * rec.normal.x + s * rec.normal.z;
+                    // Q1: the reference's z line reads the x it has just overwritten
+                    R pxz = (quirks & 1u) ? px : rec.p.x;
+                    R nxz = (quirks & 1u) ? nx : rec.normal.x;
+                    R pz = -s * pxz + c * rec.p.z;
+                    R nz = -s * nxz + c * rec.normal.z;
+                    rec.p.x = px; rec.p.z = pz;
+                    rec.normal.x = nx; rec.normal.z = nz;
+                } else { // hittable.rs:607-611
+                    rec.p = rec.p + V3<R>(in.ops[i].v);
+                }
+                V3<R> n; bool ff;
+                face_normal(dirs[i], rec.normal, n, ff);
+                rec.normal = n; rec.front_face = ff;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- world.hit (main.rs:33)
+// Solids through the BVH, then the constant media in creation order with the shrinking `closest`
+// they would see in the reference's world List (hittable.rs:740-796, Q13).
+template <typename R, typename Stack, typename Cnt>
+RT_HD bool world_hit(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_t key, uint32_t bounce, uint32_t quirks,
+                     HitRecord<R>& rec, Stack& stack, Cnt& cnt) {
+    cnt.ray();
+    R closest = Lim<R>::max();
+    HitRef best;
+    best.prim = make_ref(PRIM_NONE, 0);
+    best.inst = -1;
+    best.aux = 0;
+    bool found = closest_solid(sc, ray, t_min, closest, best, stack, cnt);
+    int32_t medium = -1;
+    for (int32_t m = 0; m < sc.n_media; ++m) {
+        const MediumRec<R>& md = sc.media[m];
+        Ray<R> bray = md.inst >= 0 ? to_object(sc.insts[md.inst], ray) : ray;
+        const uint32_t bk = ref_kind(md.boundary), bi = ref_index(md.boundary);
+        R t1, t2;
+        int aux;
+        cnt.prim();
+        if (!prim_t(sc, bk, bi, bray, -Lim<R>::inf(), Lim<R>::inf(), t1, aux)) continue;
+        cnt.prim();
+        if (!prim_t(sc, bk, bi, bray, t1 + R(0.0001), Lim<R>::inf(), t2, aux)) continue;
+        t1 = rt_max(t1, t_min);
+        t2 = rt_min(t2, closest);
+        if (t1 >= t2) continue; // before any draw
+        t1 = rt_max(t1, R(0));
+        R ray_length = magnitude(ray.d);
+        R distance_inside = (t2 - t1) * ray_length;
+        R hit_distance = md.neg_inv_density * rt_log(uniform01<R>(key, rng_ctr(bounce + 1, SLOT_MEDIUM + uint32_t(m))));
+        if (hit_distance > distance_inside) continue;
+        closest = t1 + hit_distance / ray_length;
+        medium = m;
+        found = true;
+    }
+    if (!found) return false;
+    if (medium >= 0) { // hittable.rs:770-789
+        rec.t = closest;
+        rec.p = ray.at(closest);
+        rec.normal = V3<R>(R(1), R(0), R(0));
+        rec.front_face = true;
+        rec.u = R(0); rec.v = R(0);
+        rec.mat = sc.media[medium].mat;
+    } else {
+        make_record(sc, ray, best, closest, quirks, rec);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- textures (texture.rs, noise.rs)
+template <typename R> RT_HD R perlin_noise(const R* vec, const uint8_t* perm, V3<R> p) { // noise.rs:50-94
+    R fx = rt_floor(p.x), fy = rt_floor(p.y), fz = rt_floor(p.z);
+    R u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int32_t i = int32_t(fx), j = int32_t(fy), k = int32_t(fz);
+    R uu = u * u * (R(3) - R(2) * u), vv = v * v * (R(3) - R(2) * v), ww = w * w * (R(3) - R(2) * w);
+    R acc = 0;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                uint32_t h = uint32_t(perm[(i + di) & 255]) ^ uint32_t(perm[256 + ((j + dj) & 255)]) ^ uint32_t(perm[512 + ((k + dk) & 255)]);
+                V3<R> c(vec + 3 * h);
+                V3<R> weight(u - R(di), v - R(dj), w - R(dk));
+                acc += (R(di) * uu + R(1 - di) * (R(1) - uu)) * (R(dj) * vv + R(1 - dj) * (R(1) - vv)) *
+                       (R(dk) * ww + R(1 - dk) * (R(1) - ww)) * dot(c, weight);
+            }
+    return acc;
+}
+template <typename R> RT_HD R perlin_turbulence(const R* vec, const uint8_t* perm, V3<R> p, int depth) { // noise.rs:96-108
+    R acc = 0, weight = 1;
+    for (int o = 0; o < depth; ++o) {
+        acc = acc + weight * perlin_noise(vec, perm, p);
+        weight = weight * R(0.5);
+        p = p * R(2);
+    }
+    return acc;
+}
+
+template <typename R, typename Cnt>
+RT_HD V3<R> texture_value(const SceneView<R>& sc, int32_t tex, R u, R v, V3<R> p, Cnt& cnt) {
+    for (;;) {
+        const TextureRec<R>& t = sc.texs[tex];
+        if (t.type == TEX_CHECKER) { // texture.rs:20-29
+            R sines = rt_sin(R(10) * p.x) * rt_sin(R(10) * p.y) * rt_sin(R(10) * p.z);
+            tex = sines < R(0) ? t.a : t.b;
+            continue;
+        }
+        if (t.type == TEX_SOLID) return V3<R>(t.color);
+        if (t.type == TEX_NOISE) { // texture.rs:54-58
+            const R* vec = sc.perlin_vec + size_t(t.a) * 768;
+            const uint8_t* perm = sc.perlin_perm + size_t(t.a) * 768;
+            R g = R(0.5) * (R(1) + rt_sin(t.scale * p.z + R(10) * perlin_turbulence(vec, perm, p, 7)));
+            return V3<R>(g, g, g);
+        }
+        if (t.type == TEX_IMAGE) { // texture.rs:78-101
+            const ImageRec im = sc.images[t.a];
+            if (u < R(0)) u = R(0);
+            if (u > R(1)) u = R(1);
+            if (v < R(0)) v = R(0);
+            if (v > R(1)) v = R(1);
+            v = R(1) - v;
+            R fi = u * R(im.w), fj = v * R(im.h);
+            uint32_t i = (fi == fi && fi > R(0)) ? uint32_t(fi) : 0u; // `as u32`: NaN -> 0, saturating
+            uint32_t j = (fj == fj && fj > R(0)) ? uint32_t(fj) : 0u;
+            if (i >= im.w) i = im.w - 1;
+            if (j >= im.h) j = im.h - 1;
+            cnt.texel();
+            uint32_t px = sc.texels[im.offset + size_t(j) * im.w + i];
+            const R s = R(1) / R(255);
+            return V3<R>(R(px & 255u) * s, R((px >> 8) & 255u) * s, R((px >> 16) & 255u) * s);
+        }
+        return V3<R>(R(0), R(1), R(1)); // TEX_CYAN — texture.rs:102-105
+    }
+}
+
+template <typename R, typename Cnt>
+RT_HD V3<R> material_color(const SceneView<R>& sc, const MaterialRec<R>& m, const HitRecord<R>& rec, Cnt& cnt) {
+    if (m.tex < 0) return V3<R>(m.albedo);
+    return texture_value(sc, m.tex, rec.u, rec.v, rec.p, cnt);
+}
+
+// ---------------------------------------------------------------- scatter (material.rs)
+RT_HD float schlick_pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+RT_HD double schlick_pow5(double x) { double x2 = x * x; return x2 * x2 * x; }
+template <typename R> RT_HD R schlick(R cosine, R ri) { // material.rs:173-176
+    R r0 = (R(1) - ri) / (R(1) + ri);
+    r0 = r0 * r0;
+    return r0 + (R(1) - r0) * schlick_pow5(R(1) - cosine);
+}
+
+// Returns true when the path continues; `att` and `ray` (in/out) are then the attenuation and the
+// scattered ray.  `emitted` is always set (material.rs:10-12,247-249).
+template <typename R, typename Cnt>
+RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, uint32_t bounce, Ray<R>& ray, V3<R>& att,
+                 V3<R>& emitted, Cnt& cnt) {
+    const MaterialRec<R> m = sc.mats[rec.mat];
+    emitted = V3<R>();
+    if (m.type == MAT_DIFFUSE_LIGHT) { // material.rs:242-250
+        emitted = material_color(sc, m, rec, cnt);
+        return false;
+    }
+    if (m.type == MAT_LAMBERTIAN) { // material.rs:89-100
+        V3<R> target = rec.p + rec.normal + random_in_unit_space<R>(key, bounce);
+        ray.d = target - rec.p;
+        ray.o = rec.p;
+        att = material_color(sc, m, rec, cnt);
+        return true;
+    }
+    if (m.type == MAT_ISOTROPIC) { // material.rs:256-265
+        ray.o = rec.p;
+        ray.d = random_in_unit_space<R>(key, bounce);
+        att = material_color(sc, m, rec, cnt);
+        return true;
+    }
+    if (m.type == MAT_METAL) { // material.rs:134-149
+        V3<R> reflected = reflect(unit(ray.d), rec.normal);
+        ray.o = rec.p;
+        ray.d = reflected + m.param * random_in_unit_space<R>(key, bounce);
+        att = V3<R>(m.albedo);
+        return dot(ray.d, rec.normal) > R(0);
+    }
+    // MAT_DIELECTRIC — material.rs:179-203
+    att = V3<R>(R(1), R(1), R(1));
+    R ratio = rec.front_face ? R(1) / m.param : m.param;
+    V3<R> ud = unit(ray.d);
+    R cos_theta = rt_min(dot(-ud, rec.normal), R(1));
+    R sin_theta = rt_sqrt(R(1) - cos_theta * cos_theta);
+    bool cannot_refract = ratio * sin_theta > R(1);
+    // the draw is keyed, so evaluating it unconditionally is equivalent to the short-circuit (Q6)
+    bool refl = cannot_refract || schlick(cos_theta, ratio) > uniform01<R>(key, rng_ctr(bounce + 1, SLOT_DIELECTRIC));
+    ray.o = rec.p;
+    ray.d = refl ? reflect(ud, rec.normal) : refract(ud, rec.normal, ratio);
+    return true;
+}
+
+// ---------------------------------------------------------------- one path, lane-resident state
+template <typename R> struct PathState {
+    Ray<R> ray;
+    V3<R> throughput; // product of attenuations so far
+    V3<R> radiance;   // sum of throughput * emitted
+    uint64_t key;
+    uint32_t bounce;
+};
+
+// Start sample `s` of pixel (px, row) — main.rs:212-215.  row 0 is the TOP row (j = height-1).
+template <typename R>
+RT_HD void path_begin(PathState<R>& ps, const CameraRec<R>& cam, const RenderConsts& rc, uint32_t px, uint32_t row, uint32_t s) {
+    const uint64_t pixel = uint64_t(row) * rc.width + px;
+    ps.key = sample_key(rc.seed, pixel, s);
+    const uint32_t j = rc.height - 1 - row;
+    R u = (R(px) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_U))) / R(rc.width);
+    R v = (R(j) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_V))) / R(rc.height);
+    ps.ray = camera_ray(cam, u, v, ps.key);
+    ps.throughput = V3<R>(R(1), R(1), R(1));
+    ps.radiance = V3<R>();
+    ps.bounce = 0;
+}
+
+// One world.hit + shade: the body of color() (main.rs:26-45) unrolled into a loop:
+//   L = sum_k (prod_{i<k} att_i) * emitted_k  (+ throughput * background on a miss).
+// Returns true while the path is alive.
+template <typename R, typename Stack, typename Cnt>
+RT_HD bool path_step(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min,
+                     Stack& stack, Cnt& cnt) {
+    HitRecord<R> rec;
+    if (!world_hit(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, rec, stack, cnt)) {
+        ps.radiance = ps.radiance + ps.throughput * background;
+        return false;
+    }
+    V3<R> att, emitted;
+    bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, emitted, cnt);
+    ps.radiance = ps.radiance + ps.throughput * emitted;
+    if (!cont) return false;
+    ps.throughput = ps.throughput * att;
+    ps.bounce += 1;
+    // color(depth == 0) returns black without tracing (main.rs:28-30): at most max_depth hits
+    return ps.bounce < rc.max_depth;
+}
+
+// Gamma + quantise — main.rs:219-225 (`as u8` saturates, NaN -> 0)
+RT_HD uint8_t quantise(double mean) {
+    double x = sqrt(mean);
+    if (x < 0.0) x = 0.0;
+    if (x > 0.999) x = 0.999;
+    x = x * 256.;
+    if (!(x == x) || x <= 0.0) return 0;
+    if (x >= 255.0) return 255;
+    return uint8_t(x);
+}
+RT_HD uint8_t quantise(float mean) {
+    float x = sqrtf(mean);
+    if (x < 0.0f) x = 0.0f;
+    if (x > 0.999f) x = 0.999f;
+    x = x * 256.f;
+    if (!(x == x) || x <= 0.0f) return 0;
+    if (x >= 255.0f) return 255;
+    return uint8_t(x);
+}
+
+// Tile partition (include/rttnw_hip.h rttnw_tile_layout): rows are rotated by ty so that a column of
+// tiles is spread over all ranks.
+RT_HD uint32_t tile_permuted(uint32_t tx, uint32_t ty, uint32_t tiles_x) { return ty * tiles_x + (tx + ty) % tiles_x; }
+RT_HD void tile_unpermute(uint32_t permuted, uint32_t tiles_x, uint32_t& tx, uint32_t& ty) {
+    ty = permuted / tiles_x;
+    uint32_t c = permuted % tiles_x;
+    tx = (c + tiles_x - ty % tiles_x) % tiles_x;
+}
+
+} // namespace rt

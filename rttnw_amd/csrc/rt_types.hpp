@@ -1,0 +1,139 @@
+// rt_types.hpp — layout of the flattened scene as it lies in HBM (and, for small scenes, in LDS).
+//
+// The reference keeps the scene as a graph of `Box/Arc<dyn Hittable>` trait objects
+// (src/math/hittable.rs) and walks it by virtual dispatch.  Here the graph is lowered once, on the
+// host (scene_lower.cpp), into flat, index-linked POD arrays, one array per primitive kind, so
+// that a lane's traversal is a loop over 64-byte node records and 16..64-byte primitive records.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rt {
+
+// ---- primitive kinds (leaf payloads of the flat BVH)
+enum : uint32_t {
+    PRIM_SPHERE = 0,        // Sphere — hittable.rs:69-131
+    PRIM_MOVING_SPHERE = 1, // MovingSphere — hittable.rs:179-245
+    PRIM_RECT = 2,          // Rectangle<M,P> — hittable.rs:434-547
+    PRIM_BOX = 3,           // Cube (six rectangles, one record) — hittable.rs:549-592
+    PRIM_INSTANCE = 4,      // Translate / YRotate chain over a sub-BVH — hittable.rs:594-722
+    PRIM_MEDIUM = 5,        // ConstantMedium (never inside the BVH; hit-reference kind only)
+    PRIM_NONE = 7
+};
+
+// A child slot of a node: >= 0 -> index of an inner node; < 0 -> ~(leaf bits):
+//   leaf bits = kind(3) << 28 | (count-1)(2) << 26 | first(26)   (count same-kind records)
+constexpr int32_t CHILD_EMPTY = INT32_MIN;        // kind 7: nothing there
+constexpr int32_t STACK_SENTINEL = INT32_MIN + 1; // marks "leave the instance" on the stack
+RT_HD int32_t make_leaf(uint32_t kind, uint32_t count, uint32_t first) {
+    return ~int32_t((kind << 28) | ((count - 1u) << 26) | first);
+}
+RT_HD uint32_t leaf_kind(int32_t child) { return uint32_t(~child) >> 28; }
+RT_HD uint32_t leaf_count(int32_t child) { return ((uint32_t(~child) >> 26) & 3u) + 1u; }
+RT_HD uint32_t leaf_first(int32_t child) { return uint32_t(~child) & 0x3FFFFFFu; }
+// hit reference: kind << 28 | record index
+RT_HD int32_t make_ref(uint32_t kind, uint32_t index) { return int32_t((kind << 28) | index); }
+RT_HD uint32_t ref_kind(int32_t ref) { return uint32_t(ref) >> 28; }
+RT_HD uint32_t ref_index(int32_t ref) { return uint32_t(ref) & 0x0FFFFFFFu; }
+
+// 64-byte BVH node holding the boxes of BOTH children: one record fetch decides which child(ren)
+// to descend into (the reference's BvhTree::hit tests its own box, then recurses, hittable.rs:356-368).
+// Boxes are f32, rounded outward from the f64 bounds; they only cull, they never shape a result.
+struct alignas(16) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// `seq` in the records below: position of the object in the reference's traversal order of the
+// world List (depth-first).  List::hit lets a LATER item replace an earlier one at exactly equal t
+// (hittable.rs:157-159) — e.g. the Cornell blocks' bottom faces coincide with the floor — so exact
+// ties are resolved by the larger seq.
+template <typename R> struct alignas(sizeof(R) * 4) SphereRec { R cx, cy, cz, r; };
+template <typename R> struct MovingSphereRec { R c0[3], r, c1[3], t0, t1; int32_t mat; int32_t seq; };
+template <typename R> struct RectRec { R a0, a1, b0, b1, k; int32_t plane; int32_t mat; int32_t seq; int32_t pad; };
+template <typename R> struct BoxRec { R mn[3], mx[3]; int32_t mat; int32_t seq; };
+
+enum : int32_t { OP_TRANSLATE = 0, OP_ROTATE_Y = 1 };
+constexpr int MAX_INSTANCE_OPS = 3;
+// ops[0] is the OUTERMOST wrapper (applied to the ray first): `x.rotate_y(a).translate(v)`
+// = Translate(YRotate(x)) lowers to ops = { translate v, rotate a }.
+template <typename R> struct InstanceRec {
+    int32_t n_ops;
+    int32_t root; // sub-BVH root node
+    struct Op { int32_t type; int32_t pad; R v[3]; } ops[MAX_INSTANCE_OPS]; // translate: offset; rotate: {sin, cos, -}
+};
+
+template <typename R> struct MediumRec {
+    int32_t boundary; // make_ref(kind, index) of the boundary primitive (sphere / box)
+    int32_t inst;     // instance whose ops wrap the boundary, or -1
+    int32_t mat;      // Isotropic material
+    int32_t pad;
+    R neg_inv_density;
+};
+
+enum : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
+template <typename R> struct MaterialRec {
+    int32_t type;
+    int32_t tex;  // texture index, or -1 when the colour below is the whole texture (solid)
+    R albedo[3];  // metal albedo / inlined solid colour
+    R param;      // metal fuzz / dielectric refraction index
+};
+
+enum : int32_t { TEX_SOLID = 0, TEX_CHECKER = 1, TEX_NOISE = 2, TEX_IMAGE = 3, TEX_CYAN = 4 };
+template <typename R> struct TextureRec {
+    int32_t type;
+    int32_t a, b; // checker: odd, even texture ids; noise: perlin table index; image: image index
+    int32_t pad;
+    R color[3];
+    R scale;
+};
+struct ImageRec { uint32_t offset, w, h, pad; }; // offset in texels (uint32 RGBA8) into `texels`
+
+template <typename R> struct CameraRec { // Camera — camera.rs:18-29
+    R origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    R lens_radius, open_time, close_time;
+};
+
+// Everything a lane needs, by pointer.  Same struct for HBM- and LDS-resident node/primitive arrays.
+template <typename R> struct SceneView {
+    const BvhNode* nodes;
+    const SphereRec<R>* spheres;
+    const int32_t* sphere_mat;
+    const int32_t* sphere_seq; // list-order sequence numbers, read only to break exact ties in t
+    const MovingSphereRec<R>* moving;
+    const RectRec<R>* rects;
+    const BoxRec<R>* boxes;
+    const InstanceRec<R>* insts;
+    const MediumRec<R>* media;
+    const MaterialRec<R>* mats;
+    const TextureRec<R>* texs;
+    const ImageRec* images;
+    const uint32_t* texels;  // RGBA8
+    const R* perlin_vec;     // [n_perlin][256][3]
+    const uint8_t* perlin_perm; // [n_perlin][3][256]
+    int32_t top_root;
+    int32_t n_media;
+};
+
+struct RenderConsts {
+    uint32_t width, height, spp, max_depth;
+    uint32_t spp_chunk, n_chunks;
+    uint32_t tiles_x, tiles_y, n_tiles;
+    uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
+    uint32_t quirks;
+    uint32_t stack_depth;
+    uint64_t seed;
+};
+
+struct DeviceCounters { unsigned long long rays, nodes, prims, texels; };
+
+} // namespace rt

@@ -1,0 +1,517 @@
+// scene_lower.cpp — flatten the recorded scene graph and build the flat BVHs (host, C++).
+//
+// Reference shapes and what they lower to:
+//   world List (main.rs:47-55)                 -> one top-level BVH over every solid in it
+//   List / BvhTree::from(list) (hittable.rs:134,254) -> flattened into the enclosing BVH (grouping only;
+//                                                 closest-hit results do not depend on topology, Q12)
+//   Sphere / MovingSphere / Rectangle / Cube   -> one record each in its own array (Cube = ONE box
+//                                                 record whose hit reproduces its six rectangles)
+//   x.rotate_y(a).translate(v) chains (hittable.rs:51-65) -> an instance: ops + a sub-BVH over x
+//   ConstantMedium (hittable.rs:724-801)       -> a medium record evaluated after the BVH walk
+// The reference's own builder (hittable.rs:265-321: random axis, whole-vector re-sort, O(n^2 log n))
+// is NOT reproduced; this one is a binned-SAH build producing 64-byte two-box nodes.
+#include "scene_lower.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rt {
+
+namespace {
+constexpr int ERR_INVALID = -1, ERR_UNSUPPORTED = -3;
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr uint64_t GAMMA = 0x9E3779B97F4A7C15ull;
+uint64_t mix64h(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+} // namespace
+
+SceneRng::SceneRng(uint64_t seed, uint64_t stream)
+    : s(mix64h(seed + GAMMA) ^ mix64h((stream + 1) * 0xD1B54A32D192ED03ull)) {}
+uint64_t SceneRng::next_u64() { s += GAMMA; return mix64h(s); }
+double SceneRng::next_f64() { return double(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+
+bool SceneGraph::is_texture(int32_t id) const {
+    return id >= 0 && size_t(id) < objs.size() && objs[id].kind <= GraphObj::TEX_IMAGE_K;
+}
+bool SceneGraph::is_material(int32_t id) const {
+    return id >= 0 && size_t(id) < objs.size() && objs[id].kind == GraphObj::MAT_K;
+}
+bool SceneGraph::is_hittable(int32_t id) const {
+    return id >= 0 && size_t(id) < objs.size() && objs[id].kind >= GraphObj::SPHERE_K && !objs[id].consumed;
+}
+
+// Camera::new — camera.rs:32-61
+void make_camera(const double lookfrom[3], const double lookat[3], const double vup[3], double vfov_deg, double aspect,
+                 double aperture, double focus, double open_time, double close_time, CameraRec<double>& c) {
+    auto unit3 = [](double* v) {
+        double k = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        v[0] *= k; v[1] *= k; v[2] *= k;
+    };
+    auto cross3 = [](const double* a, const double* b, double* o) {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = -(a[0] * b[2] - a[2] * b[0]);
+        o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    c.lens_radius = aperture / 2.0;
+    double theta = vfov_deg * kPi / 180.0;
+    double half_height = std::tan(theta / 2.0);
+    double half_width = aspect * half_height;
+    double w[3] = {lookfrom[0] - lookat[0], lookfrom[1] - lookat[1], lookfrom[2] - lookat[2]};
+    unit3(w);
+    double u[3];
+    cross3(vup, w, u);
+    unit3(u);
+    double v[3];
+    cross3(w, u, v);
+    for (int k = 0; k < 3; ++k) {
+        c.origin[k] = lookfrom[k];
+        c.u[k] = u[k];
+        c.v[k] = v[k];
+        // origin - half_width*focus*u - half_height*focus*v - focus*w  (left to right, camera.rs:41-44)
+        c.lower_left_corner[k] = ((lookfrom[k] - half_width * focus * u[k]) - half_height * focus * v[k]) - focus * w[k];
+        c.horizontal[k] = 2.0 * half_width * focus * u[k];
+        c.vertical[k] = 2.0 * half_height * focus * v[k];
+    }
+    c.open_time = open_time;
+    c.close_time = close_time;
+}
+
+namespace {
+
+struct Box3 {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    void grow(const Box3& o) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); }
+    }
+    void grow_pt(const double p[3]) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+    }
+    double area() const {
+        double d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0;
+        return 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+};
+
+struct Item {
+    uint32_t kind;  // PRIM_*
+    int32_t obj;    // graph object id (instances: index into FlatScene::insts)
+    Box3 box;
+    int32_t seq = 0; // position in the reference's depth-first traversal of the world List
+};
+
+struct Lowering {
+    const SceneGraph& g;
+    FlatScene& fs;
+    std::string& err;
+    std::vector<int32_t> tex_index, mat_index; // graph id -> flat index
+    int rc = 0;
+
+    int fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return code; }
+
+    // ---- bounds of leaf objects (Sphere :125-130, MovingSphere :233-244 over shutter 0..1,
+    //      Rectangle :532-546, Cube :585-591)
+    Box3 bounds_of(const GraphObj& o) const {
+        Box3 b;
+        switch (o.kind) {
+        case GraphObj::SPHERE_K:
+            for (int k = 0; k < 3; ++k) { b.lo[k] = o.v[k] - std::fabs(o.v[3]); b.hi[k] = o.v[k] + std::fabs(o.v[3]); }
+            break;
+        case GraphObj::MOVING_K: {
+            double r = std::fabs(o.v[8]);
+            for (double time : {0.0, 1.0}) {
+                double f = (time - o.v[6]) / (o.v[7] - o.v[6]);
+                double c[3];
+                for (int k = 0; k < 3; ++k) c[k] = o.v[k] + f * (o.v[3 + k] - o.v[k]);
+                double p0[3] = {c[0] - r, c[1] - r, c[2] - r}, p1[3] = {c[0] + r, c[1] + r, c[2] + r};
+                b.grow_pt(p0); b.grow_pt(p1);
+            }
+            break;
+        }
+        case GraphObj::RECT_K: {
+            int a0 = o.c == 2 ? 1 : 0, a1 = o.c == 0 ? 1 : 2, ka = o.c == 0 ? 2 : (o.c == 1 ? 1 : 0);
+            b.lo[a0] = std::min(o.v[0], o.v[1]); b.hi[a0] = std::max(o.v[0], o.v[1]);
+            b.lo[a1] = std::min(o.v[2], o.v[3]); b.hi[a1] = std::max(o.v[2], o.v[3]);
+            b.lo[ka] = o.v[4] - 0.0001; b.hi[ka] = o.v[4] + 0.0001;
+            break;
+        }
+        case GraphObj::CUBE_K:
+            for (int k = 0; k < 3; ++k) { b.lo[k] = std::min(o.v[k], o.v[3 + k]); b.hi[k] = std::max(o.v[k], o.v[3 + k]); }
+            break;
+        default: break;
+        }
+        return b;
+    }
+
+    // ---- record emission
+    uint32_t emit(const Item& it) {
+        const GraphObj& o = g.objs[it.obj];
+        switch (it.kind) {
+        case PRIM_SPHERE: {
+            fs.spheres.push_back({o.v[0], o.v[1], o.v[2], o.v[3]});
+            fs.sphere_mat.push_back(mat_index[o.a]);
+            fs.sphere_seq.push_back(it.seq);
+            return uint32_t(fs.spheres.size() - 1);
+        }
+        case PRIM_MOVING_SPHERE: {
+            MovingSphereRec<double> m{};
+            for (int k = 0; k < 3; ++k) { m.c0[k] = o.v[k]; m.c1[k] = o.v[3 + k]; }
+            m.t0 = o.v[6]; m.t1 = o.v[7]; m.r = o.v[8]; m.mat = mat_index[o.a]; m.seq = it.seq;
+            fs.moving.push_back(m);
+            return uint32_t(fs.moving.size() - 1);
+        }
+        case PRIM_RECT: {
+            RectRec<double> r{o.v[0], o.v[1], o.v[2], o.v[3], o.v[4], o.c, mat_index[o.a], it.seq, 0};
+            fs.rects.push_back(r);
+            return uint32_t(fs.rects.size() - 1);
+        }
+        case PRIM_BOX: {
+            BoxRec<double> bx{};
+            for (int k = 0; k < 3; ++k) { bx.mn[k] = o.v[k]; bx.mx[k] = o.v[3 + k]; }
+            bx.mat = mat_index[o.a];
+            bx.seq = it.seq;
+            fs.boxes.push_back(bx);
+            return uint32_t(fs.boxes.size() - 1);
+        }
+        default: return 0;
+        }
+    }
+
+    static void set_box(float* lo, float* hi, const Box3& b) {
+        for (int k = 0; k < 3; ++k) {
+            float l = float(b.lo[k]), h = float(b.hi[k]);
+            // round outward, then pad two ulps: covers the f32 narrowing of the primitives themselves
+            if (double(l) > b.lo[k]) l = std::nextafterf(l, -INFINITY);
+            if (double(h) < b.hi[k]) h = std::nextafterf(h, INFINITY);
+            l = std::nextafterf(std::nextafterf(l, -INFINITY), -INFINITY);
+            h = std::nextafterf(std::nextafterf(h, INFINITY), INFINITY);
+            lo[k] = l; hi[k] = h;
+        }
+    }
+    static void set_empty(float* lo, float* hi) {
+        for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    }
+
+    static bool groupable(uint32_t kind) { return kind == PRIM_SPHERE || kind == PRIM_RECT || kind == PRIM_BOX; }
+
+    // ---- binned-SAH build over items[lo, hi).  Returns the child code (node index or leaf bits).
+    int32_t build(std::vector<Item>& items, size_t lo, size_t hi, uint32_t depth, uint32_t& max_depth, Box3& out_box) {
+        max_depth = std::max(max_depth, depth);
+        const size_t n = hi - lo;
+        Box3 box, cbox;
+        bool same_kind = true;
+        for (size_t i = lo; i < hi; ++i) {
+            box.grow(items[i].box);
+            double c[3];
+            for (int k = 0; k < 3; ++k) c[k] = 0.5 * (items[i].box.lo[k] + items[i].box.hi[k]);
+            cbox.grow_pt(c);
+            same_kind = same_kind && items[i].kind == items[lo].kind;
+        }
+        out_box = box;
+        auto make_leaf_here = [&]() -> int32_t {
+            uint32_t first = 0;
+            for (size_t i = lo; i < hi; ++i) {
+                uint32_t idx = items[i].kind == PRIM_INSTANCE ? uint32_t(items[i].obj) : emit(items[i]);
+                if (i == lo) first = idx;
+            }
+            fs.n_prims_in_bvh += uint32_t(n);
+            return make_leaf(items[lo].kind, uint32_t(n), first);
+        };
+        if (n == 1) return make_leaf_here();
+        const bool can_leaf = same_kind && groupable(items[lo].kind) && n <= 4;
+
+        // best binned split
+        constexpr int NB = 16;
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            double ext = cbox.hi[ax] - cbox.lo[ax];
+            if (!(ext > 0)) continue;
+            Box3 bb[NB];
+            size_t bc[NB] = {0};
+            double scale = NB / ext;
+            for (size_t i = lo; i < hi; ++i) {
+                double c = 0.5 * (items[i].box.lo[ax] + items[i].box.hi[ax]);
+                int b = std::min(NB - 1, std::max(0, int((c - cbox.lo[ax]) * scale)));
+                bb[b].grow(items[i].box);
+                bc[b]++;
+            }
+            double right_area[NB];
+            size_t right_cnt[NB];
+            Box3 acc;
+            size_t cnt = 0;
+            for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.area(); right_cnt[b] = cnt; }
+            acc = Box3();
+            cnt = 0;
+            for (int b = 0; b < NB - 1; ++b) {
+                acc.grow(bb[b]); cnt += bc[b];
+                if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+                double cost = acc.area() * double(cnt) + right_area[b + 1] * double(right_cnt[b + 1]);
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = b; }
+            }
+        }
+        if (can_leaf) {
+            // SAH: leaf cost n * A vs. split cost A (one node fetch) + children
+            double a = box.area();
+            if (best_axis < 0 || !(best_cost + a < double(n) * a)) return make_leaf_here();
+        }
+        size_t mid;
+        if (best_axis >= 0) {
+            double ext = cbox.hi[best_axis] - cbox.lo[best_axis], scale = NB / ext, clo = cbox.lo[best_axis];
+            int ax = best_axis, bin = best_bin;
+            auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& x) {
+                double c = 0.5 * (x.box.lo[ax] + x.box.hi[ax]);
+                int b = std::min(NB - 1, std::max(0, int((c - clo) * scale)));
+                return b <= bin;
+            });
+            mid = size_t(it - items.begin());
+        } else if (!same_kind) { // coincident centroids of different kinds: separate the kinds
+            uint32_t k0 = items[lo].kind;
+            auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& x) { return x.kind == k0; });
+            mid = size_t(it - items.begin());
+        } else {
+            mid = lo + n / 2;
+        }
+        if (mid == lo || mid == hi || depth > 40) {
+            // degenerate or runaway split: fall back to an object-median cut on the widest axis
+            int ax = 0;
+            for (int k = 1; k < 3; ++k)
+                if (cbox.hi[k] - cbox.lo[k] > cbox.hi[ax] - cbox.lo[ax]) ax = k;
+            mid = lo + n / 2;
+            std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi, [ax](const Item& x, const Item& y) {
+                return x.box.lo[ax] + x.box.hi[ax] < y.box.lo[ax] + y.box.hi[ax];
+            });
+        }
+
+        const int32_t me = int32_t(fs.nodes.size());
+        fs.nodes.emplace_back();
+        Box3 b0, b1;
+        int32_t c0 = build(items, lo, mid, depth + 1, max_depth, b0);
+        int32_t c1 = build(items, mid, hi, depth + 1, max_depth, b1);
+        BvhNode& nd = fs.nodes[me];
+        set_box(nd.lo0, nd.hi0, b0);
+        set_box(nd.lo1, nd.hi1, b1);
+        nd.child0 = c0; nd.child1 = c1; nd.pad0 = nd.pad1 = 0;
+        return me;
+    }
+
+    // Build a BVH whose root is always a node record.  Returns the root index.
+    int32_t build_root(std::vector<Item>& items, uint32_t& depth_out, Box3& box_out) {
+        uint32_t md = 0;
+        if (items.empty()) {
+            BvhNode nd{};
+            set_empty(nd.lo0, nd.hi0); set_empty(nd.lo1, nd.hi1);
+            nd.child0 = nd.child1 = CHILD_EMPTY;
+            fs.nodes.push_back(nd);
+            depth_out = 1;
+            box_out = Box3();
+            return int32_t(fs.nodes.size() - 1);
+        }
+        // reserve the root slot first so that it precedes its subtree
+        int32_t code = build(items, 0, items.size(), 1, md, box_out);
+        depth_out = md + 1;
+        if (code >= 0) return code;
+        BvhNode nd{};
+        set_box(nd.lo0, nd.hi0, box_out);
+        set_empty(nd.lo1, nd.hi1);
+        nd.child0 = code; nd.child1 = CHILD_EMPTY;
+        fs.nodes.push_back(nd);
+        return int32_t(fs.nodes.size() - 1);
+    }
+
+    // ---- transform chains
+    // Walk Translate/YRotate wrappers from `id` inwards; ops[0] = outermost.  Returns the wrapped object.
+    int32_t peel_ops(int32_t id, InstanceRec<double>& in) {
+        in = InstanceRec<double>{};
+        int32_t cur = id;
+        while (g.objs[cur].kind == GraphObj::TRANSLATE_K || g.objs[cur].kind == GraphObj::ROTATE_K) {
+            const GraphObj& o = g.objs[cur];
+            if (in.n_ops >= MAX_INSTANCE_OPS) { fail(ERR_UNSUPPORTED, "more than 3 nested translate/rotate_y wrappers"); return -1; }
+            auto& op = in.ops[in.n_ops++];
+            if (o.kind == GraphObj::TRANSLATE_K) {
+                op.type = OP_TRANSLATE;
+                op.v[0] = o.v[0]; op.v[1] = o.v[1]; op.v[2] = o.v[2];
+            } else { // YRotate::new — hittable.rs:641-643
+                op.type = OP_ROTATE_Y;
+                double radians = o.v[0] * (kPi / 180.0);
+                op.v[0] = std::sin(radians); op.v[1] = std::cos(radians); op.v[2] = 0;
+            }
+            cur = o.a;
+        }
+        return cur;
+    }
+    // object -> world for a point (the CORRECT inverse; instance bounds must be conservative, Q2)
+    static void to_world(const InstanceRec<double>& in, double p[3]) {
+        for (int i = in.n_ops - 1; i >= 0; --i) {
+            if (in.ops[i].type == OP_TRANSLATE) {
+                p[0] += in.ops[i].v[0]; p[1] += in.ops[i].v[1]; p[2] += in.ops[i].v[2];
+            } else {
+                double s = in.ops[i].v[0], c = in.ops[i].v[1];
+                double x = c * p[0] + s * p[2], z = -s * p[0] + c * p[2];
+                p[0] = x; p[2] = z;
+            }
+        }
+    }
+
+    // ---- collection of solids
+    int32_t next_seq = 0;
+    int nesting = 0; // recursion guard: a list that (transitively) contains itself
+    void collect(int32_t id, std::vector<Item>& out, bool inside_instance, uint32_t& inst_depth) {
+        if (rc) return;
+        struct Guard { int& n; Guard(int& x) : n(x) { ++n; } ~Guard() { --n; } } guard(nesting);
+        if (nesting > 64) { fail(ERR_UNSUPPORTED, "scene graph nests deeper than 64 levels (cycle?)"); return; }
+        const GraphObj& o = g.objs[id];
+        switch (o.kind) {
+        case GraphObj::SPHERE_K: out.push_back({PRIM_SPHERE, id, bounds_of(o), next_seq++}); break;
+        case GraphObj::MOVING_K: out.push_back({PRIM_MOVING_SPHERE, id, bounds_of(o), next_seq++}); break;
+        case GraphObj::RECT_K: out.push_back({PRIM_RECT, id, bounds_of(o), next_seq++}); break;
+        case GraphObj::CUBE_K: out.push_back({PRIM_BOX, id, bounds_of(o), next_seq++}); break;
+        case GraphObj::LIST_K:
+        case GraphObj::BVH_K:
+            for (int32_t it : o.items) collect(it, out, inside_instance, inst_depth);
+            break;
+        case GraphObj::TRANSLATE_K:
+        case GraphObj::ROTATE_K: {
+            if (inside_instance) { fail(ERR_UNSUPPORTED, "translate/rotate_y nested inside another transformed group"); return; }
+            InstanceRec<double> in;
+            int32_t inner = peel_ops(id, in);
+            if (rc) return;
+            std::vector<Item> sub;
+            uint32_t dummy = 0;
+            collect(inner, sub, true, dummy);
+            if (rc) return;
+            uint32_t depth = 0;
+            Box3 ob;
+            in.root = build_root(sub, depth, ob);
+            inst_depth = std::max(inst_depth, depth);
+            Box3 wb;
+            if (!sub.empty()) {
+                for (int c = 0; c < 8; ++c) {
+                    double p[3] = {(c & 1) ? ob.hi[0] : ob.lo[0], (c & 2) ? ob.hi[1] : ob.lo[1], (c & 4) ? ob.hi[2] : ob.lo[2]};
+                    to_world(in, p);
+                    wb.grow_pt(p);
+                }
+                // guard the sin/cos rounding of the corner transform
+                for (int k = 0; k < 3; ++k) {
+                    double pad = 1e-9 * std::max(1.0, std::max(std::fabs(wb.lo[k]), std::fabs(wb.hi[k])));
+                    wb.lo[k] -= pad; wb.hi[k] += pad;
+                }
+            }
+            fs.insts.push_back(in);
+            out.push_back({PRIM_INSTANCE, int32_t(fs.insts.size() - 1), wb, 0});
+            break;
+        }
+        case GraphObj::MEDIUM_K: {
+            if (inside_instance) { fail(ERR_UNSUPPORTED, "constant_medium inside a transformed group"); return; }
+            InstanceRec<double> in;
+            int32_t base = peel_ops(o.a, in);
+            if (rc) return;
+            const GraphObj& bo = g.objs[base];
+            MediumRec<double> md{};
+            if (bo.kind == GraphObj::SPHERE_K) md.boundary = make_ref(PRIM_SPHERE, emit({PRIM_SPHERE, base, Box3(), 0}));
+            else if (bo.kind == GraphObj::CUBE_K) md.boundary = make_ref(PRIM_BOX, emit({PRIM_BOX, base, Box3(), 0}));
+            else { fail(ERR_UNSUPPORTED, "constant_medium boundary must be a sphere or a cube (optionally translated/rotated)"); return; }
+            md.inst = -1;
+            if (in.n_ops > 0) { in.root = -1; fs.insts.push_back(in); md.inst = int32_t(fs.insts.size() - 1); }
+            md.mat = mat_index[o.b];
+            md.neg_inv_density = -1. / o.v[0]; // hittable.rs:733
+            // media keep their creation order (= RNG slot, DESIGN.md "RNG")
+            if (size_t(o.c) >= fs.media.size()) fs.media.resize(size_t(o.c) + 1, MediumRec<double>{make_ref(PRIM_NONE, 0), -1, 0, 0, 0.0});
+            fs.media[o.c] = md;
+            break;
+        }
+        default: fail(ERR_INVALID, "world contains a non-hittable object"); break;
+        }
+    }
+
+    void lower_textures_materials() {
+        tex_index.assign(g.objs.size(), -1);
+        mat_index.assign(g.objs.size(), -1);
+        for (size_t id = 0; id < g.objs.size(); ++id) {
+            const GraphObj& o = g.objs[id];
+            if (o.kind > GraphObj::TEX_IMAGE_K) continue;
+            TextureRec<double> t{};
+            switch (o.kind) {
+            case GraphObj::TEX_SOLID_K: t.type = TEX_SOLID; t.color[0] = o.v[0]; t.color[1] = o.v[1]; t.color[2] = o.v[2]; break;
+            case GraphObj::TEX_CHECKER_K: t.type = TEX_CHECKER; t.a = o.a; t.b = o.b; break; // remapped below
+            case GraphObj::TEX_NOISE_K: t.type = TEX_NOISE; t.a = o.a; t.scale = o.v[0]; break;
+            default: // image
+                if (o.a < 0) { t.type = TEX_CYAN; break; }
+                t.type = TEX_IMAGE; t.a = o.a;
+                break;
+            }
+            tex_index[id] = int32_t(fs.texs.size());
+            fs.texs.push_back(t);
+        }
+        for (auto& t : fs.texs)
+            if (t.type == TEX_CHECKER) { t.a = tex_index[t.a]; t.b = tex_index[t.b]; }
+        // images
+        for (size_t i = 0; i < g.image_data.size(); ++i) {
+            ImageRec im{uint32_t(fs.texels.size()), g.image_w[i], g.image_h[i], 0};
+            const auto& d = g.image_data[i];
+            for (size_t p = 0; p + 3 < d.size(); p += 4)
+                fs.texels.push_back(uint32_t(d[p]) | (uint32_t(d[p + 1]) << 8) | (uint32_t(d[p + 2]) << 16) | (uint32_t(d[p + 3]) << 24));
+            fs.images.push_back(im);
+        }
+        // Perlin tables — Perlin::new (noise.rs:40-47): points, then the x, y, z permutations
+        fs.perlin_vec.resize(size_t(g.n_noise) * 768);
+        fs.perlin_perm.resize(size_t(g.n_noise) * 768);
+        for (uint32_t n = 0; n < g.n_noise; ++n) {
+            SceneRng rng(g.seed, 0x100 + n);
+            for (int i = 0; i < 768; ++i) fs.perlin_vec[size_t(n) * 768 + i] = rng.range(-1., 1.); // noise.rs:15-19, not normalised
+            for (int t = 0; t < 3; ++t) { // noise.rs:21-29 (Fisher-Yates, from the back)
+                uint8_t* p = &fs.perlin_perm[size_t(n) * 768 + size_t(t) * 256];
+                for (int i = 0; i < 256; ++i) p[i] = uint8_t(i);
+                for (uint32_t i = 255; i >= 1; --i) std::swap(p[i], p[rng.below(i + 1)]);
+            }
+        }
+        for (size_t id = 0; id < g.objs.size(); ++id) {
+            const GraphObj& o = g.objs[id];
+            if (o.kind != GraphObj::MAT_K) continue;
+            MaterialRec<double> m{};
+            m.type = o.c;
+            m.tex = -1;
+            m.albedo[0] = o.v[0]; m.albedo[1] = o.v[1]; m.albedo[2] = o.v[2];
+            m.param = o.v[3];
+            if (o.a >= 0) { // textured: inline a solid colour, else point at the texture record
+                const TextureRec<double>& t = fs.texs[tex_index[o.a]];
+                if (t.type == TEX_SOLID) { m.albedo[0] = t.color[0]; m.albedo[1] = t.color[1]; m.albedo[2] = t.color[2]; }
+                else m.tex = tex_index[o.a];
+            }
+            mat_index[id] = int32_t(fs.mats.size());
+            fs.mats.push_back(m);
+        }
+    }
+
+    int run() {
+        if (g.world < 0 || g.objs[g.world].kind != GraphObj::LIST_K) return fail(-2, "commit: world not set");
+        lower_textures_materials();
+        std::vector<Item> top;
+        uint32_t inst_depth = 0;
+        collect(g.world, top, false, inst_depth);
+        if (rc) return rc;
+        for (const auto& md : fs.media)
+            if (ref_kind(md.boundary) == PRIM_NONE) return fail(ERR_UNSUPPORTED, "a constant_medium was created but is not in the world list");
+        uint32_t top_depth = 0;
+        Box3 wb;
+        fs.top_root = build_root(top, top_depth, wb);
+        // far-child pushes: <= one per level; + the instance sentinel; + slack
+        fs.stack_depth = top_depth + inst_depth + 3;
+        return 0;
+    }
+};
+
+} // namespace
+
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err) {
+    out = FlatScene();
+    Lowering lw{g, out, err, {}, {}, 0};
+    return lw.run();
+}
+
+} // namespace rt

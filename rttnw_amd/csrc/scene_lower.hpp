@@ -1,0 +1,78 @@
+// scene_lower.hpp — host side of the boundary: records the scene graph the caller describes
+// through the C ABI (the `Box/Arc<dyn Hittable>` graph of the reference, hittable.rs) and lowers
+// it into the flat, index-linked arrays of rt_types.hpp.  Pure C++; no HIP in here.
+#pragma once
+#include "rt_types.hpp"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rt {
+
+// ---------------------------------------------------------------- recorded graph
+struct GraphObj {
+    enum Kind : int { TEX_SOLID_K, TEX_CHECKER_K, TEX_NOISE_K, TEX_IMAGE_K,
+                      MAT_K,
+                      SPHERE_K, MOVING_K, RECT_K, CUBE_K, LIST_K, BVH_K, TRANSLATE_K, ROTATE_K, MEDIUM_K };
+    Kind kind;
+    double v[10] = {0}; // numeric payload (meaning per kind, see scene_lower.cpp)
+    int32_t a = -1, b = -1, c = -1; // object references / small ints
+    std::vector<int32_t> items;     // LIST_K / BVH_K members
+    bool consumed = false;          // a list moved into a BvhTree (BvhTree::from takes it by value)
+};
+
+struct SceneGraph {
+    uint64_t seed = 0;
+    std::vector<GraphObj> objs;
+    std::vector<std::vector<uint8_t>> image_data; // RGBA8 per image texture (index = GraphObj::a)
+    std::vector<uint32_t> image_w, image_h;
+    int32_t world = -1;
+    uint32_t n_noise = 0;
+
+    bool is_texture(int32_t id) const;
+    bool is_material(int32_t id) const;
+    bool is_hittable(int32_t id) const;
+};
+
+// ---------------------------------------------------------------- lowered scene (f64 master copy)
+struct FlatScene {
+    std::vector<BvhNode> nodes;
+    std::vector<SphereRec<double>> spheres;
+    std::vector<int32_t> sphere_mat;
+    std::vector<int32_t> sphere_seq;
+    std::vector<MovingSphereRec<double>> moving;
+    std::vector<RectRec<double>> rects;
+    std::vector<BoxRec<double>> boxes;
+    std::vector<InstanceRec<double>> insts;
+    std::vector<MediumRec<double>> media;
+    std::vector<MaterialRec<double>> mats;
+    std::vector<TextureRec<double>> texs;
+    std::vector<ImageRec> images;
+    std::vector<uint32_t> texels;
+    std::vector<double> perlin_vec;   // [n][256][3]
+    std::vector<uint8_t> perlin_perm; // [n][3][256]
+    int32_t top_root = 0;
+    uint32_t stack_depth = 4;         // entries a lane's traversal stack needs
+    uint32_t n_prims_in_bvh = 0;
+};
+
+// Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err);
+
+// Camera::new — camera.rs:32-61 (computed once on the host, in f64)
+void make_camera(const double lookfrom[3], const double lookat[3], const double view_up[3], double vfov_deg,
+                 double aspect, double aperture, double focus_distance, double open_time, double close_time,
+                 CameraRec<double>& out);
+
+// Scene-construction stream of the library (Perlin tables): DESIGN.md "RNG"
+struct SceneRng {
+    uint64_t s;
+    SceneRng(uint64_t seed, uint64_t stream);
+    uint64_t next_u64();
+    double next_f64();
+    double range(double a, double b) { return a + (b - a) * next_f64(); }
+    uint32_t below(uint32_t n) { return uint32_t(next_f64() * double(n)); }
+};
+
+} // namespace rt

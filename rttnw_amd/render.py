@@ -1,0 +1,80 @@
+"""Render drivers over the C ABI: the `render()` of the reference's main.rs:58-233, minus PNG/progress.
+
+PyTorch is plumbing here (device buffers, the current HIP stream, torch.distributed over RCCL);
+all tracing happens in the hand-written HIP kernels behind `rttnw_render_tiles_device`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, library, tiles
+from .abi import Stats, check
+
+
+def render_host(scene, cam, params, want_stats=True):
+    """Blocking single-GPU render with host outputs: (linear HxWx3 f64, rgba8 HxWx4 u8, Stats)."""
+    b = library.product()
+    h, w = params.height, params.width
+    lin = np.zeros((h, w, 3), dtype=np.float64)
+    rgba = np.zeros((h, w, 4), dtype=np.uint8)
+    st = Stats()
+    rc = b.render(scene.handle, C.byref(cam), C.byref(params), lin.ctypes.data, rgba.ctypes.data,
+                  C.byref(st) if want_stats else None)
+    check(rc, b, "rttnw_render")
+    return lin, rgba, st
+
+
+def _torch_dtype(precision):
+    import torch
+    return torch.float32 if precision == abi.F32 else torch.float64
+
+
+class DeviceRenderer:
+    """Device-resident render of this rank's tiles (+ gather over torch.distributed for world > 1).
+
+    Buffers are torch tensors on the current device; kernels are launched on torch's current stream.
+    """
+
+    def __init__(self, scene, cam, params, group=None):
+        import torch
+        self.torch = torch
+        self.b = library.product()
+        self.scene, self.cam, self.params = scene, cam, params
+        self.world = params.tile_world
+        self.rank = params.tile_rank
+        self.group = group
+        self.lay = tiles.layout(params.width, params.height, self.world)
+        dt = _torch_dtype(params.precision)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.packed = torch.zeros((self.lay["pixels_per_rank"], 4), dtype=dt, device=dev)
+        root = self.rank == 0
+        self.gathered = (torch.zeros((self.world, self.lay["pixels_per_rank"], 4), dtype=dt, device=dev)
+                         if (root and self.world > 1) else None)
+        self.linear = torch.zeros((params.height, params.width, 3), dtype=dt, device=dev) if root else None
+        self.rgba8 = torch.zeros((params.height, params.width, 4), dtype=torch.uint8, device=dev) if root else None
+
+    def trace(self, stats=None):
+        """Launch the trace + resolve kernels for this rank's tiles (asynchronous)."""
+        stream = self.torch.cuda.current_stream().cuda_stream
+        rc = self.b.render_tiles_device(self.scene.handle, C.byref(self.cam), C.byref(self.params),
+                                        self.packed.data_ptr(), stream, C.byref(stats) if stats is not None else None)
+        check(rc, self.b, "rttnw_render_tiles_device")
+
+    def collect(self):
+        """Gather every rank's packed tiles on rank 0 (RCCL over xGMI) and scatter them into the framebuffer."""
+        src = self.packed
+        if self.world > 1:
+            import torch.distributed as dist
+            glist = list(self.gathered.unbind(0)) if self.rank == 0 else None
+            dist.gather(self.packed, glist, dst=0, group=self.group)
+            src = self.gathered
+        if self.rank == 0:
+            p = self.params
+            stream = self.torch.cuda.current_stream().cuda_stream
+            rc = self.b.untile_device(p.width, p.height, self.world, p.precision, src.data_ptr(),
+                                      self.linear.data_ptr(), self.rgba8.data_ptr(), stream)
+            check(rc, self.b, "rttnw_untile_device")
+
+    def step(self):
+        self.trace()
+        self.collect()

@@ -1,0 +1,188 @@
+// TEST INFRASTRUCTURE — host build of the product's per-lane tracing core (rttnw_amd/csrc/rt_core.hpp)
+// and lowering, used by tests to debug/verify the kernel LOGIC in a container without a GPU and to
+// cross-check the device counters.  It is never loaded by the rttnw_amd package: the product path has
+// no CPU fallback.  Job order and per-job accumulation mirror render.hip's trace kernel exactly.
+#include "../../include/rttnw_hip.h"
+#include "../../rttnw_amd/csrc/rt_core.hpp"
+#include "../../rttnw_amd/csrc/scene_handle.hpp"
+
+#include <atomic>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace rt {
+int device_commit(::rttnw_scene*, std::string&) { return 0; } // no device in the host build
+void device_release(DeviceState*) {}
+} // namespace rt
+
+namespace {
+using namespace rt;
+
+struct HostStack {
+    int32_t data[256];
+    void set(int i, int32_t v) { data[i] = v; }
+    int32_t get(int i) const { return data[i]; }
+};
+
+template <typename R> struct HostScene {
+    std::vector<SphereRec<R>> spheres;
+    std::vector<MovingSphereRec<R>> moving;
+    std::vector<RectRec<R>> rects;
+    std::vector<BoxRec<R>> boxes;
+    std::vector<InstanceRec<R>> insts;
+    std::vector<MediumRec<R>> media;
+    std::vector<MaterialRec<R>> mats;
+    std::vector<TextureRec<R>> texs;
+    std::vector<R> perlin_vec;
+    SceneView<R> view;
+    explicit HostScene(const FlatScene& f) {
+        for (auto& s : f.spheres) spheres.push_back({R(s.cx), R(s.cy), R(s.cz), R(s.r)});
+        for (auto& m : f.moving) {
+            MovingSphereRec<R> o{};
+            for (int k = 0; k < 3; ++k) { o.c0[k] = R(m.c0[k]); o.c1[k] = R(m.c1[k]); }
+            o.r = R(m.r); o.t0 = R(m.t0); o.t1 = R(m.t1); o.mat = m.mat; o.seq = m.seq;
+            moving.push_back(o);
+        }
+        for (auto& r : f.rects) rects.push_back({R(r.a0), R(r.a1), R(r.b0), R(r.b1), R(r.k), r.plane, r.mat, r.seq, 0});
+        for (auto& b : f.boxes) {
+            BoxRec<R> o{};
+            for (int k = 0; k < 3; ++k) { o.mn[k] = R(b.mn[k]); o.mx[k] = R(b.mx[k]); }
+            o.mat = b.mat; o.seq = b.seq;
+            boxes.push_back(o);
+        }
+        for (auto& i : f.insts) {
+            InstanceRec<R> o{};
+            o.n_ops = i.n_ops; o.root = i.root;
+            for (int k = 0; k < MAX_INSTANCE_OPS; ++k) {
+                o.ops[k].type = i.ops[k].type;
+                for (int c = 0; c < 3; ++c) o.ops[k].v[c] = R(i.ops[k].v[c]);
+            }
+            insts.push_back(o);
+        }
+        for (auto& m : f.media) media.push_back({m.boundary, m.inst, m.mat, 0, R(m.neg_inv_density)});
+        for (auto& m : f.mats) mats.push_back({m.type, m.tex, {R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2])}, R(m.param)});
+        for (auto& t : f.texs) texs.push_back({t.type, t.a, t.b, 0, {R(t.color[0]), R(t.color[1]), R(t.color[2])}, R(t.scale)});
+        for (double v : f.perlin_vec) perlin_vec.push_back(R(v));
+        view.nodes = f.nodes.data();
+        view.spheres = spheres.data(); view.sphere_mat = f.sphere_mat.data(); view.sphere_seq = f.sphere_seq.data();
+        view.moving = moving.data(); view.rects = rects.data(); view.boxes = boxes.data();
+        view.insts = insts.data(); view.media = media.data(); view.mats = mats.data(); view.texs = texs.data();
+        view.images = f.images.data(); view.texels = f.texels.data();
+        view.perlin_vec = perlin_vec.data(); view.perlin_perm = f.perlin_perm.data();
+        view.top_root = f.top_root; view.n_media = int32_t(media.size());
+    }
+};
+
+template <typename R> CameraRec<R> narrow_camera(const CameraRec<double>& c) {
+    CameraRec<R> o;
+    for (int k = 0; k < 3; ++k) {
+        o.origin[k] = R(c.origin[k]); o.lower_left_corner[k] = R(c.lower_left_corner[k]);
+        o.horizontal[k] = R(c.horizontal[k]); o.vertical[k] = R(c.vertical[k]); o.u[k] = R(c.u[k]); o.v[k] = R(c.v[k]);
+    }
+    o.lens_radius = R(c.lens_radius); o.open_time = R(c.open_time); o.close_time = R(c.close_time);
+    return o;
+}
+
+template <typename R>
+int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear, rttnw_stats* stats,
+             int n_threads) {
+    HostScene<R> hs(s->flat);
+    CameraRec<double> cam64;
+    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
+                cam->focus_distance, cam->open_time, cam->close_time, cam64);
+    CameraRec<R> camr = narrow_camera<R>(cam64);
+    RenderConsts rc{};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
+    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 15) / 16;
+    rc.n_chunks = (p->spp + rc.spp_chunk - 1) / rc.spp_chunk;
+    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));
+    const R t_min = R(p->t_min);
+    if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());
+    std::atomic<uint32_t> next_row{0};
+    std::vector<LaneCounters> counters(n_threads);
+    auto worker = [&](int tid) {
+        HostStack stack;
+        LaneCounters& cnt = counters[tid];
+        for (;;) {
+            uint32_t row = next_row.fetch_add(1);
+            if (row >= rc.height) break;
+            for (uint32_t px = 0; px < rc.width; ++px) {
+                V3<R> total;
+                for (uint32_t c = 0; c < rc.n_chunks; ++c) { // one job = (pixel, chunk), folded sequentially
+                    V3<R> acc;
+                    uint32_t s0 = c * rc.spp_chunk, s1 = std::min(rc.spp, s0 + rc.spp_chunk);
+                    for (uint32_t si = s0; si < s1; ++si) {
+                        PathState<R> ps;
+                        path_begin(ps, camr, rc, px, row, si);
+                        while (path_step(ps, hs.view, rc, background, t_min, stack, cnt)) {}
+                        acc = acc + ps.radiance;
+                    }
+                    total = total + acc; // chunk partials added in chunk order (resolve kernel)
+                }
+                V3<R> mean = total / R(rc.spp);
+                size_t o = (size_t(row) * rc.width + px) * 3;
+                out_linear[o] = double(mean.x); out_linear[o + 1] = double(mean.y); out_linear[o + 2] = double(mean.z);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& t : th) t.join();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->samples = uint64_t(rc.width) * rc.height * rc.spp;
+        for (auto& c : counters) {
+            stats->rays += c.rays; stats->nodes_visited += c.nodes; stats->prims_tested += c.prims; stats->texel_fetches += c.texels;
+        }
+        stats->n_nodes = uint32_t(s->flat.nodes.size());
+        stats->n_prims = s->flat.n_prims_in_bvh;
+    }
+    return RTTNW_OK;
+}
+} // namespace
+
+extern "C" {
+int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
+                   rttnw_stats* stats, int n_threads) {
+    if (!s || !s->committed || !cam || !p || !out_linear) return RTTNW_ERR_INVALID;
+    return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
+                                     : render_t<double>(s, cam, p, out_linear, stats, n_threads);
+}
+int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, rects, boxes, insts, media, stack_depth */) {
+    if (!s || !s->committed) return RTTNW_ERR_INVALID;
+    out[0] = uint32_t(s->flat.nodes.size()); out[1] = uint32_t(s->flat.spheres.size()); out[2] = uint32_t(s->flat.moving.size());
+    out[3] = uint32_t(s->flat.rects.size()); out[4] = uint32_t(s->flat.boxes.size()); out[5] = uint32_t(s->flat.insts.size());
+    out[6] = uint32_t(s->flat.media.size()); out[7] = s->flat.stack_depth;
+    return RTTNW_OK;
+}
+int hostsim_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
+                       uint32_t sample, double* out, uint32_t max_out) {
+    using R = double;
+    HostScene<R> hs(s->flat);
+    CameraRec<double> camr;
+    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
+                cam->focus_distance, cam->open_time, cam->close_time, camr);
+    RenderConsts rc{};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth; rc.quirks = p->quirks; rc.seed = p->seed;
+    PathState<R> ps;
+    path_begin(ps, camr, rc, px, row, sample);
+    HostStack stack; NoCounters cnt;
+    uint32_t n = 0;
+    while (n < max_out) {
+        HitRecord<R> rec;
+        if (!world_hit(hs.view, ps.ray, R(p->t_min), ps.key, ps.bounce, rc.quirks, rec, stack, cnt)) break;
+        double* o = out + size_t(n) * 8;
+        o[0] = rec.t; o[1] = rec.p.x; o[2] = rec.p.y; o[3] = rec.p.z; o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z;
+        o[7] = double(rec.mat);
+        ++n;
+        V3<R> att, em;
+        if (!shade(hs.view, rec, ps.key, ps.bounce, ps.ray, att, em, cnt)) break;
+        ps.bounce += 1;
+        if (ps.bounce >= rc.max_depth) break;
+    }
+    return int(n);
+}
+}

@@ -1,0 +1,100 @@
+"""The product's tracing core + lowering (host build, tests/hostsim) against the oracle.
+
+This is the logic gate that can run without a GPU: same rt_core.hpp / scene_lower.cpp the kernels are
+compiled from, same job/chunk accumulation order as the trace + resolve kernels.  f64 must agree with
+the oracle to rounding on every scene of the catalogue; f32 must agree statistically.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from golden_cases import CASES, load
+from oracle import rto
+from rttnw_amd import abi
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_core_f64_equals_golden(hostsim, scenes_lib, earth, case):
+    key, name, w, h, spp, chunk, param = case
+    sc, setup = util.build(hostsim, scenes_lib, name, earth, param)
+    cam, p = util.params_for(setup, w, h, spp, spp_chunk=chunk, precision=abi.F64)
+    lin, _ = util.hostsim_render(hostsim, sc, cam, p)
+    g = load()[key + "_linear"]
+    d = np.abs(lin - g)
+    # recursion (oracle) vs throughput loop (core) differ by rounding only
+    assert d.max() <= 1e-12 * max(1.0, g.max()), (key, d.max())
+
+
+def test_core_counts_match_oracle_rays(hostsim, oracle, scenes_lib, earth):
+    """Same number of world.hit() calls as the oracle; far fewer node visits than the reference's tree."""
+    for name in ("cornell_box", "final_scene"):
+        so, setup = util.build(oracle, scenes_lib, name, earth)
+        sh, _ = util.build(hostsim, scenes_lib, name, earth)
+        cam, p = util.params_for(setup, 32, 32, 8, spp_chunk=4, collect_counters=1)
+        _, _, st_o = rto.render(so, cam, p)
+        _, st_h = util.hostsim_render(hostsim, sh, cam, p)
+        assert st_h.rays == st_o.rays and st_h.samples == st_o.samples == 32 * 32 * 8
+        if name == "final_scene":
+            assert st_h.nodes_visited < st_o.nodes_visited / 3
+
+
+def test_core_f32_is_statistically_equal(hostsim, oracle, scenes_lib, earth):
+    """f32 shares every uniform's top 24 bits with f64, so images differ only through rare branch flips."""
+    for name, tol in (("cornell_box", 0.01), ("final_scene", 0.03)):
+        so, setup = util.build(oracle, scenes_lib, name, earth)
+        sh, _ = util.build(hostsim, scenes_lib, name, earth)
+        cam, p = util.params_for(setup, 48, 48, 32)
+        lo, _, _ = rto.render(so, cam, p)
+        p.precision = abi.F32
+        lh, _ = util.hostsim_render(hostsim, sh, cam, p)
+        assert abs(lh.mean() - lo.mean()) / lo.mean() < tol
+        # most pixels agree closely; flips touch a minority
+        assert (np.abs(lh - lo).max(axis=2) < 1e-3).mean() > 0.8
+
+
+def test_chunking_changes_only_rounding(hostsim, scenes_lib):
+    sc, setup = util.build(hostsim, scenes_lib, "cornell_box")
+    imgs = []
+    for chunk in (1, 3, 16, 0):
+        cam, p = util.params_for(setup, 24, 24, 16, spp_chunk=chunk)
+        imgs.append(util.hostsim_render(hostsim, sc, cam, p)[0])
+    for im in imgs[1:]:
+        assert np.abs(im - imgs[0]).max() < 1e-13
+
+
+def test_lowering_shapes(hostsim, scenes_lib, earth):
+    dims = (C.c_uint32 * 8)()
+    sc, _ = util.build(hostsim, scenes_lib, "cornell_box")
+    hostsim.lib.hostsim_scene_dims(sc.handle, dims)
+    nodes, sph, mov, rect, box, inst, media, stack = list(dims)
+    assert (sph, mov, rect, box, inst, media) == (0, 0, 6, 2, 2, 0)             # Cube = one box record
+    sc, _ = util.build(hostsim, scenes_lib, "final_scene", earth)
+    hostsim.lib.hostsim_scene_dims(sc.handle, dims)
+    nodes, sph, mov, rect, box, inst, media, stack = list(dims)
+    assert (sph, mov, rect, box, inst, media) == (1007, 1, 1, 400, 1, 2)        # 1000 + 5 free + 2 boundaries
+    assert nodes < 1500 and stack <= 40
+    sc, _ = util.build(hostsim, scenes_lib, "smoke_cornell_box")
+    hostsim.lib.hostsim_scene_dims(sc.handle, dims)
+    assert list(dims)[3:7] == [6, 2, 2, 2]                                       # box boundaries under rotate+translate
+
+
+def test_unsupported_graphs_are_rejected(hostsim):
+    from rttnw_amd import scene as S
+    sc = S.Scene(hostsim)
+    m = sc.lambertian((0.5, 0.5, 0.5))
+    inner = sc.translate(sc.sphere((0, 0, 0), 1.0, m), (1, 0, 0))
+    outer = sc.rotate_y(sc.list([inner]), 10.0)                                  # transform nested in a transformed group
+    sc.set_world(sc.list([outer]))
+    with pytest.raises(abi.RttnwError, match="UNSUPPORTED"):
+        sc.commit()
+    sc2 = S.Scene(hostsim)
+    m2 = sc2.lambertian((0.5, 0.5, 0.5))
+    rect = sc2.rectangle(abi.XY, (0, 1), (0, 1), 0.0, m2)
+    sc2.set_world(sc2.list([sc2.constant_medium(rect, 0.1, (1, 1, 1))]))         # non-closed boundary
+    with pytest.raises(abi.RttnwError, match="UNSUPPORTED"):
+        sc2.commit()
+    sc3 = S.Scene(hostsim)
+    with pytest.raises(abi.RttnwError):
+        sc3.commit()                                                             # world not set

@@ -1,0 +1,199 @@
+"""GPU parity tests proper: the hand-written HIP path, called through the C ABI, against the CPU oracle
+(live and through the committed golden vectors).
+
+Tolerances (north_star: "within a stated per-channel float tolerance under identical RNG seeding"):
+  T1  F64 kernels vs oracle f64: |delta| <= 1e-9 per channel of the linear mean radiance on >= 99.9 % of the
+      pixels (the reference recursion vs the kernel's throughput loop, FMA contraction and OCML-vs-glibc
+      transcendentals differ by rounding; a rounding-induced branch flip is the allowed remainder), and
+      RGBA8 identical on >= 99.9 % of pixels.
+  T2  F32 kernels vs oracle f64 at equal seeds: image mean within 1 %, >= 80 % of pixels within 1e-3 at
+      low spp (f32 shares the top 24 bits of every uniform, so only rare branch flips differ), and RGBA8
+      within 1 LSB on >= 97 % of pixels at 256 spp.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from golden_cases import CASES, load
+from oracle import rto
+from rttnw_amd import abi, render, tiles
+
+pytestmark = pytest.mark.gpu
+
+T1_ABS = 1e-9
+
+
+def gpu_render(gpu, sc, cam, p):
+    lin, rgba, st = render.render_host(sc, cam, p)
+    return lin, rgba, st
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_T1_f64_vs_golden(gpu, scenes_lib, earth, case):
+    key, name, w, h, spp, chunk, param = case
+    sc, setup = util.build(gpu, scenes_lib, name, earth, param)
+    cam, p = util.params_for(setup, w, h, spp, spp_chunk=chunk, precision=abi.F64)
+    lin, rgba, st = gpu_render(gpu, sc, cam, p)
+    g = load()
+    d = np.abs(lin - g[key + "_linear"]).max(axis=2)
+    frac_ok = (d <= T1_ABS).mean()
+    assert frac_ok >= 0.999, (key, frac_ok, d.max())
+    assert (rgba == g[key + "_rgba8"]).all(axis=2).mean() >= 0.999
+    assert st.samples == w * h * spp and st.kernel_ms > 0
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "final_scene"])
+def test_T1_f64_vs_live_oracle_and_counters(gpu, oracle, hostsim, scenes_lib, earth, name):
+    sg, setup = util.build(gpu, scenes_lib, name, earth)
+    so, _ = util.build(oracle, scenes_lib, name, earth)
+    sh, _ = util.build(hostsim, scenes_lib, name, earth)
+    cam, p = util.params_for(setup, 96, 96, 8, spp_chunk=4, precision=abi.F64, collect_counters=1, seed=77)
+    lin, rgba, st = gpu_render(gpu, sg, cam, p)
+    lo, ro, st_o = rto.render(so, cam, p)
+    d = np.abs(lin - lo).max(axis=2)
+    assert (d <= T1_ABS).mean() >= 0.999, (d.max(), (d > T1_ABS).sum())
+    assert (rgba == ro).all(axis=2).mean() >= 0.999
+    # device counters: same world.hit() count as the oracle, same node/primitive reads as the host build of
+    # the same traversal (on the agreeing paths; allow the rare flipped path)
+    _, st_h = util.hostsim_render(hostsim, sh, cam, p)
+    assert abs(int(st.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
+    assert abs(int(st.nodes_visited) - int(st_h.nodes_visited)) <= 1e-3 * st_h.nodes_visited
+    assert abs(int(st.prims_tested) - int(st_h.prims_tested)) <= 1e-3 * st_h.prims_tested
+    assert st.texel_fetches == st_h.texel_fetches or abs(int(st.texel_fetches) - int(st_h.texel_fetches)) <= 1e-3 * st_h.texel_fetches
+
+
+@pytest.mark.parametrize("name,mean_tol", [("cornell_box", 0.01), ("final_scene", 0.02)])
+def test_T2_f32_vs_oracle(gpu, oracle, scenes_lib, earth, name, mean_tol):
+    sg, setup = util.build(gpu, scenes_lib, name, earth)
+    so, _ = util.build(oracle, scenes_lib, name, earth)
+    cam, p = util.params_for(setup, 64, 64, 256, precision=abi.F32)
+    lin, rgba, _ = gpu_render(gpu, sg, cam, p)
+    p64 = util.params_for(setup, 64, 64, 256)[1]
+    lo, ro, _ = rto.render(so, cam, p64)
+    assert abs(lin.mean() - lo.mean()) / lo.mean() < mean_tol
+    per_channel = np.abs(lin.mean(axis=(0, 1)) - lo.mean(axis=(0, 1))) / lo.mean(axis=(0, 1))
+    assert per_channel.max() < 2 * mean_tol
+    lsb = np.abs(rgba[..., :3].astype(int) - ro[..., :3].astype(int)).max(axis=2)
+    assert (lsb <= 1).mean() >= 0.97, (lsb <= 1).mean()
+    assert np.isfinite(lin).all()
+
+
+def test_f32_low_spp_shares_decisions_with_f64(gpu, oracle, scenes_lib):
+    sg, setup = util.build(gpu, scenes_lib, "cornell_box")
+    so, _ = util.build(oracle, scenes_lib, "cornell_box")
+    cam, p = util.params_for(setup, 64, 64, 16, precision=abi.F32)
+    lin, _, _ = gpu_render(gpu, sg, cam, p)
+    lo, _, _ = rto.render(so, cam, util.params_for(setup, 64, 64, 16)[1])
+    assert (np.abs(lin - lo).max(axis=2) < 1e-3).mean() > 0.8
+
+
+@pytest.mark.parametrize("precision", [abi.F64, abi.F32])
+def test_deterministic_and_schedule_independent(gpu, scenes_lib, earth, precision):
+    """Bit-identical run to run, and for any chunking of the same per-pixel fold only rounding differs."""
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
+    cam, p = util.params_for(setup, 72, 40, 12, spp_chunk=4, precision=precision)
+    a = gpu_render(gpu, sc, cam, p)
+    b = gpu_render(gpu, sc, cam, p)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    p2 = util.params_for(setup, 72, 40, 12, spp_chunk=12, precision=precision)[1]
+    c = gpu_render(gpu, sc, cam, p2)
+    tol = 1e-12 if precision == abi.F64 else 2e-5
+    assert np.abs(c[0] - a[0]).max() <= tol * max(1.0, a[0].max())
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("precision", [abi.F64, abi.F32])
+def test_tile_partition_is_bit_identical_to_one_gpu(gpu, scenes_lib, world, precision):
+    """Emulates N GPUs on one: render each rank's tiles, concatenate the packed buffers like the gather
+    does, un-tile on the device — the image must equal the 1-GPU image bit for bit."""
+    import torch
+    sc, setup = util.build(gpu, scenes_lib, "cornell_box")
+    w, h = 100, 52
+    cam, p1 = util.params_for(setup, w, h, 6, spp_chunk=3, precision=precision)
+    one_lin, one_rgba, _ = gpu_render(gpu, sc, cam, p1)
+    lay = tiles.layout(w, h, world)
+    dt = torch.float32 if precision == abi.F32 else torch.float64
+    gathered = torch.zeros((world, lay["pixels_per_rank"], 4), dtype=dt, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        p = util.params_for(setup, w, h, 6, spp_chunk=3, precision=precision, tile_rank=r, tile_world=world)[1]
+        rc = gpu.render_tiles_device(sc.handle, C.byref(cam), C.byref(p), gathered[r].data_ptr(), stream, None)
+        abi.check(rc, gpu, "render_tiles_device")
+    lin = torch.zeros((h, w, 3), dtype=dt, device="cuda")
+    rgba = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    abi.check(gpu.untile_device(w, h, world, precision, gathered.data_ptr(), lin.data_ptr(), rgba.data_ptr(), stream),
+              gpu, "untile_device")
+    torch.cuda.synchronize()
+    assert np.array_equal(lin.cpu().numpy().astype(np.float64), one_lin)
+    assert np.array_equal(rgba.cpu().numpy(), one_rgba)
+    # and the packed layout is the documented one
+    ref = tiles.untile_reference(gathered.cpu().numpy(), w, h, world)
+    assert np.array_equal(ref.astype(np.float64), one_lin)
+
+
+def test_device_renderer_single_rank(gpu, scenes_lib):
+    import torch
+    sc, setup = util.build(gpu, scenes_lib, "cornell_box")
+    cam, p = util.params_for(setup, 64, 64, 4, precision=abi.F32)
+    r = render.DeviceRenderer(sc, cam, p)
+    r.step()
+    torch.cuda.synchronize()
+    lin, rgba, _ = gpu_render(gpu, sc, cam, p)
+    assert np.array_equal(r.linear.cpu().numpy().astype(np.float64), lin)
+    assert np.array_equal(r.rgba8.cpu().numpy(), rgba)
+
+
+def test_edge_cases(gpu, oracle, scenes_lib):
+    sg, setup = util.build(gpu, scenes_lib, "cornell_box")
+    so, _ = util.build(oracle, scenes_lib, "cornell_box")
+    for (w, h, spp, depth) in [(1, 1, 1, 50), (7, 3, 1, 50), (9, 17, 3, 1), (16, 8, 2, 2)]:
+        cam, p = util.params_for(setup, w, h, spp, max_depth=depth)
+        lin, rgba, _ = gpu_render(gpu, sg, cam, p)
+        lo, ro, _ = rto.render(so, cam, p)
+        assert np.abs(lin - lo).max() <= T1_ABS and np.array_equal(rgba, ro)
+    # empty world: every ray misses -> background everywhere
+    from rttnw_amd import scene as S
+    sc = S.Scene(gpu)
+    sc.set_world(sc.list())
+    sc.commit()
+    cam = S.camera_desc((0, 0, 0), (0, 0, -1), 40.0, 1.0)
+    p = S.make_params(8, 8, 2, background=(0.7, 0.8, 1.0))
+    lin, rgba, _ = gpu_render(gpu, sc, cam, p)
+    assert np.allclose(lin, [0.7, 0.8, 1.0], atol=1e-15)
+    # argument errors
+    bad = S.make_params(8, 8, 0)
+    with pytest.raises(abi.RttnwError):
+        gpu_render(gpu, sc, cam, bad)
+    with pytest.raises(abi.RttnwError):
+        gpu_render(gpu, sc, cam, S.make_params(8, 8, 1, tile_world=2))
+
+
+def test_spheres_stress_scene_matches_oracle(gpu, oracle, scenes_lib):
+    """Deep-BVH scene (BASELINE.md config 5 at a size the oracle's O(n^2 log n) reference builder can do)."""
+    n = 3000
+    sg, setup = util.build(gpu, scenes_lib, "spheres_1m", param=n)
+    so, _ = util.build(oracle, scenes_lib, "spheres_1m", param=n)
+    cam, p = util.params_for(setup, 64, 64, 4, spp_chunk=2)
+    lin, rgba, _ = gpu_render(gpu, sg, cam, p)
+    lo, ro, _ = rto.render(so, cam, p)
+    assert (np.abs(lin - lo).max(axis=2) <= T1_ABS).mean() >= 0.999
+
+
+def test_full_size_invariants(gpu, scenes_lib, earth):
+    """BASELINE sizes are beyond the oracle's reach in a test, so check size-independent properties on the
+    headline config (final_scene 800x800): determinism across the partition, the light patch saturates,
+    linearity of the estimator in spp (mean of two disjoint sample sets == the joint render)."""
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
+    cam, p = util.params_for(setup, 800, 800, 8, precision=abi.F32, spp_chunk=4)
+    lin, rgba, st = gpu_render(gpu, sc, cam, p)
+    assert st.samples == 800 * 800 * 8 and np.isfinite(lin).all() and lin.min() >= 0
+    assert (rgba[..., 3] == 255).all()
+    assert (rgba[20:60, 300:400, :3] == 255).all()                              # inside the ceiling light
+    # chunk sums are disjoint sample sets: spp 8 with chunk 4 == average of samples [0,4) and [4,8)
+    cam4, p4 = util.params_for(setup, 800, 800, 4, precision=abi.F32, spp_chunk=4)
+    lin4, _, _ = gpu_render(gpu, sc, cam4, p4)
+    half_b = lin * 2 - lin4                                                      # mean of samples [4,8)
+    assert half_b.min() > -1e-3
+    assert abs(half_b.mean() - lin4.mean()) / lin4.mean() < 0.05

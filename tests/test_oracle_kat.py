@@ -1,0 +1,372 @@
+"""T0 — known-answer tests that pin the CPU oracle to the reference's formulas.
+
+The expected values are closed-form consequences of the cited reference lines (derived by hand /
+NumPy), not outputs of the reference: it has no tests and cannot be built or seeded here.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle import rto
+from rttnw_amd import abi
+from rttnw_amd import scene as S
+
+REL = 1e-12
+
+
+def close(a, b, tol=REL):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b)))
+
+
+def probe_camera(o, cam):
+    out, p = rto.darr(*([0.0] * 24))
+    assert o.probe_camera(C.byref(cam), p) == 0
+    names = ["origin", "llc", "horizontal", "vertical", "u", "v", "w"]
+    d = {n: out[3 * i:3 * i + 3].copy() for i, n in enumerate(names)}
+    d["lens_radius"], d["open"], d["close"] = out[21:24]
+    return d
+
+
+def hit(o, sc, hid, org, d, time=0.0, t_min=0.001, t_max=1e30, bounce=0, quirks=abi.QUIRKS_REFERENCE, key=(1, 0, 0)):
+    _, ray = rto.darr(*org, *d, time)
+    rec, rp = rto.darr(*([0.0] * 11))
+    r = o.probe_hit(sc.handle, hid, ray, t_min, t_max, key[0], key[1], key[2], bounce, quirks, rp)
+    if r == 0:
+        return None
+    assert r == 1
+    return dict(t=rec[0], p=rec[1:4].copy(), n=rec[4:7].copy(), u=rec[7], v=rec[8], front=bool(rec[9]), mat=int(rec[10]))
+
+
+# E1 — camera.rs:32-61 with main.rs:137-150 (cornell_box)
+def test_E1_camera_cornell(oracle):
+    cam = S.camera_desc((278, 278, -800), (278, 278, 0), 40.0, 1.0)
+    c = probe_camera(oracle, cam)
+    assert close(c["w"], [0, 0, -1]) and close(c["u"], [-1, 0, 0]) and close(c["v"], [0, 1, 0])
+    hh = math.tan(math.radians(20.0))
+    assert close(hh, 0.36397023426620234)
+    assert close(c["llc"], [281.639702342662, 274.360297657338, -790], 1e-11)
+    assert close(c["horizontal"], [-7.279404685324, 0, 0], 1e-11)
+    assert close(c["vertical"], [0, 7.279404685324, 0], 1e-11)
+    out, p = rto.darr(*([0.0] * 7))
+    oracle.probe_camera_ray(C.byref(cam), 0.5, 0.5, 1, 0, 0, p)
+    assert close(out[3:6], [0, 0, 10], 1e-11)          # aperture 0: centre ray dir = (0,0,10)
+    assert close(out[0:3], [278, 278, -800]) and 0.0 <= out[6] < 1.0
+
+
+# E2 — final_scene camera, main.rs:165-178
+def test_E2_camera_final(oracle):
+    cam = S.camera_desc((478, 278, -600), (278, 278, 0), 40.0, 1.0)
+    c = probe_camera(oracle, cam)
+    assert close(c["w"], [0.316227766017, 0, -0.948683298051], 1e-11)
+    assert close(c["u"], [-0.948683298051, 0, -0.316227766017], 1e-11)
+    assert close(c["v"], [0, 1, 0])
+    assert close(c["llc"], [478.29064716219, 274.360297657338, -589.362192078709], 1e-11)
+    assert close(c["horizontal"], [-6.905849644718, 0, -2.301949881573], 1e-11)
+    assert close(c["vertical"], [0, 7.279404685324, 0], 1e-11)
+
+
+# E3 — random_scene camera, main.rs:67-77
+def test_E3_camera_random_scene(oracle):
+    cam = S.camera_desc((13, 2, 3), (0, 0, 0), 20.0, 16.0 / 9.0, aperture=0.1)
+    c = probe_camera(oracle, cam)
+    assert close(c["w"], [0.963624111659, 0.148249863332, 0.222374794998], 1e-11)
+    assert close(c["u"], [0.224859506699, 0, -0.974391195695], 1e-11)
+    assert close(c["v"], [-0.144453361594, 0.988949937066, -0.033335391137], 1e-11)
+    assert close(c["llc"], [2.913601616218, -1.226284198068, 3.889457250996], 1e-11)
+    assert close(c["horizontal"], [1.409735036437, 0, -6.10885182456], 1e-11)
+    assert close(c["vertical"], [-0.509420502061, 3.487571129492, -0.117558577399], 1e-11)
+    assert close(c["lens_radius"], 0.05)
+
+
+@pytest.fixture()
+def sc(oracle):
+    return S.Scene(oracle)
+
+
+# E4 / E5 — Sphere::hit + uv, hittable.rs:77-123
+def test_E4_sphere_unit_dir(oracle, sc):
+    s = sc.sphere((0, 0, 0), 1.0, sc.lambertian((0.5, 0.5, 0.5)))
+    r = hit(oracle, sc, s, (0, 0, -5), (0, 0, 1))
+    assert close(r["t"], 4) and close(r["p"], [0, 0, -1]) and close(r["n"], [0, 0, -1]) and r["front"]
+    assert close(r["u"], 0.75) and close(r["v"], 0.5)
+
+
+def test_E5_sphere_nonunit_dir(oracle, sc):
+    s = sc.sphere((1.5, 1, 3), 2.0, sc.lambertian((0.5, 0.5, 0.5)))
+    r = hit(oracle, sc, s, (1, 2, -10), (0.1, -0.2, 4))
+    assert close(r["t"], 2.7658494191432488)
+    assert close(r["p"], [1.276584941914, 1.446830116171, 1.063397676573], 1e-11)
+    assert close(r["n"], [-0.111707529043, 0.223415058086, -0.968301161714], 1e-11)
+    assert r["front"] and close(r["u"], 0.7682800120271379) and close(r["v"], 0.5717205298189993)
+
+
+def test_sphere_inclusive_bounds_and_inside(oracle, sc):
+    s = sc.sphere((0, 0, 0), 1.0, sc.lambertian((0.5, 0.5, 0.5)))
+    # Q10: root == t_max is accepted (only `<` / `>` reject) — hittable.rs:102,105
+    assert hit(oracle, sc, s, (0, 0, -5), (0, 0, 1), t_max=4.0)["t"] == 4.0
+    assert hit(oracle, sc, s, (0, 0, -5), (0, 0, 1), t_max=3.999) is None
+    # origin inside: near root negative -> far root, normal flipped against the ray, front_face false
+    r = hit(oracle, sc, s, (0, 0, 0), (0, 0, 1))
+    assert close(r["t"], 1) and close(r["n"], [0, 0, -1]) and not r["front"]
+
+
+# E6 — Bound::hit, bound.rs:13-32
+def test_E6_aabb(oracle):
+    _, box = rto.darr(0, 0, 0, 1, 1, 1)
+    _, r1 = rto.darr(-1, .5, .5, 1, .1, .1)
+    _, r2 = rto.darr(-1, 2.5, .5, 1, .1, .1)
+    assert oracle.probe_aabb(box, r1, 0.001, 1e30) == 1
+    assert oracle.probe_aabb(box, r2, 0.001, 1e30) == 0
+    # strict `tmax < tmin`: a grazing ray along a face still passes (Q10)
+    _, r3 = rto.darr(-1, 1.0, .5, 1, 0, 0)
+    assert oracle.probe_aabb(box, r3, 0.001, 1e30) == 1
+
+
+# E7 — YRotate back-rotation quirk Q1, hittable.rs:700-705
+def test_E7_yrotate_quirk(oracle, sc):
+    m = sc.lambertian((0.73, 0.73, 0.73))
+    wall = sc.rectangle(abi.XY, (0, 200), (-50, 50), 0.0, m)      # object-space z = 0 face
+    rot = sc.rotate_y(wall, 15.0)
+    s15, c15 = 0.25881904510252074, 0.9659258262890683
+    # world ray that, rotated into object space, is o=(100,0,-10), d=(0,0,1): hits p_obj=(100,0,0), n_obj=(0,0,-1)
+    o_obj, d_obj = np.array([100.0, 0, -10]), np.array([0.0, 0, 1])
+    inv = lambda v: np.array([c15 * v[0] + s15 * v[2], v[1], -s15 * v[0] + c15 * v[2]])  # correct object->world
+    r = hit(oracle, sc, rot, inv(o_obj), inv(d_obj))
+    assert close(r["t"], 10, 1e-10)
+    assert close(r["p"][0], 96.59258262890683, 1e-10)
+    assert close(r["p"][2], -24.999999999999996, 1e-10)          # a correct rotation gives -25.8819...
+    assert close(r["n"][0], -0.25881904510252074, 1e-10) and close(r["n"][2], -0.8989385281812876, 1e-10)
+    assert close(np.dot(r["n"], r["n"]), 0.87508, 1e-5)          # non-unit normal
+    fixed = hit(oracle, sc, rot, inv(o_obj), inv(d_obj), quirks=0)
+    assert close(fixed["p"][2], -25.881904510252074, 1e-10) and close(fixed["n"][2], -0.9659258262890683, 1e-10)
+
+
+# E8 / E9 — material.rs:173-176, vec3.rs:112-121
+def test_E8_schlick(oracle):
+    assert close(oracle.probe_schlick(0.5, 1 / 1.5), 0.07)
+    assert close(oracle.probe_schlick(1.0, 1.5), 0.04)
+
+
+def test_E9_refract_reflect(oracle):
+    out, p = rto.darr(0, 0, 0)
+    _, v = rto.darr(1 / math.sqrt(2), -1 / math.sqrt(2), 0)
+    _, n = rto.darr(0, 1, 0)
+    oracle.probe_refract(v, n, 1 / 1.5, p)
+    assert close(out, [0.471404520791, -0.881917103688, 0], 1e-11)
+    oracle.probe_reflect(v, n, p)
+    assert close(out, [1 / math.sqrt(2), 1 / math.sqrt(2), 0])
+
+
+# E10 — ConstantMedium::hit, hittable.rs:740-790 with scenes.rs:282-292
+def test_E10_constant_medium(oracle, sc):
+    boundary = sc.sphere((360, 150, 145), 70.0, sc.dielectric(1.5))
+    med = sc.constant_medium(boundary, 0.2, (0.2, 0.4, 0.9))
+    # find a key whose medium draw (block bounce+1, slot 0) is known, then check t = t1 - 5 ln(U) / |d|
+    U = oracle.probe_uniform(7, 3, 5, 1, 0)
+    r = hit(oracle, sc, med, (360, 150, -600), (0, 0, 2), key=(7, 3, 5))
+    t1, t2, length = 337.5, 407.5, 2.0
+    hd = -5.0 * math.log(U)
+    if hd > (t2 - t1) * length:
+        assert r is None
+    else:
+        assert close(r["t"], t1 + hd / length) and close(r["n"], [1, 0, 0]) and r["front"] and r["u"] == 0 and r["v"] == 0
+    # with U = 0.5 the ledger value is t = 339.23286795139984
+    assert close(337.5 + (-5 * math.log(0.5)) / 2.0, 339.23286795139984)
+    # interval clipped empty by t_max -> None before any draw (Q13)
+    assert hit(oracle, sc, med, (360, 150, -600), (0, 0, 2), t_max=300.0, key=(7, 3, 5)) is None
+
+
+# E12 — gamma/quantise, main.rs:219-225
+def test_E12_quantise(oracle):
+    assert oracle.probe_quantise(0.0) == 0
+    assert oracle.probe_quantise(0.25) == 128
+    assert oracle.probe_quantise(0.998001) == 255 and oracle.probe_quantise(50.0) == 255
+    assert oracle.probe_quantise(float("nan")) == 0
+    assert oracle.probe_quantise(-1.0) == 0      # sqrt(-1) = NaN -> 0
+
+
+# Rectangle: half-open extents (Q9), uv, normal — hittable.rs:503-529
+def test_rectangle(oracle, sc):
+    m = sc.lambertian((0.5, 0.5, 0.5))
+    r = sc.rectangle(abi.XZ, (213, 343), (227, 332), 554.0, m)
+    h = hit(oracle, sc, r, (278, 0, 279.5), (0, 1, 0))
+    assert close(h["t"], 554) and close(h["n"], [0, -1, 0]) and not h["front"]   # outward +y, ray goes +y
+    assert close(h["u"], (278 - 213) / 130) and close(h["v"], (279.5 - 227) / 105)
+    assert hit(oracle, sc, r, (213, 0, 300), (0, 1, 0)) is not None               # start inclusive
+    assert hit(oracle, sc, r, (343, 0, 300), (0, 1, 0)) is None                   # end exclusive
+    assert hit(oracle, sc, r, (300, 0, 332), (0, 1, 0)) is None
+
+
+# Cube = six rectangles in a fixed order; Translate/YRotate compose — hittable.rs:556-629
+def test_cube_and_translate(oracle, sc):
+    m = sc.lambertian((0.5, 0.5, 0.5))
+    cube = sc.cube((0, 0, 0), (165, 330, 165), m)
+    h = hit(oracle, sc, cube, (50, 100, -10), (0, 0, 1))
+    assert close(h["t"], 10) and close(h["n"], [0, 0, -1]) and close(h["u"], 50 / 165) and close(h["v"], 100 / 330)
+    moved = sc.translate(cube, (265, 0, 295))
+    h2 = hit(oracle, sc, moved, (315, 100, 0), (0, 0, 1))
+    assert close(h2["t"], 295) and close(h2["p"], [315, 100, 295]) and h2["front"]
+    out, p = rto.darr(*([0.0] * 6))
+    assert oracle.probe_bbox(sc.handle, moved, 0.0, 1.0, p) == 1
+    assert close(out, [265, 0, 295, 430, 330, 460])
+
+
+# List: a later item with EQUAL t replaces the earlier one — hittable.rs:157-159
+def test_list_tie_later_wins(oracle, sc):
+    a, b = sc.lambertian((0.1, 0.1, 0.1)), sc.lambertian((0.9, 0.9, 0.9))
+    floor = sc.rectangle(abi.XZ, (0, 555), (0, 555), 0.0, a)
+    bottom = sc.rectangle(abi.XZ, (100, 200), (100, 200), 0.0, b)
+    l1, l2 = sc.list([floor, bottom]), sc.list([bottom, floor])
+    assert hit(oracle, sc, l1, (150, 10, 150), (0, -1, 0))["mat"] == b
+    assert hit(oracle, sc, l2, (150, 10, 150), (0, -1, 0))["mat"] == a
+
+
+# MovingSphere: centre lerped by ray.time, u = v = 0 — hittable.rs:187-231
+def test_moving_sphere(oracle, sc):
+    m = sc.lambertian((0.7, 0.3, 0.1))
+    ms = sc.moving_sphere((400, 400, 400), (430, 400, 400), 0.0, 1.0, 50.0, m)
+    h = hit(oracle, sc, ms, (415, 400, 0), (0, 0, 1), time=0.5)
+    assert close(h["t"], 350) and h["u"] == 0 and h["v"] == 0
+    assert hit(oracle, sc, ms, (460, 400, 0), (0, 0, 1), time=0.0) is None       # centre (400,..): 60 > r
+    assert close(hit(oracle, sc, ms, (460, 400, 0), (0, 0, 1), time=1.0)["t"], 360)  # centre (430,..)
+
+
+# Perlin tables / noise — noise.rs:15-29,50-108; texture.rs:54-58
+def test_perlin(oracle):
+    sc = S.Scene(oracle, 1234)
+    t = sc.noise(0.1)
+    pts = np.zeros(768)
+    perm = np.zeros(768, dtype=np.uint32)
+    oracle.probe_perlin_tables(sc.handle, t, pts.ctypes.data_as(C.POINTER(C.c_double)), perm.ctypes.data_as(C.POINTER(C.c_uint32)))
+    for k in range(3):
+        assert sorted(perm[256 * k:256 * (k + 1)]) == list(range(256))          # permutations of 0..255
+    assert pts.min() >= -1 and pts.max() < 1 and abs(pts.mean()) < 0.1             # U[-1,1), not normalised
+    # noise at a lattice point is 0 (all corner weights vanish or dot with zero offset)
+    out, p = rto.darr(0, 0)
+    _, q = rto.darr(3.0, -2.0, 7.0)
+    oracle.probe_perlin(sc.handle, t, q, 7, p)
+    assert abs(out[0]) < 1e-15
+    # independent NumPy restatement of noise() at a generic point
+    P = pts.reshape(256, 3)
+    x = np.array([1.3, -2.6, 0.45])
+    f = np.floor(x)
+    u = x - f
+    i = f.astype(int)
+    uu = u * u * (3 - 2 * u)
+    acc = 0.0
+    for a in range(2):
+        for b in range(2):
+            for c in range(2):
+                h = perm[(i[0] + a) & 255] ^ perm[256 + ((i[1] + b) & 255)] ^ perm[512 + ((i[2] + c) & 255)]
+                w = np.array([u[0] - a, u[1] - b, u[2] - c])
+                acc += ((a * uu[0] + (1 - a) * (1 - uu[0])) * (b * uu[1] + (1 - b) * (1 - uu[1]))
+                        * (c * uu[2] + (1 - c) * (1 - uu[2])) * np.dot(P[h], w))
+    _, q = rto.darr(*x)
+    oracle.probe_perlin(sc.handle, t, q, 1, p)
+    assert close(out[0], acc, 1e-12) and close(out[1], acc, 1e-12)               # turbulence depth 1 = noise
+    # NoiseTexture::value = 0.5 (1 + sin(scale z + 10 turb(p,7))), grey
+    oracle.probe_perlin(sc.handle, t, q, 7, p)
+    col, cp = rto.darr(0, 0, 0)
+    oracle.probe_tex(sc.handle, t, 0.0, 0.0, q, cp)
+    g = 0.5 * (1 + math.sin(0.1 * x[2] + 10 * out[1]))
+    assert close(col, [g, g, g])
+
+
+# ImageTexture: nearest texel, v flipped, clamps, cyan when missing — texture.rs:78-106
+def test_image_texture(oracle):
+    sc = S.Scene(oracle)
+    img = np.zeros((2, 4, 4), dtype=np.uint8)
+    img[0, 0] = (255, 0, 0, 255)
+    img[1, 3] = (0, 51, 255, 7)
+    t = sc.image(img)
+    col, cp = rto.darr(0, 0, 0)
+    _, q = rto.darr(0, 0, 0)
+    oracle.probe_tex(sc.handle, t, 0.0, 1.0, q, cp)      # v=1 -> row 0
+    assert close(col, [1, 0, 0])
+    oracle.probe_tex(sc.handle, t, 1.0, 0.0, q, cp)      # u=1 -> i clamps to w-1; v=0 -> row h-1
+    assert close(col, [0, 0.2, 1])
+    oracle.probe_tex(sc.handle, t, 5.0, -3.0, q, cp)     # clamped
+    assert close(col, [0, 0.2, 1])
+    cyan = sc.image(None)
+    oracle.probe_tex(sc.handle, cyan, 0.3, 0.3, q, cp)
+    assert close(col, [0, 1, 1])
+
+
+# Checker — texture.rs:20-29
+def test_checker(oracle):
+    sc = S.Scene(oracle)
+    t = sc.checker(sc.solid(0.2, 0.3, 0.1), sc.solid(0.9, 0.9, 0.9))
+    col, cp = rto.darr(0, 0, 0)
+    for pt in [(0.1, 0.1, 0.1), (0.1, 0.1, -0.1), (0.4, 0.2, 0.3)]:
+        _, q = rto.darr(*pt)
+        oracle.probe_tex(sc.handle, t, 0, 0, q, cp)
+        s = math.sin(10 * pt[0]) * math.sin(10 * pt[1]) * math.sin(10 * pt[2])
+        assert close(col, [0.2, 0.3, 0.1] if s < 0 else [0.9, 0.9, 0.9])
+
+
+# Materials — material.rs:89-100,134-149,179-204,242-266
+def test_materials(oracle, sc):
+    ray = (0.0, 0.0, -5.0, 0.3, -0.2, 1.0, 0.25)
+    rec = (4.0, 1.2, -0.8, -1.0, 0.0, 0.0, -1.0, 0.3, 0.6, 1.0, 0.0)    # t, p, n, u, v, front, mat
+    _, rp = rto.darr(*ray)
+    _, cp = rto.darr(*rec)
+    out, op = rto.darr(*([0.0] * 13))
+
+    def ball(key, bounce):
+        it = 0
+        while True:
+            r = np.array([oracle.probe_uniform(key[0], key[1], key[2], bounce + 1, 32 + 3 * it + c) for c in range(3)])
+            v = 2 * r - 1
+            if v @ v < 1:
+                return v
+            it += 1
+    key = (11, 22, 33)
+    b = ball(key, 4)
+    lam = sc.lambertian((0.1, 0.2, 0.3))
+    oracle.probe_scatter(sc.handle, lam, rp, cp, *key, 4, op)
+    assert out[0] == 1 and close(out[1:4], [0.1, 0.2, 0.3]) and close(out[4:7], rec[1:4])
+    assert close(out[7:10], (np.array(rec[1:4]) + np.array(rec[4:7]) + b) - np.array(rec[1:4]), 1e-12)
+    met = sc.metal((0.8, 0.8, 0.9), 3.0)                 # fuzz clamps to 1 — material.rs:129
+    oracle.probe_scatter(sc.handle, met, rp, cp, *key, 4, op)
+    d = np.array(ray[3:6])
+    ud = d / np.sqrt(d @ d)
+    n = np.array(rec[4:7])
+    refl = ud - 2 * (ud @ n) * n
+    assert close(out[7:10], refl + 1.0 * b, 1e-12) and out[0] == float((refl + b) @ n > 0)
+    light = sc.diffuse_light((7, 7, 7))
+    oracle.probe_scatter(sc.handle, light, rp, cp, *key, 4, op)
+    assert out[0] == 0 and close(out[10:13], [7, 7, 7])
+    iso = sc.isotropic((0.2, 0.4, 0.9))
+    oracle.probe_scatter(sc.handle, iso, rp, cp, *key, 4, op)
+    assert out[0] == 1 and close(out[7:10], b) and close(out[1:4], [0.2, 0.4, 0.9])
+    glass = sc.dielectric(1.5)
+    oracle.probe_scatter(sc.handle, glass, rp, cp, *key, 4, op)
+    cos_t = min(float(-ud @ n), 1.0)
+    U = oracle.probe_uniform(*key, 5, 16)
+    r0 = ((1 - 1 / 1.5) / (1 + 1 / 1.5)) ** 2
+    reflects = (r0 + (1 - r0) * (1 - cos_t) ** 5) > U
+    if reflects:
+        assert close(out[7:10], refl, 1e-12)
+    else:
+        perp = (1 / 1.5) * (ud + cos_t * n)
+        par = -math.sqrt(abs(1 - perp @ perp)) * n
+        assert close(out[7:10], perp + par, 1e-12)
+    assert close(out[1:4], [1, 1, 1])
+
+
+# Keyed RNG: uniform in [0,1), reproducible, distinct per address (DESIGN.md "RNG")
+def test_rng(oracle):
+    u = np.array([oracle.probe_uniform(1, p, s, b, k) for p in range(8) for s in range(8) for b in range(4) for k in range(8)])
+    assert u.min() >= 0 and u.max() < 1 and len(np.unique(u)) == len(u)
+    assert abs(u.mean() - 0.5) < 0.03 and abs(u.var() - 1 / 12) < 0.01
+    assert oracle.probe_uniform(1, 2, 3, 4, 5) == oracle.probe_uniform(1, 2, 3, 4, 5)
+    # SplitMix64 reference value: mix64(0x9E3779B97F4A7C15) = 0xE220A8397B1DCDAF (first output for seed 0)
+    z = 0x9E3779B97F4A7C15
+    M = (1 << 64) - 1
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    assert z == 0xE220A8397B1DCDAF

@@ -100,6 +100,15 @@ template <> RT_HD double uniform01<double>(uint64_t key, uint32_t ctr) {
 template <> RT_HD float uniform01<float>(uint64_t key, uint32_t ctr) {
     return float(uint32_t(rng_word(key, ctr) >> 40)) * (1.0f / 16777216.0f);
 }
+// Uniform for a draw that goes through log() (the media's free-flight distance, hittable.rs:765): f32 keeps 24
+// SIGNIFICANT bits of the same word instead of its top 24 bits, so that -ln(U)/density keeps f32's relative
+// precision for small U (top-24-bit U near 0.01 would move a fog event by ~0.06 scene units).  May round to 1.0
+// (ln = 0).  f64 is unchanged.
+template <typename R> RT_HD R uniform01_log(uint64_t key, uint32_t ctr);
+template <> RT_HD double uniform01_log<double>(uint64_t key, uint32_t ctr) { return uniform01<double>(key, ctr); }
+template <> RT_HD float uniform01_log<float>(uint64_t key, uint32_t ctr) {
+    return float(rng_word(key, ctr) >> 11) * (1.0f / 9007199254740992.0f);
+}
 // counter = block * 1024 + slot; block 0 = camera, block b+1 = b-th world.hit() of the path
 enum : uint32_t { SLOT_JITTER_U = 0, SLOT_JITTER_V = 1, SLOT_TIME = 2, SLOT_LENS = 8,
                   SLOT_MEDIUM = 0, SLOT_DIELECTRIC = 16, SLOT_SCATTER = 32 };
@@ -178,13 +187,25 @@ RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, V3<R> inv, R tmin
 
 // ---------------------------------------------------------------- primitive tests: t only
 // Sphere::hit — hittable.rs:87-109 (bounds inclusive: only `<` / `>` reject, Q10)
+// f64 evaluates the reference's expression literally.  In f32 the textbook discriminant
+// hb^2 - a*(|oc|^2 - r^2) cancels catastrophically for a small sphere far from the ray origin (the
+// final_scene cluster: r = 10 seen from 1100 units, |oc|^2 ~ 1.2e6 has an ulp of 0.125), so the f32
+// instantiation uses the algebraically identical, cancellation-free form  a*(r^2 - |oc - (hb/a) d|^2).
+template <typename R> RT_HD R sphere_discriminant(V3<R> oc, V3<R> d, R a, R half_b, R radius) {
+    if constexpr (sizeof(R) == 4) {
+        V3<R> l = oc - (half_b / a) * d; // from the centre to the closest point of the ray's line
+        return a * (radius * radius - dot(l, l));
+    } else {
+        R c = dot(oc, oc) - radius * radius;
+        return half_b * half_b - a * c;
+    }
+}
 template <typename R>
 RT_HD bool sphere_t(V3<R> center, R radius, const Ray<R>& ray, R t_min, R t_max, R& t_out) {
     V3<R> oc = ray.o - center;
     R a = dot(ray.d, ray.d);
     R half_b = dot(oc, ray.d);
-    R c = dot(oc, oc) - radius * radius;
-    R disc = half_b * half_b - a * c;
+    R disc = sphere_discriminant(oc, ray.d, a, half_b, radius);
     if (disc < R(0)) return false;
     R sqrtd = rt_sqrt(disc);
     R root = (-half_b - sqrtd) / a;
@@ -499,14 +520,18 @@ RT_HD bool world_hit(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_
         cnt.prim();
         if (!prim_t(sc, bk, bi, bray, -Lim<R>::inf(), Lim<R>::inf(), t1, aux)) continue;
         cnt.prim();
-        if (!prim_t(sc, bk, bi, bray, t1 + R(0.0001), Lim<R>::inf(), t2, aux)) continue;
+        // hittable.rs:751: `record1.t + 0.0001`.  The absolute epsilon must stay above the spacing of R at t1,
+        // or the second query finds the SAME root again (f32: ulp(5000) = 4.9e-4 swallows it and the medium is
+        // skipped); in f64 the guard never binds below |t| ~ 1e11, so the reference value is used unchanged.
+        const R sep = rt_max(R(0.0001), rt_fabs(t1) * (sizeof(R) == 4 ? R(4.8e-7) : R(8.9e-16)));
+        if (!prim_t(sc, bk, bi, bray, t1 + sep, Lim<R>::inf(), t2, aux)) continue;
         t1 = rt_max(t1, t_min);
         t2 = rt_min(t2, closest);
         if (t1 >= t2) continue; // before any draw
         t1 = rt_max(t1, R(0));
         R ray_length = magnitude(ray.d);
         R distance_inside = (t2 - t1) * ray_length;
-        R hit_distance = md.neg_inv_density * rt_log(uniform01<R>(key, rng_ctr(bounce + 1, SLOT_MEDIUM + uint32_t(m))));
+        R hit_distance = md.neg_inv_density * rt_log(uniform01_log<R>(key, rng_ctr(bounce + 1, SLOT_MEDIUM + uint32_t(m))));
         if (hit_distance > distance_inside) continue;
         closest = t1 + hit_distance / ray_length;
         medium = m;

@@ -144,27 +144,14 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
 }
 } // namespace
 
-extern "C" {
-int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
-                   rttnw_stats* stats, int n_threads) {
-    if (!s || !s->committed || !cam || !p || !out_linear) return RTTNW_ERR_INVALID;
-    return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
-                                     : render_t<double>(s, cam, p, out_linear, stats, n_threads);
-}
-int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, rects, boxes, insts, media, stack_depth */) {
-    if (!s || !s->committed) return RTTNW_ERR_INVALID;
-    out[0] = uint32_t(s->flat.nodes.size()); out[1] = uint32_t(s->flat.spheres.size()); out[2] = uint32_t(s->flat.moving.size());
-    out[3] = uint32_t(s->flat.rects.size()); out[4] = uint32_t(s->flat.boxes.size()); out[5] = uint32_t(s->flat.insts.size());
-    out[6] = uint32_t(s->flat.media.size()); out[7] = s->flat.stack_depth;
-    return RTTNW_OK;
-}
-int hostsim_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
-                       uint32_t sample, double* out, uint32_t max_out) {
-    using R = double;
+template <typename R>
+static int probe_path_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
+                        uint32_t sample, double* out, uint32_t max_out) {
     HostScene<R> hs(s->flat);
-    CameraRec<double> camr;
+    CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
-                cam->focus_distance, cam->open_time, cam->close_time, camr);
+                cam->focus_distance, cam->open_time, cam->close_time, cam64);
+    CameraRec<R> camr = narrow_camera<R>(cam64);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth; rc.quirks = p->quirks; rc.seed = p->seed;
     PathState<R> ps;
@@ -184,5 +171,25 @@ int hostsim_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
         if (ps.bounce >= rc.max_depth) break;
     }
     return int(n);
+}
+
+extern "C" {
+int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
+                   rttnw_stats* stats, int n_threads) {
+    if (!s || !s->committed || !cam || !p || !out_linear) return RTTNW_ERR_INVALID;
+    return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
+                                     : render_t<double>(s, cam, p, out_linear, stats, n_threads);
+}
+int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, rects, boxes, insts, media, stack_depth */) {
+    if (!s || !s->committed) return RTTNW_ERR_INVALID;
+    out[0] = uint32_t(s->flat.nodes.size()); out[1] = uint32_t(s->flat.spheres.size()); out[2] = uint32_t(s->flat.moving.size());
+    out[3] = uint32_t(s->flat.rects.size()); out[4] = uint32_t(s->flat.boxes.size()); out[5] = uint32_t(s->flat.insts.size());
+    out[6] = uint32_t(s->flat.media.size()); out[7] = s->flat.stack_depth;
+    return RTTNW_OK;
+}
+int hostsim_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
+                       uint32_t sample, double* out, uint32_t max_out) {
+    return p->precision == RTTNW_F32 ? probe_path_t<float>(s, cam, p, px, row, sample, out, max_out)
+                                     : probe_path_t<double>(s, cam, p, px, row, sample, out, max_out);
 }
 }

@@ -42,7 +42,7 @@ def test_core_counts_match_oracle_rays(hostsim, oracle, scenes_lib, earth):
 
 def test_core_f32_is_statistically_equal(hostsim, oracle, scenes_lib, earth):
     """f32 shares every uniform's top 24 bits with f64, so images differ only through rare branch flips."""
-    for name, tol in (("cornell_box", 0.01), ("final_scene", 0.03)):
+    for name, tol in (("cornell_box", 0.001), ("final_scene", 0.002)):
         so, setup = util.build(oracle, scenes_lib, name, earth)
         sh, _ = util.build(hostsim, scenes_lib, name, earth)
         cam, p = util.params_for(setup, 48, 48, 32)
@@ -51,7 +51,7 @@ def test_core_f32_is_statistically_equal(hostsim, oracle, scenes_lib, earth):
         lh, _ = util.hostsim_render(hostsim, sh, cam, p)
         assert abs(lh.mean() - lo.mean()) / lo.mean() < tol
         # most pixels agree closely; flips touch a minority
-        assert (np.abs(lh - lo).max(axis=2) < 1e-3).mean() > 0.8
+        assert (np.abs(lh - lo).max(axis=2) < 1e-3).mean() > 0.9
 
 
 def test_chunking_changes_only_rounding(hostsim, scenes_lib):

@@ -6,9 +6,11 @@ Tolerances (north_star: "within a stated per-channel float tolerance under ident
       pixels (the reference recursion vs the kernel's throughput loop, FMA contraction and OCML-vs-glibc
       transcendentals differ by rounding; a rounding-induced branch flip is the allowed remainder), and
       RGBA8 identical on >= 99.9 % of pixels.
-  T2  F32 kernels vs oracle f64 at equal seeds: image mean within 1 %, >= 80 % of pixels within 1e-3 at
-      low spp (f32 shares the top 24 bits of every uniform, so only rare branch flips differ), and RGBA8
-      within 1 LSB on >= 97 % of pixels at 256 spp.
+  T2  F32 kernels vs oracle f64 at equal seeds (f32 shares the top 24 bits of every uniform, so the two trace
+      the same paths up to f32 rounding drift and rare branch flips): image mean within 0.2 % overall and
+      0.5 % per channel; at 256 spp RGBA8 within 1 LSB on >= 99 % (cornell_box) / >= 95 % (final_scene: glass,
+      fuzzy metal and the r=10 sphere cluster amplify f32 rounding) of the pixels; at 16 spp >= 95 % of the
+      pixels within 1e-3 of linear radiance.  (Measured on the host build: 99.7 % / 97.2 % / 99.9 %.)
 """
 import ctypes as C
 
@@ -64,19 +66,19 @@ def test_T1_f64_vs_live_oracle_and_counters(gpu, oracle, hostsim, scenes_lib, ea
     assert st.texel_fetches == st_h.texel_fetches or abs(int(st.texel_fetches) - int(st_h.texel_fetches)) <= 1e-3 * st_h.texel_fetches
 
 
-@pytest.mark.parametrize("name,mean_tol", [("cornell_box", 0.01), ("final_scene", 0.02)])
-def test_T2_f32_vs_oracle(gpu, oracle, scenes_lib, earth, name, mean_tol):
+@pytest.mark.parametrize("name,lsb_frac", [("cornell_box", 0.99), ("final_scene", 0.95)])
+def test_T2_f32_vs_oracle(gpu, oracle, scenes_lib, earth, name, lsb_frac):
     sg, setup = util.build(gpu, scenes_lib, name, earth)
     so, _ = util.build(oracle, scenes_lib, name, earth)
     cam, p = util.params_for(setup, 64, 64, 256, precision=abi.F32)
     lin, rgba, _ = gpu_render(gpu, sg, cam, p)
     p64 = util.params_for(setup, 64, 64, 256)[1]
     lo, ro, _ = rto.render(so, cam, p64)
-    assert abs(lin.mean() - lo.mean()) / lo.mean() < mean_tol
+    assert abs(lin.mean() - lo.mean()) / lo.mean() < 0.002
     per_channel = np.abs(lin.mean(axis=(0, 1)) - lo.mean(axis=(0, 1))) / lo.mean(axis=(0, 1))
-    assert per_channel.max() < 2 * mean_tol
+    assert per_channel.max() < 0.005
     lsb = np.abs(rgba[..., :3].astype(int) - ro[..., :3].astype(int)).max(axis=2)
-    assert (lsb <= 1).mean() >= 0.97, (lsb <= 1).mean()
+    assert (lsb <= 1).mean() >= lsb_frac, (lsb <= 1).mean()
     assert np.isfinite(lin).all()
 
 
@@ -86,7 +88,7 @@ def test_f32_low_spp_shares_decisions_with_f64(gpu, oracle, scenes_lib):
     cam, p = util.params_for(setup, 64, 64, 16, precision=abi.F32)
     lin, _, _ = gpu_render(gpu, sg, cam, p)
     lo, _, _ = rto.render(so, cam, util.params_for(setup, 64, 64, 16)[1])
-    assert (np.abs(lin - lo).max(axis=2) < 1e-3).mean() > 0.8
+    assert (np.abs(lin - lo).max(axis=2) < 1e-3).mean() > 0.95
 
 
 @pytest.mark.parametrize("precision", [abi.F64, abi.F32])

@@ -208,6 +208,16 @@ const char* rttnw_last_error(void);
 /* Debug/inspection: sizes of the lowered scene (valid after commit). */
 int rttnw_scene_info(rttnw_scene* s, rttnw_stats* out);
 
+/* Debug/inspection: walk sample `sample` of pixel (px, row; row 0 = top) on the device with the kernels of
+ * `p->precision` and dump every world.hit() of its path, 20 doubles per bounce:
+ *   [0] t  [1..3] p  [4..6] normal  [7] material index  [8] u  [9] v  [10] front_face
+ *   [11..13] ray origin  [14..16] ray direction  [17] ray time  [18] emitted.r  [19] attenuation.r (-1: absorbed)
+ * `out` must hold max_out*20 + 4 doubles: out[max_out*20 .. +3] = the sample's radiance r,g,b (background taken
+ * as black) and its final bounce count, computed by the same path_step() loop the trace kernel runs.
+ * Returns the number of bounces written (<= max_out) or a negative error.  Blocking; test use only. */
+int rttnw_debug_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p,
+                           uint32_t px, uint32_t row, uint32_t sample, double* out, uint32_t max_out);
+
 /* ---------------------------------------------------------------- entry-point table -------- */
 
 /* Scene-building entry points as a table, so one host-side scene catalogue (the `scenes.rs`

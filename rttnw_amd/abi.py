@@ -96,6 +96,8 @@ PRODUCT_FUNCS = [
     ("device_count", C.c_int, []),
     ("scene_info", C.c_int, [scene_p, C.POINTER(Stats)]),
     ("builder", C.c_void_p, []),
+    ("debug_probe_path", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint32,
+                                   C.c_uint32, C.c_void_p, C.c_uint32]),
 ]
 
 SCENES_FUNCS = [

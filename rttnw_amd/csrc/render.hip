@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,7 +53,7 @@ template <typename R, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
-                                                            DeviceCounters* __restrict__ counters) {
+                                                            DeviceCounters* __restrict__ counters, double* __restrict__ dbg) {
     extern __shared__ int32_t lds_stack[];
     LdsStack stack{lds_stack + threadIdx.x, blockDim.x};
     typename CounterSel<COUNT>::type cnt;
@@ -111,6 +113,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                 alive = true;
             }
             if (alive) {
+                if constexpr (COUNT) { // instrumented variant: tap one sample's per-bounce state
+                    if (rc.dbg_on && px == rc.dbg_px && row == rc.dbg_row && s == rc.dbg_sample && ps.bounce < 60) {
+                        double* o = dbg + 1 + ps.bounce * 16;
+                        o[0] = ps.ray.o.x; o[1] = ps.ray.o.y; o[2] = ps.ray.o.z; o[3] = ps.ray.d.x; o[4] = ps.ray.d.y; o[5] = ps.ray.d.z;
+                        o[6] = ps.ray.time; o[7] = ps.throughput.x; o[8] = ps.radiance.x; o[9] = double(lane);
+                        dbg[0] = double(ps.bounce + 1);
+                    }
+                }
                 alive = path_step(ps, sc, rc, background, t_min, stack, cnt);
                 if (!alive) { // main.rs:216: acc + color(...)
                     acc = acc + ps.radiance;
@@ -167,6 +177,44 @@ __global__ void untile_kernel(const R* __restrict__ gathered, R* __restrict__ li
     if (rgba8) {
         rgba8[o * 4] = quantise(r); rgba8[o * 4 + 1] = quantise(g); rgba8[o * 4 + 2] = quantise(b); rgba8[o * 4 + 3] = 255;
     }
+}
+
+// Debug probe: one lane walks one sample's path and dumps every hit record (t, p, normal, material, u, v,
+// front_face) plus the ray it was found with — the device half of the per-bounce CPU-vs-GPU vector tests.
+constexpr int PROBE_STRIDE = 20;
+template <typename R>
+__global__ void probe_path_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R t_min, uint32_t px, uint32_t row,
+                                  uint32_t sample, double* __restrict__ out, uint32_t max_out, int32_t* __restrict__ n_out) {
+    extern __shared__ int32_t lds_stack[];
+    if (threadIdx.x != 0) return;
+    LdsStack stack{lds_stack, blockDim.x};
+    NoCounters cnt;
+    PathState<R> ps;
+    path_begin(ps, cam, rc, px, row, sample);
+    uint32_t n = 0;
+    while (n < max_out) {
+        HitRecord<R> rec;
+        const Ray<R> ray = ps.ray;
+        if (!world_hit(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, rec, stack, cnt)) break;
+        double* o = out + size_t(n) * PROBE_STRIDE;
+        o[0] = rec.t; o[1] = rec.p.x; o[2] = rec.p.y; o[3] = rec.p.z;
+        o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z; o[7] = double(rec.mat);
+        o[8] = rec.u; o[9] = rec.v; o[10] = rec.front_face ? 1.0 : 0.0;
+        o[11] = ray.o.x; o[12] = ray.o.y; o[13] = ray.o.z; o[14] = ray.d.x; o[15] = ray.d.y; o[16] = ray.d.z; o[17] = ray.time;
+        ++n;
+        V3<R> att, em;
+        const bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, em, cnt);
+        o[18] = em.x; o[19] = cont ? att.x : -1.0;
+        if (!cont) break;
+        ps.bounce += 1;
+        if (ps.bounce >= rc.max_depth) break;
+    }
+    *n_out = int32_t(n);
+    // the same sample again through path_step(), exactly as the trace kernel runs it: radiance after `out`
+    path_begin(ps, cam, rc, px, row, sample);
+    while (path_step(ps, sc, rc, V3<R>(), t_min, stack, cnt)) {}
+    double* tail = out + size_t(max_out) * PROBE_STRIDE;
+    tail[0] = ps.radiance.x; tail[1] = ps.radiance.y; tail[2] = ps.radiance.z; tail[3] = double(ps.bounce);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,6 +443,15 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    if (const char* e = getenv("RTTNW_DEBUG_STACK_EXTRA")) rc.stack_depth += uint32_t(atoi(e));
+    double* d_dbg = nullptr;
+    if (const char* e = getenv("RTTNW_DEBUG_TAP")) { // "px,row,sample" — instrumented variant only
+        if (p->collect_counters && sscanf(e, "%u,%u,%u", &rc.dbg_px, &rc.dbg_row, &rc.dbg_sample) == 3) {
+            rc.dbg_on = 1;
+            HIP_TRY(hipMalloc((void**)&d_dbg, 1024 * sizeof(double)));
+            HIP_TRY(hipMemset(d_dbg, 0, 1024 * sizeof(double)));
+        }
+    }
 
     const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
     if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(n_jobs, 1) * 3 * sizeof(R))) return g;
@@ -423,7 +480,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
     if (n_jobs > 0) {
         hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
-                           R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc);
+                           R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, d_dbg);
         HIP_TRY(hipGetLastError());
     }
     if (stats) HIP_TRY(hipEventRecord(d->ev1, stream));
@@ -431,6 +488,17 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
                        (R*)d_packed, rc, L.pixels_per_rank);
     HIP_TRY(hipGetLastError());
 
+    if (d_dbg) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        std::vector<double> h(1024);
+        HIP_TRY(hipMemcpy(h.data(), d_dbg, 1024 * sizeof(double), hipMemcpyDeviceToHost));
+        for (int b = 0; b < int(h[0]); ++b) {
+            const double* o = &h[1 + b * 16];
+            fprintf(stderr, "[tap] bounce %d lane %.0f o=(%.6f %.6f %.6f) d=(%.7f %.7f %.7f) time=%.6f T.x=%.6f L.x=%.6f\n", b, o[9], o[0], o[1],
+                    o[2], o[3], o[4], o[5], o[6], o[7], o[8]);
+        }
+        (void)hipFree(d_dbg);
+    }
     if (stats) {
         HIP_TRY(hipStreamSynchronize(stream));
         std::memset(stats, 0, sizeof(*stats));
@@ -458,10 +526,51 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     return RTTNW_OK;
 }
 
+template <typename R>
+int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row, uint32_t sample,
+                 double* out, uint32_t max_out) {
+    DeviceState* d = s->device;
+    HIP_TRY(hipSetDevice(d->device));
+    DeviceScene<R>& ds = scene_of<R>(d);
+    if (!ds.ready)
+        if (int rc = ds.upload(s->flat)) return rc;
+    RenderConsts rc{};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
+    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    CameraRec<double> cam64;
+    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
+                cam->focus_distance, cam->open_time, cam->close_time, cam64);
+    double* d_out = nullptr;
+    int32_t* d_n = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_out, (size_t(max_out) * PROBE_STRIDE + 4) * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&d_n, sizeof(int32_t)));
+    HIP_TRY(hipMemset(d_n, 0, sizeof(int32_t)));
+    const size_t lds = size_t(rc.stack_depth) * 64 * sizeof(int32_t);
+    hipLaunchKernelGGL(probe_path_kernel<R>, dim3(1), dim3(64), lds, 0, ds.view, narrow_camera<R>(cam64), rc, R(p->t_min), px, row,
+                       sample, d_out, max_out, d_n);
+    HIP_TRY(hipGetLastError());
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, d_n, sizeof(n), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out, size_t(n) * PROBE_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
+    // radiance of the sample (path_step loop) is returned after the last possible bounce record
+    HIP_TRY(hipMemcpy(out + size_t(max_out) * PROBE_STRIDE, d_out + size_t(max_out) * PROBE_STRIDE, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d_out); (void)hipFree(d_n);
+    return n;
+}
+
 } // namespace rt
 
 // =============================================================================================
 extern "C" {
+
+int rttnw_debug_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
+                           uint32_t sample, double* out, uint32_t max_out) {
+    if (int rc = rt::validate(s, cam, p)) return rc;
+    if (!out || px >= p->width || row >= p->height) { rt::set_last_error("debug_probe_path: bad arguments"); return RTTNW_ERR_INVALID; }
+    return p->precision == RTTNW_F32 ? rt::probe_path_t<float>(s, cam, p, px, row, sample, out, max_out)
+                                     : rt::probe_path_t<double>(s, cam, p, px, row, sample, out, max_out);
+}
+
 
 int rttnw_device_count(void) {
     int n = 0;

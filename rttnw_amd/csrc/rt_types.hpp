@@ -131,6 +131,7 @@ struct RenderConsts {
     uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
     uint32_t quirks;
     uint32_t stack_depth;
+    uint32_t dbg_px, dbg_row, dbg_sample, dbg_on; // instrumented kernel variant only: tap one sample's path
     uint64_t seed;
 };
 

@@ -6,7 +6,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, "csrc", "librttnw_hip.so")
+HIP_LIB = os.environ.get("RTTNW_HIP_LIB") or os.path.join(_HERE, "csrc", "librttnw_hip.so")  # env: debug builds
 SCENES_LIB = os.path.join(_HERE, "host", "librttnw_scenes.so")
 
 _product = None
@@ -20,6 +20,12 @@ def product():
         if not os.path.exists(HIP_LIB):
             raise RuntimeError("rttnw_amd: %s is missing — the HIP extension is not built and there is no "
                                "CPU fallback (run __graft_entry__.build())" % HIP_LIB)
+        # PyTorch ships its own copy of the HIP runtime.  Load it first so that this library binds to the same
+        # runtime instance (a second instance in one process sees no devices); torch is plumbing only.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(HIP_LIB)
         b = abi.Binding(lib, "rttnw_", abi.BUILDER_FUNCS)
         b.add(abi.PRODUCT_FUNCS)

@@ -10,6 +10,11 @@ run() { # name, counters...
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
 }
 BENCH_ARGS="$*"
+if [ -n "$PMC_QUICK" ]; then
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU
+run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+else
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_VALU
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run sq3 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM SQ_INSTS_BRANCH
@@ -19,6 +24,7 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 run tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
+fi
 # summarise: counter values of the trace kernel dispatches
 python3 - "$ROOT/$OUT" <<'PY'
 import csv, glob, os, sys, collections
@@ -41,4 +47,11 @@ with open(os.path.join(out, "summary.txt"), "w") as fo:
     for k, v in summ.items():
         line = "%-40s %s" % (k, v[0] if isinstance(v[0], str) else "%.6g (n=%d)" % (sum(v) / len(v), len(v)))
         print(line); fo.write(line + "\n")
+    g = lambda k: sum(summ[k]) / len(summ[k]) if k in summ else None
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU") and g("GRBM_GUI_ACTIVE"):
+        d = ["lane_utilisation = SQ_THREAD_CYCLES_VALU/(SQ_ACTIVE_INST_VALU*64) = %.3f" % (g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64)),
+             "valu_busy = SQ_ACTIVE_INST_VALU*4/(1024*GRBM_GUI_ACTIVE/8) = %.3f" % (g("SQ_ACTIVE_INST_VALU") * 4 / (1024 * g("GRBM_GUI_ACTIVE") / 8)),
+             "wave_time: wait_any %.3f  wait_inst %.3f  active %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"))]
+        for line in d:
+            print(line); fo.write(line + "\n")
 PY

@@ -15,6 +15,7 @@
 // No CPU fallback: every entry point needs a HIP device.
 #include "../../include/rttnw_hip.h"
 #include "rt_core.hpp"
+#include "rt_sched.hpp"
 #include "scene_handle.hpp"
 
 #include <hip/hip_runtime.h>
@@ -49,94 +50,107 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 constexpr int TRACE_BLOCK = 256;
 
+// The per-pixel sample loop of main.rs:202-229 as ONE persistent kernel with an intra-wave scheduler.
+//
+// Every lane owns one path and is, at any moment, waiting for exactly one kind of step (rt_sched.hpp ST_*).
+// Each iteration the wave ballots the states and runs ONE stage for the lanes waiting on it, so the
+// instruction stream of an iteration is one stage's code at (#waiting lanes / 64) utilisation, instead of node
+// code + every primitive kind + shading serialised behind the slowest lane of the wave.  Lanes that are not
+// picked keep their state; every executed stage advances all of its lanes, so the loop always makes progress.
+// The policy keeps lanes accumulated at inner nodes (80 % of all steps) and drains the other queues at
+// thresholds that adapt to the scene (rt_sched.hpp adapt_policy).
+// Jobs ((pixel, sample chunk); 64 consecutive jobs = one 8x8 tile) come from one global counter: the lanes
+// that ran dry are counted with __ballot, the wave leader takes that many jobs with ONE atomic and each lane
+// picks its own by popcount rank.
 template <typename R, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
-                                                            DeviceCounters* __restrict__ counters, double* __restrict__ dbg) {
+                                                            DeviceCounters* __restrict__ counters) {
     extern __shared__ int32_t lds_stack[];
     LdsStack stack{lds_stack + threadIdx.x, blockDim.x};
     typename CounterSel<COUNT>::type cnt;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
-    const unsigned long long n_jobs = jobs_per_chunk * rc.n_chunks;
+    const unsigned long long n_jobs = (unsigned long long)rc.my_tiles * 64ull * rc.n_chunks;
     const V3<R> background(bg_r, bg_g, bg_b);
 
-    bool has_job = false, alive = false, done = false;
-    unsigned long long job = 0;
-    uint32_t px = 0, row = 0, s = 0, s_end = 0;
-    V3<R> acc;
-    PathState<R> ps;
+    Lane<R> ln;
+    ln.init();
+    SchedPolicy pol = default_policy();
+    uint32_t served[ST_COUNT] = {0, 0, 0, 0, 0, 0}; // lane-steps per stage so far (wave-uniform)
+    uint32_t execs[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+    unsigned long long pop[ST_COUNT] = {0, 0, 0, 0, 0, 0};
+    uint32_t iter = 0;
+
+    // vote + bookkeeping of one scheduler iteration; returns the stage to run (ST_DONE: every lane is done)
+    auto vote = [&]() -> uint32_t {
+        uint32_t n[ST_COUNT];
+#pragma unroll
+        for (uint32_t k = 0; k < ST_COUNT; ++k) n[k] = uint32_t(__popcll(__ballot(ln.st == k)));
+        const uint32_t pick = sched_pick(n, pol);
+        if (pick == ST_DONE) return pick;
+#pragma unroll
+        for (uint32_t k = 0; k < ST_COUNT; ++k)
+            if (pick == k) { served[k] += n[k]; execs[k] += 1; }
+        if ((++iter & 127u) == 0) adapt_policy(pol, served);
+        if constexpr (COUNT) { // scheduler statistics: time-average population of every queue
+#pragma unroll
+            for (uint32_t k = 0; k < ST_COUNT; ++k) pop[k] += n[k];
+        }
+        return pick;
+    };
 
     for (;;) {
-        // ---- job hand-out: wave-aggregated, one atomic per refill event
-        const bool need = !done && !alive && s >= s_end;
-        const unsigned long long mask = __ballot(need);
-        if (mask != 0ull) {
-            if (need && has_job) { // retire the finished job: its sequential sum
-                R* dst = partial + job * 3ull;
-                dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
-                has_job = false;
-            }
-            const int leader = __ffsll((long long)mask) - 1;
-            unsigned long long base = 0;
-            if (int(lane) == leader) base = atomicAdd(job_counter, (unsigned long long)__popcll(mask));
-            const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
-            base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
-            if (need) {
-                job = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
-                if (job >= n_jobs) {
-                    done = true;
-                } else {
-                    const uint32_t chunk = uint32_t(job / jobs_per_chunk);
-                    const uint32_t rem = uint32_t(job % jobs_per_chunk);
-                    const uint32_t local_tile = rem >> 6, l = rem & 63u;
-                    uint32_t tx, ty;
-                    tile_unpermute(rc.tile_rank + local_tile * rc.tile_world, rc.tiles_x, tx, ty);
-                    px = tx * 8u + (l & 7u);
-                    row = ty * 8u + (l >> 3);
-                    s = chunk * rc.spp_chunk;
-                    s_end = min(rc.spp, s + rc.spp_chunk);
-                    if (px >= rc.width || row >= rc.height) s = s_end; // outside the image: an empty job
-                    acc = V3<R>();
-                    has_job = true;
-                }
-            }
+        uint32_t pick = vote();
+        // inner-node visits are most of the iterations: run them in a tight loop of their own, so that only the
+        // traversal registers are loop-carried there (no shuffling of the whole lane state per iteration)
+        while (pick == ST_NODE) {
+            if (ln.st == ST_NODE) ln.step_node(sc, t_min, stack, cnt);
+            pick = vote();
         }
-        if (__ballot(!done) == 0ull) break;
+        if (pick == ST_DONE) break;
 
-        // ---- one path per lane: regenerate or advance by one bounce
-        if (!done) {
-            if (!alive && s < s_end) {
-                path_begin(ps, cam, rc, px, row, s);
-                alive = true;
-            }
-            if (alive) {
-                if constexpr (COUNT) { // instrumented variant: tap one sample's per-bounce state
-                    if (rc.dbg_on && px == rc.dbg_px && row == rc.dbg_row && s == rc.dbg_sample && ps.bounce < 60) {
-                        double* o = dbg + 1 + ps.bounce * 16;
-                        o[0] = ps.ray.o.x; o[1] = ps.ray.o.y; o[2] = ps.ray.o.z; o[3] = ps.ray.d.x; o[4] = ps.ray.d.y; o[5] = ps.ray.d.z;
-                        o[6] = ps.ray.time; o[7] = ps.throughput.x; o[8] = ps.radiance.x; o[9] = double(lane);
-                        dbg[0] = double(ps.bounce + 1);
-                    }
+        if (pick == ST_SPHERE || pick == ST_BOX || pick == ST_MISC) {
+            if (ln.st == pick) ln.step_leaf(sc, t_min, stack, cnt);
+        } else if (pick == ST_POST) {
+            if (ln.st == ST_POST) ln.step_post(sc, rc, background, t_min, cnt);
+        } else { // ST_NEW
+            // job hand-out for the lanes that ran dry: wave-aggregated, one atomic per refill event
+            const bool need = ln.needs_job();
+            const unsigned long long mask = __ballot(need);
+            if (mask != 0ull) {
+                if (need && ln.has_job) { // retire the finished job: its sequential sum
+                    R* dst = partial + ln.job * 3ull;
+                    dst[0] = ln.acc.x; dst[1] = ln.acc.y; dst[2] = ln.acc.z;
+                    ln.has_job = false;
                 }
-                alive = path_step(ps, sc, rc, background, t_min, stack, cnt);
-                if (!alive) { // main.rs:216: acc + color(...)
-                    acc = acc + ps.radiance;
-                    ++s;
-                }
+                const int leader = __ffsll((long long)mask) - 1;
+                unsigned long long base = 0;
+                if (int(lane) == leader) base = atomicAdd(job_counter, (unsigned long long)__popcll(mask));
+                const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
+                base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+                if (need) ln.take_job(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)), n_jobs, rc);
             }
+            if (ln.st == ST_NEW && ln.s < ln.s_end) ln.step_new(sc, cam, rc, cnt);
         }
     }
 
     if constexpr (COUNT) {
-        uint32_t r = wave_sum(cnt.rays), n = wave_sum(cnt.nodes), p = wave_sum(cnt.prims), t = wave_sum(cnt.texels);
+        uint32_t r = wave_sum(cnt.rays), nn = wave_sum(cnt.nodes), p = wave_sum(cnt.prims), t = wave_sum(cnt.texels);
         if (lane == 0) {
             atomicAdd(&counters->rays, (unsigned long long)r);
-            atomicAdd(&counters->nodes, (unsigned long long)n);
+            atomicAdd(&counters->nodes, (unsigned long long)nn);
             atomicAdd(&counters->prims, (unsigned long long)p);
             atomicAdd(&counters->texels, (unsigned long long)t);
+#pragma unroll
+            for (uint32_t k = 0; k < ST_COUNT; ++k) {
+                atomicAdd(&counters->stage_execs[k], (unsigned long long)execs[k]);
+                atomicAdd(&counters->stage_lanes[k], (unsigned long long)served[k]);
+                atomicAdd(&counters->thr_sum[k], (unsigned long long)pol.threshold[k]);
+                atomicAdd(&counters->pop_sum[k], pop[k]);
+            }
+            atomicAdd(&counters->waves, 1ull);
         }
     }
 }
@@ -437,22 +451,13 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     fill_layout(p->width, p->height, p->tile_world, L);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 15u) / 16u; // default: <= 16 chunks per pixel
+    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 63u) / 64u; // default: <= 64 chunks per pixel (fine jobs: short tail)
     rc.n_chunks = (p->spp + rc.spp_chunk - 1) / rc.spp_chunk;
     rc.tiles_x = L.tiles_x; rc.tiles_y = L.tiles_y; rc.n_tiles = L.n_tiles;
     rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     if (const char* e = getenv("RTTNW_DEBUG_STACK_EXTRA")) rc.stack_depth += uint32_t(atoi(e));
-    double* d_dbg = nullptr;
-    if (const char* e = getenv("RTTNW_DEBUG_TAP")) { // "px,row,sample" — instrumented variant only
-        if (p->collect_counters && sscanf(e, "%u,%u,%u", &rc.dbg_px, &rc.dbg_row, &rc.dbg_sample) == 3) {
-            rc.dbg_on = 1;
-            HIP_TRY(hipMalloc((void**)&d_dbg, 1024 * sizeof(double)));
-            HIP_TRY(hipMemset(d_dbg, 0, 1024 * sizeof(double)));
-        }
-    }
-
     const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
     if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(n_jobs, 1) * 3 * sizeof(R))) return g;
 
@@ -480,7 +485,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
     if (n_jobs > 0) {
         hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
-                           R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, d_dbg);
+                           R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc);
         HIP_TRY(hipGetLastError());
     }
     if (stats) HIP_TRY(hipEventRecord(d->ev1, stream));
@@ -488,17 +493,6 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
                        (R*)d_packed, rc, L.pixels_per_rank);
     HIP_TRY(hipGetLastError());
 
-    if (d_dbg) {
-        HIP_TRY(hipStreamSynchronize(stream));
-        std::vector<double> h(1024);
-        HIP_TRY(hipMemcpy(h.data(), d_dbg, 1024 * sizeof(double), hipMemcpyDeviceToHost));
-        for (int b = 0; b < int(h[0]); ++b) {
-            const double* o = &h[1 + b * 16];
-            fprintf(stderr, "[tap] bounce %d lane %.0f o=(%.6f %.6f %.6f) d=(%.7f %.7f %.7f) time=%.6f T.x=%.6f L.x=%.6f\n", b, o[9], o[0], o[1],
-                    o[2], o[3], o[4], o[5], o[6], o[7], o[8]);
-        }
-        (void)hipFree(d_dbg);
-    }
     if (stats) {
         HIP_TRY(hipStreamSynchronize(stream));
         std::memset(stats, 0, sizeof(*stats));
@@ -518,6 +512,21 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             DeviceCounters hc;
             HIP_TRY(hipMemcpy(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
             stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
+            if (getenv("RTTNW_DEBUG_SCHED")) {
+                static const char* names[] = {"NODE", "SPHERE", "BOX", "MISC", "POST", "NEW"};
+                unsigned long long te = 0;
+                for (int k = 0; k < 6; ++k) te += hc.stage_execs[k];
+                for (int k = 0; k < 6; ++k)
+                    fprintf(stderr, "[sched] %-6s execs %12llu (%.1f%%)  lanes/exec %.2f  lane-steps/sample %.2f\n", names[k], hc.stage_execs[k],
+                            100.0 * hc.stage_execs[k] / double(te ? te : 1), hc.stage_execs[k] ? double(hc.stage_lanes[k]) / hc.stage_execs[k] : 0.0,
+                            double(hc.stage_lanes[k]) / double(stats->samples ? stats->samples : 1));
+                fprintf(stderr, "[sched] waves %llu mean final thresholds:", hc.waves);
+                for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f", names[k], double(hc.thr_sum[k]) / double(hc.waves ? hc.waves : 1));
+                fprintf(stderr, "\n[sched] time-average queue population:");
+                double tp = 0;
+                for (int k = 0; k < 6; ++k) { fprintf(stderr, " %s %.1f", names[k], double(hc.pop_sum[k]) / double(te ? te : 1)); tp += double(hc.pop_sum[k]) / double(te ? te : 1); }
+                fprintf(stderr, "  total live %.1f\n", tp);
+            }
         }
         stats->n_nodes = uint32_t(s->flat.nodes.size());
         stats->n_prims = s->flat.n_prims_in_bvh;

@@ -224,10 +224,13 @@ template <typename R> RT_HD V3<R> moving_center(const MovingSphereRec<R>& m, R t
 template <typename R>
 RT_HD bool rect_t(int plane, R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, R t_min, R t_max, R& t_out, R& a_out, R& b_out) {
     // (axis0, axis1, k-axis): XY -> (x,y,z); XZ -> (x,z,y); YZ -> (y,z,x) — hittable.rs:450-488
-    R ok = plane == 0 ? ray.o.z : (plane == 1 ? ray.o.y : ray.o.x);
-    R dk = plane == 0 ? ray.d.z : (plane == 1 ? ray.d.y : ray.d.x);
-    R oa = plane == 2 ? ray.o.y : ray.o.x, da = plane == 2 ? ray.d.y : ray.d.x;
-    R ob = plane == 0 ? ray.o.y : ray.o.z, db = plane == 0 ? ray.d.y : ray.d.z;
+    // The components are copied into scalars first: `c ? ray.o.z : ray.o.y` on member lvalues is an lvalue, i.e. a
+    // pointer select into the ray, which keeps the whole lane state from being promoted to registers.
+    const R ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    const R ok = plane == 0 ? oz : (plane == 1 ? oy : ox);
+    const R dk = plane == 0 ? dz : (plane == 1 ? dy : dx);
+    const R oa = plane == 2 ? oy : ox, da = plane == 2 ? dy : dx;
+    const R ob = plane == 0 ? oy : oz, db = plane == 0 ? dy : dz;
     R t = (k - ok) / dk;
     if (t < t_min || t > t_max) return false;
     R a = oa + t * da;
@@ -279,8 +282,9 @@ template <typename R> RT_HD Ray<R> to_object(const InstanceRec<R>& in, Ray<R> ra
 
 // Rectangle hit coordinates at parameter t, no range checks (used to rebuild the winner's record).
 template <typename R> RT_HD void rect_ab(int plane, const Ray<R>& ray, R t, R& a, R& b) {
-    R oa = plane == 2 ? ray.o.y : ray.o.x, da = plane == 2 ? ray.d.y : ray.d.x;
-    R ob = plane == 0 ? ray.o.y : ray.o.z, db = plane == 0 ? ray.d.y : ray.d.z;
+    const R ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    const R oa = plane == 2 ? oy : ox, da = plane == 2 ? dy : dx;
+    const R ob = plane == 0 ? oy : oz, db = plane == 0 ? dy : dz;
     a = oa + t * da;
     b = ob + t * db;
 }
@@ -324,69 +328,122 @@ struct HitRef {
 // List::hit / BvhTree::hit: closest t in [t_min, t_max], a candidate with t == closest replaces
 // the incumbent (hittable.rs:157-159,366-367).  Only (t, primitive, instance) are tracked here;
 // the hit record is rebuilt once for the winner (Q11: same result, far fewer acos/atan2).
+//
+// The walk is written as RESUMABLE STEPS over an explicit per-lane state, so that the trace kernel's
+// intra-wave scheduler can run "one inner-node step" or "one primitive test" for whichever lanes
+// are waiting on it (render.hip), while closest_solid() below simply drives the same steps to
+// completion (probe kernel, host build).  The per-lane sequence of steps — hence every result and
+// counter — is the same whoever drives it.
+constexpr int32_t TRAV_DONE = INT32_MIN + 2; // Trav::node once the stack has run empty
+
+template <typename R> struct Trav {
+    Ray<R> ray;       // the ray in the current space (world, or an instance's object space)
+    V3<R> inv;        // 1 / ray.d
+    R closest;
+    HitRef best;
+    int32_t node;     // >= 0: inner node to visit; < 0: leaf bits (or CHILD_EMPTY); TRAV_DONE: finished
+    int32_t sp;       // stack entries in use
+    int32_t cur_inst; // instance being walked, or -1
+    uint32_t leaf_k;  // next record of the current leaf
+    bool found;
+};
+
+template <typename R> RT_HD V3<R> inv_dir(V3<R> d) { return V3<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z); }
+
+template <typename R> RT_HD void trav_begin(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray) {
+    tr.ray = wray;
+    tr.inv = inv_dir(wray.d);
+    tr.closest = Lim<R>::max(); // world.hit(ray, t_min, f64::MAX) — main.rs:33
+    tr.best.prim = make_ref(PRIM_NONE, 0);
+    tr.best.inst = -1;
+    tr.best.aux = 0;
+    tr.node = sc.top_root;
+    tr.sp = 0;
+    tr.cur_inst = -1;
+    tr.leaf_k = 0;
+    tr.found = false;
+}
+
+// Take the next pending subtree off the stack (leaving an instance when its sentinel comes up).
+template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray<R>& wray, Stack& stack) {
+    tr.leaf_k = 0;
+    if (tr.sp == 0) { tr.node = TRAV_DONE; return; }
+    int32_t node = stack.get(--tr.sp);
+    if (node == STACK_SENTINEL) {
+        tr.ray = wray;
+        tr.inv = inv_dir(wray.d);
+        tr.cur_inst = -1;
+        if (tr.sp == 0) { tr.node = TRAV_DONE; return; }
+        node = stack.get(--tr.sp);
+    }
+    tr.node = node;
+}
+
+// One inner node (tr.node >= 0): test both child boxes, descend into the nearer hit child, push the other.
 template <typename R, typename Stack, typename Cnt>
-RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R& closest, HitRef& best, Stack& stack, Cnt& cnt) {
-    Ray<R> ray = wray;
-    V3<R> inv(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
-    int sp = 0;
-    int32_t node = sc.top_root;
-    int32_t cur_inst = -1;
-    bool found = false;
-    for (;;) {
-        if (node >= 0) {
-            const BvhNode nd = sc.nodes[node];
-            cnt.node();
-            R e0, e1;
-            bool h0 = slab_hit(nd.lo0, nd.hi0, ray.o, inv, t_min, closest, e0);
-            bool h1 = slab_hit(nd.lo1, nd.hi1, ray.o, inv, t_min, closest, e1);
-            if (h0 && h1) {
-                bool swap = e1 < e0; // nearer child first
-                stack.set(sp++, swap ? nd.child0 : nd.child1);
-                node = swap ? nd.child1 : nd.child0;
-                continue;
-            }
-            if (h0) { node = nd.child0; continue; }
-            if (h1) { node = nd.child1; continue; }
-        } else if (node != CHILD_EMPTY) {
-            uint32_t kind = leaf_kind(node), count = leaf_count(node), first = leaf_first(node);
-            if (kind == PRIM_INSTANCE) {
-                cnt.prim();
-                const InstanceRec<R>& in = sc.insts[first];
-                stack.set(sp++, STACK_SENTINEL);
-                ray = to_object(in, wray);
-                inv = V3<R>(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
-                cur_inst = int32_t(first);
-                node = in.root;
-                continue;
-            }
-            for (uint32_t k = 0; k < count; ++k) {
-                R t;
-                int aux = 0;
-                cnt.prim();
-                if (prim_t(sc, kind, first + k, ray, t_min, closest, t, aux)) {
-                    // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
-                    if (found && t == closest &&
-                        prim_seq(sc, kind, first + k) < prim_seq(sc, ref_kind(best.prim), ref_index(best.prim)))
-                        continue;
-                    closest = t;
-                    best.prim = make_ref(kind, first + k);
-                    best.inst = cur_inst;
-                    best.aux = aux;
-                    found = true;
-                }
-            }
-        }
-        if (sp == 0) break;
-        node = stack.get(--sp);
-        if (node == STACK_SENTINEL) {
-            ray = wray;
-            inv = V3<R>(R(1) / ray.d.x, R(1) / ray.d.y, R(1) / ray.d.z);
-            cur_inst = -1;
-            if (sp == 0) break;
-            node = stack.get(--sp);
+RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
+    const BvhNode nd = sc.nodes[tr.node];
+    cnt.node();
+    R e0, e1;
+    const bool h0 = slab_hit(nd.lo0, nd.hi0, tr.ray.o, tr.inv, t_min, tr.closest, e0);
+    const bool h1 = slab_hit(nd.lo1, nd.hi1, tr.ray.o, tr.inv, t_min, tr.closest, e1);
+    if (h0 && h1) {
+        const bool swap = e1 < e0; // nearer child first
+        stack.set(tr.sp++, swap ? nd.child0 : nd.child1);
+        tr.node = swap ? nd.child1 : nd.child0;
+    } else if (h0) {
+        tr.node = nd.child0;
+    } else if (h1) {
+        tr.node = nd.child1;
+    } else {
+        trav_pop(tr, wray, stack);
+    }
+}
+
+// One step at a leaf (tr.node < 0, not TRAV_DONE): enter an instance, or test ONE primitive record.
+template <typename R, typename Stack, typename Cnt>
+RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
+    if (tr.node == CHILD_EMPTY) { trav_pop(tr, wray, stack); return; }
+    const uint32_t kind = leaf_kind(tr.node), count = leaf_count(tr.node), first = leaf_first(tr.node);
+    cnt.prim();
+    if (kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
+        const InstanceRec<R>& in = sc.insts[first];
+        stack.set(tr.sp++, STACK_SENTINEL);
+        tr.ray = to_object(in, wray);
+        tr.inv = inv_dir(tr.ray.d);
+        tr.cur_inst = int32_t(first);
+        tr.node = in.root;
+        return;
+    }
+    const uint32_t idx = first + tr.leaf_k;
+    R t;
+    int aux = 0;
+    if (prim_t(sc, kind, idx, tr.ray, t_min, tr.closest, t, aux)) {
+        // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
+        const bool loses_tie = tr.found && t == tr.closest &&
+                               prim_seq(sc, kind, idx) < prim_seq(sc, ref_kind(tr.best.prim), ref_index(tr.best.prim));
+        if (!loses_tie) {
+            tr.closest = t;
+            tr.best.prim = make_ref(kind, idx);
+            tr.best.inst = tr.cur_inst;
+            tr.best.aux = aux;
+            tr.found = true;
         }
     }
-    return found;
+    if (++tr.leaf_k >= count) trav_pop(tr, wray, stack);
+}
+
+template <typename R, typename Stack, typename Cnt>
+RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R& closest, HitRef& best, Stack& stack, Cnt& cnt) {
+    Trav<R> tr;
+    trav_begin(tr, sc, wray);
+    while (tr.node != TRAV_DONE) {
+        if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
+        else trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
+    }
+    closest = tr.closest;
+    best = tr.best;
+    return tr.found;
 }
 
 // ---------------------------------------------------------------- hit record of the winner
@@ -421,8 +478,12 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         V3<R> c(s.cx, s.cy, s.cz);
         rec.p = ray.at(t);
         outward = (rec.p - c) / s.r;
-        sphere_uv(outward, rec.u, rec.v);
         rec.mat = sc.sphere_mat[idx];
+        // Sphere::uv (acos + atan2) is evaluated by the reference for every hit (Q11) but only an image texture
+        // (possibly under a checker) ever reads it: compute it only then — same result, ~100 instructions saved.
+        const int32_t tex = sc.mats[rec.mat].tex;
+        rec.u = R(0); rec.v = R(0);
+        if (tex >= 0 && (sc.texs[tex].type == TEX_IMAGE || sc.texs[tex].type == TEX_CHECKER)) sphere_uv(outward, rec.u, rec.v);
     } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
         const MovingSphereRec<R>& m = sc.moving[idx];
         rec.p = ray.at(t);
@@ -500,31 +561,52 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
 // ---------------------------------------------------------------- world.hit (main.rs:33)
 // Solids through the BVH, then the constant media in creation order with the shrinking `closest`
 // they would see in the reference's world List (hittable.rs:740-796, Q13).
-template <typename R, typename Stack, typename Cnt>
-RT_HD bool world_hit(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_t key, uint32_t bounce, uint32_t quirks,
-                     HitRecord<R>& rec, Stack& stack, Cnt& cnt) {
-    cnt.ray();
-    R closest = Lim<R>::max();
-    HitRef best;
-    best.prim = make_ref(PRIM_NONE, 0);
-    best.inst = -1;
-    best.aux = 0;
-    bool found = closest_solid(sc, ray, t_min, closest, best, stack, cnt);
+// world_hit_finish(): everything after the BVH walk — media, then the winner's hit record.
+// hittable.rs:751: `record1.t + 0.0001`.  The absolute epsilon must stay above the spacing of R at t1, or the
+// second query finds the SAME root again (f32: ulp(5000) = 4.9e-4 swallows it and the medium is skipped); in
+// f64 the guard never binds below |t| ~ 1e11, so the reference value is used unchanged.
+template <typename R> RT_HD R medium_sep(R t1) {
+    return rt_max(R(0.0001), rt_fabs(t1) * (sizeof(R) == 4 ? R(4.8e-7) : R(8.9e-16)));
+}
+
+template <typename R, typename Cnt>
+RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_t key, uint32_t bounce, uint32_t quirks,
+                            bool found, R closest, HitRef best, HitRecord<R>& rec, Cnt& cnt) {
     int32_t medium = -1;
     for (int32_t m = 0; m < sc.n_media; ++m) {
         const MediumRec<R>& md = sc.media[m];
         Ray<R> bray = md.inst >= 0 ? to_object(sc.insts[md.inst], ray) : ray;
         const uint32_t bk = ref_kind(md.boundary), bi = ref_index(md.boundary);
         R t1, t2;
-        int aux;
         cnt.prim();
-        if (!prim_t(sc, bk, bi, bray, -Lim<R>::inf(), Lim<R>::inf(), t1, aux)) continue;
         cnt.prim();
-        // hittable.rs:751: `record1.t + 0.0001`.  The absolute epsilon must stay above the spacing of R at t1,
-        // or the second query finds the SAME root again (f32: ulp(5000) = 4.9e-4 swallows it and the medium is
-        // skipped); in f64 the guard never binds below |t| ~ 1e11, so the reference value is used unchanged.
-        const R sep = rt_max(R(0.0001), rt_fabs(t1) * (sizeof(R) == 4 ? R(4.8e-7) : R(8.9e-16)));
-        if (!prim_t(sc, bk, bi, bray, t1 + sep, Lim<R>::inf(), t2, aux)) continue;
+        if (bk == PRIM_SPHERE) {
+            // boundary.hit(ray, -inf, +inf) then boundary.hit(ray, t1 + 0.0001, +inf) (hittable.rs:745-751) are two
+            // evaluations of ONE quadratic: same discriminant, near root first, far root if the near one is out of
+            // range.  Evaluated once here, with Sphere::hit's range tests kept literally (NaN behaviour included).
+            const SphereRec<R> sp = sc.spheres[bi];
+            const V3<R> oc = bray.o - V3<R>(sp.cx, sp.cy, sp.cz);
+            const R a = dot(bray.d, bray.d), half_b = dot(oc, bray.d);
+            const R disc = sphere_discriminant(oc, bray.d, a, half_b, sp.r);
+            if (disc < R(0)) continue;
+            const R sqrtd = rt_sqrt(disc);
+            const R near_root = (-half_b - sqrtd) / a, far_root = (-half_b + sqrtd) / a;
+            t1 = near_root;
+            if (t1 < -Lim<R>::inf() || Lim<R>::inf() < t1) {
+                t1 = far_root;
+                if (t1 < -Lim<R>::inf() || Lim<R>::inf() < t1) continue;
+            }
+            const R lo2 = t1 + medium_sep(t1);
+            t2 = near_root;
+            if (t2 < lo2 || Lim<R>::inf() < t2) {
+                t2 = far_root;
+                if (t2 < lo2 || Lim<R>::inf() < t2) continue;
+            }
+        } else {
+            int aux;
+            if (!prim_t(sc, bk, bi, bray, -Lim<R>::inf(), Lim<R>::inf(), t1, aux)) continue;
+            if (!prim_t(sc, bk, bi, bray, t1 + medium_sep(t1), Lim<R>::inf(), t2, aux)) continue;
+        }
         t1 = rt_max(t1, t_min);
         t2 = rt_min(t2, closest);
         if (t1 >= t2) continue; // before any draw
@@ -549,6 +631,16 @@ RT_HD bool world_hit(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_
         make_record(sc, ray, best, closest, quirks, rec);
     }
     return true;
+}
+
+template <typename R, typename Stack, typename Cnt>
+RT_HD bool world_hit(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_t key, uint32_t bounce, uint32_t quirks,
+                     HitRecord<R>& rec, Stack& stack, Cnt& cnt) {
+    cnt.ray();
+    R closest;
+    HitRef best;
+    const bool found = closest_solid(sc, ray, t_min, closest, best, stack, cnt);
+    return world_hit_finish(sc, ray, t_min, key, bounce, quirks, found, closest, best, rec, cnt);
 }
 
 // ---------------------------------------------------------------- textures (texture.rs, noise.rs)
@@ -704,12 +796,13 @@ RT_HD void path_begin(PathState<R>& ps, const CameraRec<R>& cam, const RenderCon
 
 // One world.hit + shade: the body of color() (main.rs:26-45) unrolled into a loop:
 //   L = sum_k (prod_{i<k} att_i) * emitted_k  (+ throughput * background on a miss).
+// path_shade(): the part after the BVH walk (media, hit record, emitted/scatter, bookkeeping).
 // Returns true while the path is alive.
-template <typename R, typename Stack, typename Cnt>
-RT_HD bool path_step(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min,
-                     Stack& stack, Cnt& cnt) {
+template <typename R, typename Cnt>
+RT_HD bool path_shade(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min, bool found,
+                      R closest, HitRef best, Cnt& cnt) {
     HitRecord<R> rec;
-    if (!world_hit(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, rec, stack, cnt)) {
+    if (!world_hit_finish(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, found, closest, best, rec, cnt)) {
         ps.radiance = ps.radiance + ps.throughput * background;
         return false;
     }
@@ -721,6 +814,16 @@ RT_HD bool path_step(PathState<R>& ps, const SceneView<R>& sc, const RenderConst
     ps.bounce += 1;
     // color(depth == 0) returns black without tracing (main.rs:28-30): at most max_depth hits
     return ps.bounce < rc.max_depth;
+}
+
+template <typename R, typename Stack, typename Cnt>
+RT_HD bool path_step(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min,
+                     Stack& stack, Cnt& cnt) {
+    cnt.ray();
+    R closest;
+    HitRef best;
+    const bool found = closest_solid(sc, ps.ray, t_min, closest, best, stack, cnt);
+    return path_shade(ps, sc, rc, background, t_min, found, closest, best, cnt);
 }
 
 // Gamma + quantise — main.rs:219-225 (`as u8` saturates, NaN -> 0)

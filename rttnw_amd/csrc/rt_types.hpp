@@ -131,10 +131,13 @@ struct RenderConsts {
     uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
     uint32_t quirks;
     uint32_t stack_depth;
-    uint32_t dbg_px, dbg_row, dbg_sample, dbg_on; // instrumented kernel variant only: tap one sample's path
     uint64_t seed;
 };
 
-struct DeviceCounters { unsigned long long rays, nodes, prims, texels; };
+struct DeviceCounters {
+    unsigned long long rays, nodes, prims, texels;
+    unsigned long long stage_execs[8], stage_lanes[8]; // scheduler statistics (counting variant only)
+    unsigned long long thr_sum[8], pop_sum[8], waves;               // final thresholds summed over waves
+};
 
 } // namespace rt

@@ -162,7 +162,7 @@ def main():
                        "scene_build_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                         "kernel": "rt::trace_kernel<%s,false>" % ("float" if precision == abi.F32 else "double"),
+                         "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if st.reserved == 0 else "", "float" if precision == abi.F32 else "double"),
                          "kernel_ms": round(kernel_ms, 3),
                          "alg_bytes_per_sample": round(b_alg, 2),
                          "per_sample": {k: round(v, 3) for k, v in per_sample.items()},

@@ -162,7 +162,7 @@ typedef struct rttnw_stats {
     uint32_t n_nodes;        /* flat scene size */
     uint32_t n_prims;
     uint32_t scene_bytes;    /* bytes of node+primitive arrays resident on the device */
-    uint32_t reserved;
+    uint32_t reserved;       /* render: kernel form that ran (0 = lane-owns-path, 1 = decoupled); scene_info: stack depth */
 } rttnw_stats;
 
 /* Framebuffer partition: 8x8-pixel tiles, tile t owned by rank

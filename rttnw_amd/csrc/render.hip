@@ -49,90 +49,241 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 constexpr int TRACE_BLOCK = 256;
+constexpr uint32_t SLOTS_PER_WAVE = 128; // paths owned by one wave64: 64 being traversed + up to 64 queued
+constexpr uint32_t QCAP = 128;           // capacity of a wave's ray queue and hit queue (entries)
 
-// The per-pixel sample loop of main.rs:202-229 as ONE persistent kernel with an intra-wave scheduler.
+// Path state of a slot, in global memory (L2-resident), struct-of-arrays over all slots of the launch.
+enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_LX, PR_LY, PR_LZ, PR_AX, PR_AY, PR_AZ, PR_COUNT };
+enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
+// bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
+template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
+    return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + stack_depth * 64u * 4u;
+}
+constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
+
+// The per-pixel sample loop of main.rs:202-229 as ONE persistent kernel in which PATHS ARE DECOUPLED FROM LANES.
 //
-// Every lane owns one path and is, at any moment, waiting for exactly one kind of step (rt_sched.hpp ST_*).
-// Each iteration the wave ballots the states and runs ONE stage for the lanes waiting on it, so the
-// instruction stream of an iteration is one stage's code at (#waiting lanes / 64) utilisation, instead of node
-// code + every primitive kind + shading serialised behind the slowest lane of the wave.  Lanes that are not
-// picked keep their state; every executed stage advances all of its lanes, so the loop always makes progress.
-// The policy keeps lanes accumulated at inner nodes (80 % of all steps) and drains the other queues at
-// thresholds that adapt to the scene (rt_sched.hpp adapt_policy).
-// Jobs ((pixel, sample chunk); 64 consecutive jobs = one 8x8 tile) come from one global counter: the lanes
-// that ran dry are counted with __ballot, the wave leader takes that many jobs with ONE atomic and each lane
-// picks its own by popcount rank.
+// A wave64 owns 128 path slots whose state (ray, throughput, radiance, RNG key, pixel/sample bookkeeping) lives in
+// global memory; a lane only ever holds a RAY BEING TRAVERSED (origin, direction, closest hit, BVH cursor), so the
+// traversal loop is tight and nothing else is loop-carried.  Two wave-private LDS queues connect the two halves:
+//   * TRAVERSE iteration: lanes without a ray pop one from the ray queue (ranks by __ballot/popcount — the queues are
+//     private to the wave, no atomics), every lane advances its ray by one node / primitive step, lanes whose ray
+//     is finished push (slot, t, primitive) onto the hit queue and are free for the next ray immediately: no lane
+//     waits for the longest traversal in the wave.
+//   * SHADE: as soon as 64 hits are queued the whole wave processes them at full occupancy — media, hit record,
+//     emitted + scatter (rt_core.hpp path_shade) — and pushes the 64 continuation rays.  A path that ended adds its
+//     radiance to its job's sequential sum (main.rs:211-216) and starts the job's next sample; a slot whose job is
+//     finished writes the job's partial sum and takes the next job ((pixel, sample chunk); 64 consecutive jobs =
+//     one 8x8 tile) from the global counter with one wave-aggregated atomic.
+// Results do not depend on any of this scheduling: every draw is keyed by (pixel, sample, bounce), every job is a
+// sequential fold, and the resolve kernel adds a pixel's jobs in chunk order.
 template <typename R, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
-                                                            DeviceCounters* __restrict__ counters) {
-    extern __shared__ int32_t lds_stack[];
-    LdsStack stack{lds_stack + threadIdx.x, blockDim.x};
+                                                            DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,
+                                                            uint32_t* __restrict__ pool_u, uint32_t n_slots) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
     typename CounterSel<COUNT>::type cnt;
+    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    unsigned char* wbase = lds_raw + wave_in_block * wave_lds_bytes<R>(rc.stack_depth);
+    R* const rq_f = reinterpret_cast<R*>(wbase);            // ray queue [7][QCAP]: o.xyz, d.xyz, time
+    R* const hq_t = rq_f + 7u * QCAP;                       // hit queue: t
+    uint32_t* const rq_slot = reinterpret_cast<uint32_t*>(hq_t + QCAP);
+    int32_t* const hq_prim = reinterpret_cast<int32_t*>(rq_slot + QCAP);
+    int32_t* const hq_inst = hq_prim + QCAP;
+    uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
+    LdsStack stack{reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane, 64u};
 
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave_global = blockIdx.x * (TRACE_BLOCK / 64) + wave_in_block;
+    const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;
     const unsigned long long n_jobs = (unsigned long long)rc.my_tiles * 64ull * rc.n_chunks;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const V3<R> background(bg_r, bg_g, bg_b);
 
-    Lane<R> ln;
-    ln.init();
-    SchedPolicy pol = default_policy();
-    uint32_t served[ST_COUNT] = {0, 0, 0, 0, 0, 0}; // lane-steps per stage so far (wave-uniform)
-    uint32_t execs[ST_COUNT] = {0, 0, 0, 0, 0, 0};
-    unsigned long long pop[ST_COUNT] = {0, 0, 0, 0, 0, 0};
-    uint32_t iter = 0;
+    // every slot starts out needing its first job
+    hq_meta[lane] = lane | HIT_FRESH;
+    hq_meta[lane + 64u] = (lane + 64u) | HIT_FRESH;
+    uint32_t ray_n = 0, hit_n = SLOTS_PER_WAVE; // wave-uniform queue fill levels
 
-    // vote + bookkeeping of one scheduler iteration; returns the stage to run (ST_DONE: every lane is done)
-    auto vote = [&]() -> uint32_t {
-        uint32_t n[ST_COUNT];
-#pragma unroll
-        for (uint32_t k = 0; k < ST_COUNT; ++k) n[k] = uint32_t(__popcll(__ballot(ln.st == k)));
-        const uint32_t pick = sched_pick(n, pol);
-        if (pick == ST_DONE) return pick;
-#pragma unroll
-        for (uint32_t k = 0; k < ST_COUNT; ++k)
-            if (pick == k) { served[k] += n[k]; execs[k] += 1; }
-        if ((++iter & 127u) == 0) adapt_policy(pol, served);
-        if constexpr (COUNT) { // scheduler statistics: time-average population of every queue
-#pragma unroll
-            for (uint32_t k = 0; k < ST_COUNT; ++k) pop[k] += n[k];
-        }
-        return pick;
-    };
+    SchedPolicy pol = default_policy();
+    uint32_t served[ST_COUNT] = {0, 0, 0, 0}; // lane-steps per traversal stage so far (wave-uniform)
+    uint32_t iter = 0;
+    uint32_t dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    bool has_ray = false;
+    uint32_t slot = 0;
+    Ray<R> wray; // the ray this lane is traversing, in world space
+    Trav<R> tr;
 
     for (;;) {
-        uint32_t pick = vote();
-        // inner-node visits are most of the iterations: run them in a tight loop of their own, so that only the
-        // traversal registers are loop-carried there (no shuffling of the whole lane state per iteration)
-        while (pick == ST_NODE) {
-            if (ln.st == ST_NODE) ln.step_node(sc, t_min, stack, cnt);
-            pick = vote();
-        }
-        if (pick == ST_DONE) break;
+        __builtin_amdgcn_wave_barrier();
+        const bool any_ray = __ballot(has_ray) != 0ull;
+        if (hit_n >= 64u || (!any_ray && ray_n == 0u)) {
+            if (hit_n == 0u) break; // nothing traversing, nothing queued: this wave is done
+            // ================================================================== SHADE (up to 64 queued hits)
+            const uint32_t m = hit_n < 64u ? hit_n : 64u;
+            if constexpr (COUNT) { dbg[9] += 1; dbg[10] += m; }
+            const bool on = lane < m;
+            const uint32_t e = hit_n - 1u - (on ? lane : 0u);
+            hit_n -= m;
+            const uint32_t meta = on ? hq_meta[e] : HIT_FRESH;
+            const uint32_t hslot = meta & 0x7Fu;
+            const bool fresh = (meta & HIT_FRESH) != 0u;
+            const size_t g = gbase + hslot;
+            R* const pr = pool_r + g;
+            uint32_t* const pu = pool_u + g;
 
-        if (pick == ST_SPHERE || pick == ST_BOX || pick == ST_MISC) {
-            if (ln.st == pick) ln.step_leaf(sc, t_min, stack, cnt);
-        } else if (pick == ST_POST) {
-            if (ln.st == ST_POST) ln.step_post(sc, rc, background, t_min, cnt);
-        } else { // ST_NEW
-            // job hand-out for the lanes that ran dry: wave-aggregated, one atomic per refill event
-            const bool need = ln.needs_job();
-            const unsigned long long mask = __ballot(need);
-            if (mask != 0ull) {
-                if (need && ln.has_job) { // retire the finished job: its sequential sum
-                    R* dst = partial + ln.job * 3ull;
-                    dst[0] = ln.acc.x; dst[1] = ln.acc.y; dst[2] = ln.acc.z;
-                    ln.has_job = false;
+            PathState<R> ps;
+            bool emit = false, need_sample = false, slot_done = false;
+            uint32_t pxrow = 0, smp = 0, smp_end = 0;
+            unsigned long long job = ~0ull;
+            V3<R> acc;
+            if (on && !fresh) {
+                ps.ray.o = V3<R>(pr[size_t(PR_OX) * n_slots], pr[size_t(PR_OY) * n_slots], pr[size_t(PR_OZ) * n_slots]);
+                ps.ray.d = V3<R>(pr[size_t(PR_DX) * n_slots], pr[size_t(PR_DY) * n_slots], pr[size_t(PR_DZ) * n_slots]);
+                ps.ray.time = pr[size_t(PR_TIME) * n_slots];
+                ps.throughput = V3<R>(pr[size_t(PR_TX) * n_slots], pr[size_t(PR_TY) * n_slots], pr[size_t(PR_TZ) * n_slots]);
+                ps.radiance = V3<R>(pr[size_t(PR_LX) * n_slots], pr[size_t(PR_LY) * n_slots], pr[size_t(PR_LZ) * n_slots]);
+                ps.key = (unsigned long long)pu[size_t(PU_KEY_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_KEY_HI) * n_slots] << 32);
+                ps.bounce = pu[size_t(PU_BOUNCE) * n_slots];
+                HitRef best;
+                best.prim = hq_prim[e];
+                best.inst = hq_inst[e];
+                best.aux = int32_t((meta >> 8) & 7u);
+                const bool found = ref_kind(best.prim) != PRIM_NONE;
+                if (path_shade(ps, sc, rc, background, t_min, found, hq_t[e], best, cnt)) {
+                    emit = true; // next world.hit of the same path
+                } else {         // main.rs:216: acc + color(...)
+                    pxrow = pu[size_t(PU_PXROW) * n_slots];
+                    smp = pu[size_t(PU_S) * n_slots];
+                    smp_end = pu[size_t(PU_SEND) * n_slots];
+                    job = (unsigned long long)pu[size_t(PU_JOB_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_JOB_HI) * n_slots] << 32);
+                    acc = V3<R>(pr[size_t(PR_AX) * n_slots], pr[size_t(PR_AY) * n_slots], pr[size_t(PR_AZ) * n_slots]) + ps.radiance;
+                    ++smp;
+                    need_sample = true;
                 }
-                const int leader = __ffsll((long long)mask) - 1;
+            } else if (on) {
+                need_sample = true; // fresh slot: smp == smp_end == 0, no job yet
+            }
+            // job hand-out for the slots whose job is finished: wave-aggregated, one atomic per round.  An empty job
+            // (a tile pixel outside the image) is finished at once, hence the loop.
+            for (;;) {
+                const bool need_job = need_sample && !slot_done && smp >= smp_end;
+                const unsigned long long jm = __ballot(need_job);
+                if (jm == 0ull) break;
+                if (need_job && job != ~0ull) { // retire the finished job: its sequential sum
+                    R* dst = partial + job * 3ull;
+                    dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
+                }
+                const int leader = __ffsll((long long)jm) - 1;
                 unsigned long long base = 0;
-                if (int(lane) == leader) base = atomicAdd(job_counter, (unsigned long long)__popcll(mask));
+                if (int(lane) == leader) base = atomicAdd(job_counter, (unsigned long long)__popcll(jm));
                 const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
                 base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
-                if (need) ln.take_job(base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull)), n_jobs, rc);
+                if (need_job) {
+                    job = base + (unsigned long long)__popcll(jm & lanes_below);
+                    if (job >= n_jobs) {
+                        slot_done = true; // no jobs left: this slot retires
+                    } else {
+                        const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
+                        const uint32_t chunk = uint32_t(job / jobs_per_chunk), rem = uint32_t(job % jobs_per_chunk);
+                        uint32_t tx, ty;
+                        tile_unpermute(rc.tile_rank + (rem >> 6) * rc.tile_world, rc.tiles_x, tx, ty);
+                        const uint32_t px = tx * 8u + (rem & 7u), row = ty * 8u + ((rem & 63u) >> 3);
+                        pxrow = px | (row << 16);
+                        smp = chunk * rc.spp_chunk;
+                        smp_end = smp + rc.spp_chunk < rc.spp ? smp + rc.spp_chunk : rc.spp;
+                        if (px >= rc.width || row >= rc.height) smp = smp_end; // outside the image: an empty job
+                        acc = V3<R>();
+                    }
+                }
             }
-            if (ln.st == ST_NEW && ln.s < ln.s_end) ln.step_new(sc, cam, rc, cnt);
+            if (need_sample && !slot_done) { // main.rs:212-215: the job's next sample
+                path_begin(ps, cam, rc, pxrow & 0xFFFFu, pxrow >> 16, smp);
+                pu[size_t(PU_KEY_LO) * n_slots] = uint32_t(ps.key);
+                pu[size_t(PU_KEY_HI) * n_slots] = uint32_t(ps.key >> 32);
+                pu[size_t(PU_PXROW) * n_slots] = pxrow;
+                pu[size_t(PU_S) * n_slots] = smp;
+                pu[size_t(PU_SEND) * n_slots] = smp_end;
+                pu[size_t(PU_JOB_LO) * n_slots] = uint32_t(job);
+                pu[size_t(PU_JOB_HI) * n_slots] = uint32_t(job >> 32);
+                pr[size_t(PR_AX) * n_slots] = acc.x; pr[size_t(PR_AY) * n_slots] = acc.y; pr[size_t(PR_AZ) * n_slots] = acc.z;
+                emit = true;
+            }
+            const unsigned long long em = __ballot(emit);
+            if (emit) { // the slot's next ray: path state back to memory, ray onto the queue
+                pr[size_t(PR_OX) * n_slots] = ps.ray.o.x; pr[size_t(PR_OY) * n_slots] = ps.ray.o.y; pr[size_t(PR_OZ) * n_slots] = ps.ray.o.z;
+                pr[size_t(PR_DX) * n_slots] = ps.ray.d.x; pr[size_t(PR_DY) * n_slots] = ps.ray.d.y; pr[size_t(PR_DZ) * n_slots] = ps.ray.d.z;
+                pr[size_t(PR_TIME) * n_slots] = ps.ray.time;
+                pr[size_t(PR_TX) * n_slots] = ps.throughput.x; pr[size_t(PR_TY) * n_slots] = ps.throughput.y; pr[size_t(PR_TZ) * n_slots] = ps.throughput.z;
+                pr[size_t(PR_LX) * n_slots] = ps.radiance.x; pr[size_t(PR_LY) * n_slots] = ps.radiance.y; pr[size_t(PR_LZ) * n_slots] = ps.radiance.z;
+                pu[size_t(PU_BOUNCE) * n_slots] = ps.bounce;
+                const uint32_t idx = ray_n + uint32_t(__popcll(em & lanes_below));
+                rq_f[0u * QCAP + idx] = ps.ray.o.x; rq_f[1u * QCAP + idx] = ps.ray.o.y; rq_f[2u * QCAP + idx] = ps.ray.o.z;
+                rq_f[3u * QCAP + idx] = ps.ray.d.x; rq_f[4u * QCAP + idx] = ps.ray.d.y; rq_f[5u * QCAP + idx] = ps.ray.d.z;
+                rq_f[6u * QCAP + idx] = ps.ray.time;
+                rq_slot[idx] = hslot;
+            }
+            ray_n += uint32_t(__popcll(em));
+            continue;
+        }
+
+        // ====================================================================== TRAVERSE (one step for every ray)
+        const unsigned long long nm = __ballot(!has_ray);
+        if (nm != 0ull && ray_n != 0u) { // hand queued rays to the idle lanes
+            const uint32_t want = uint32_t(__popcll(nm)), take = want < ray_n ? want : ray_n;
+            if constexpr (COUNT) { dbg[11] += 1; dbg[12] += take; }
+            const uint32_t rank = uint32_t(__popcll(nm & lanes_below));
+            if (!has_ray && rank < take) {
+                const uint32_t e = ray_n - 1u - rank;
+                wray.o = V3<R>(rq_f[0u * QCAP + e], rq_f[1u * QCAP + e], rq_f[2u * QCAP + e]);
+                wray.d = V3<R>(rq_f[3u * QCAP + e], rq_f[4u * QCAP + e], rq_f[5u * QCAP + e]);
+                wray.time = rq_f[6u * QCAP + e];
+                slot = rq_slot[e];
+                cnt.ray();
+                trav_begin(tr, sc, wray);
+                has_ray = true;
+            }
+            ray_n -= take;
+        }
+        // A burst of traversal steps: one stage per step, chosen by vote (rt_sched.hpp) — the code of ONE step kind runs,
+        // for all lanes waiting on it; the others keep their cursor.  Only the traversal cursor is loop-carried here.
+        // The burst ends once enough lanes have finished their ray to make the hand-over below worth its cost.
+        {
+            const uint32_t retire_batch = ray_n != 0u ? 16u : 64u;
+            if constexpr (COUNT) dbg[8] += 1;
+            for (;;) {
+                const uint32_t st = (has_ray && tr.node != TRAV_DONE) ? stage_of(tr.node) : uint32_t(ST_NONE);
+                uint32_t n[ST_COUNT];
+#pragma unroll
+                for (uint32_t k = 0; k < ST_COUNT; ++k) n[k] = uint32_t(__popcll(__ballot(st == k)));
+                if (n[0] + n[1] + n[2] + n[3] == 0u) break; // every ray of the wave is finished
+                const uint32_t pick = sched_pick(n, pol);
+#pragma unroll
+                for (uint32_t k = 0; k < ST_COUNT; ++k)
+                    if (pick == k) { served[k] += n[k]; if constexpr (COUNT) { dbg[k] += 1; dbg[4 + k] += n[k]; } }
+                if ((++iter & 255u) == 0u) adapt_policy(pol, served);
+                if (pick == ST_NODE) {
+                    if (st == ST_NODE) trav_node_step(tr, sc, wray, t_min, stack, cnt);
+                } else if (st == pick) {
+                    trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
+                }
+                if (uint32_t(__popcll(__ballot(has_ray && tr.node == TRAV_DONE))) >= retire_batch) break;
+            }
+        }
+        const bool fin = has_ray && tr.node == TRAV_DONE;
+        const unsigned long long fm = __ballot(fin);
+        if (fm != 0ull) { // finished rays: hit onto the queue, lane free again
+            if (fin) {
+                const uint32_t idx = hit_n + uint32_t(__popcll(fm & lanes_below));
+                hq_t[idx] = tr.closest;
+                hq_prim[idx] = tr.found ? tr.best.prim : make_ref(PRIM_NONE, 0);
+                hq_inst[idx] = tr.best.inst;
+                hq_meta[idx] = slot | (uint32_t(tr.best.aux) << 8);
+                has_ray = false;
+            }
+            hit_n += uint32_t(__popcll(fm));
         }
     }
 
@@ -144,13 +295,95 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
             atomicAdd(&counters->prims, (unsigned long long)p);
             atomicAdd(&counters->texels, (unsigned long long)t);
 #pragma unroll
-            for (uint32_t k = 0; k < ST_COUNT; ++k) {
-                atomicAdd(&counters->stage_execs[k], (unsigned long long)execs[k]);
-                atomicAdd(&counters->stage_lanes[k], (unsigned long long)served[k]);
-                atomicAdd(&counters->thr_sum[k], (unsigned long long)pol.threshold[k]);
-                atomicAdd(&counters->pop_sum[k], pop[k]);
+            for (int k = 0; k < 16; ++k) atomicAdd(&counters->dbg[k], (unsigned long long)dbg[k]);
+        }
+    }
+}
+
+// The plain form of the same loop: a lane OWNS a path (and its job) and alternates "regenerate or advance by one
+// bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
+// bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
+// decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
+template <typename R, bool COUNT>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+                                                            R bg_b, R t_min, R* __restrict__ partial,
+                                                            unsigned long long* __restrict__ job_counter,
+                                                            DeviceCounters* __restrict__ counters) {
+    extern __shared__ int32_t lds_stack[];
+    LdsStack stack{lds_stack + threadIdx.x, blockDim.x};
+    typename CounterSel<COUNT>::type cnt;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
+    const unsigned long long n_jobs = jobs_per_chunk * rc.n_chunks;
+    const V3<R> background(bg_r, bg_g, bg_b);
+
+    bool has_job = false, alive = false, done = false;
+    unsigned long long job = 0;
+    uint32_t px = 0, row = 0, s = 0, s_end = 0;
+    V3<R> acc;
+    PathState<R> ps;
+
+    for (;;) {
+        // ---- job hand-out: wave-aggregated, one atomic per refill event
+        const bool need = !done && !alive && s >= s_end;
+        const unsigned long long mask = __ballot(need);
+        if (mask != 0ull) {
+            if (need && has_job) { // retire the finished job: its sequential sum
+                R* dst = partial + job * 3ull;
+                dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
+                has_job = false;
             }
-            atomicAdd(&counters->waves, 1ull);
+            const int leader = __ffsll((long long)mask) - 1;
+            unsigned long long base = 0;
+            if (int(lane) == leader) base = atomicAdd(job_counter, (unsigned long long)__popcll(mask));
+            const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
+            base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+            if (need) {
+                job = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+                if (job >= n_jobs) {
+                    done = true;
+                } else {
+                    const uint32_t chunk = uint32_t(job / jobs_per_chunk);
+                    const uint32_t rem = uint32_t(job % jobs_per_chunk);
+                    const uint32_t local_tile = rem >> 6, l = rem & 63u;
+                    uint32_t tx, ty;
+                    tile_unpermute(rc.tile_rank + local_tile * rc.tile_world, rc.tiles_x, tx, ty);
+                    px = tx * 8u + (l & 7u);
+                    row = ty * 8u + (l >> 3);
+                    s = chunk * rc.spp_chunk;
+                    s_end = min(rc.spp, s + rc.spp_chunk);
+                    if (px >= rc.width || row >= rc.height) s = s_end; // outside the image: an empty job
+                    acc = V3<R>();
+                    has_job = true;
+                }
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+
+        // ---- one path per lane: regenerate or advance by one bounce
+        if (!done) {
+            if (!alive && s < s_end) {
+                path_begin(ps, cam, rc, px, row, s);
+                alive = true;
+            }
+            if (alive) {
+                alive = path_step(ps, sc, rc, background, t_min, stack, cnt);
+                if (!alive) { // main.rs:216: acc + color(...)
+                    acc = acc + ps.radiance;
+                    ++s;
+                }
+            }
+        }
+    }
+
+    if constexpr (COUNT) {
+        uint32_t r = wave_sum(cnt.rays), n = wave_sum(cnt.nodes), p = wave_sum(cnt.prims), t = wave_sum(cnt.texels);
+        if (lane == 0) {
+            atomicAdd(&counters->rays, (unsigned long long)r);
+            atomicAdd(&counters->nodes, (unsigned long long)n);
+            atomicAdd(&counters->prims, (unsigned long long)p);
+            atomicAdd(&counters->texels, (unsigned long long)t);
         }
     }
 }
@@ -352,6 +585,8 @@ struct DeviceState {
     // workspace, grown on demand and kept
     void* partial = nullptr;
     size_t partial_bytes = 0;
+    void* pool_r = nullptr; size_t pool_r_bytes = 0; // path-slot state (reals / words), SoA over all slots
+    void* pool_u = nullptr; size_t pool_u_bytes = 0;
     unsigned long long* job_counter = nullptr; // [0] job counter, then DeviceCounters
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the blocking host-output render()
@@ -373,6 +608,8 @@ void device_release(DeviceState* d) {
     if (!d) return;
     d->s32.release(); d->s64.release();
     if (d->partial) (void)hipFree(d->partial);
+    if (d->pool_r) (void)hipFree(d->pool_r);
+    if (d->pool_u) (void)hipFree(d->pool_u);
     if (d->job_counter) (void)hipFree(d->job_counter);
     if (d->packed) (void)hipFree(d->packed);
     if (d->linear) (void)hipFree(d->linear);
@@ -457,7 +694,6 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
-    if (const char* e = getenv("RTTNW_DEBUG_STACK_EXTRA")) rc.stack_depth += uint32_t(atoi(e));
     const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
     if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(n_jobs, 1) * 3 * sizeof(R))) return g;
 
@@ -467,26 +703,52 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     const CameraRec<R> camr = narrow_camera<R>(cam64);
 
     const bool count = p->collect_counters != 0;
-    auto kernel = count ? trace_kernel<R, true> : trace_kernel<R, false>;
-    const size_t lds_bytes = size_t(rc.stack_depth) * TRACE_BLOCK * sizeof(int32_t);
-    if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stack does not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
-    HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-    int blocks_per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, (const void*)kernel, TRACE_BLOCK, lds_bytes));
-    blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
-    // persistent grid: what the chip holds at once (no inter-workgroup dependency, so a little
-    // over-subscription is harmless), but never more waves than jobs/64
-    const size_t waves_needed = (n_jobs + 63) / 64;
-    size_t grid = std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + 3) / 4);
-    grid = std::max<size_t>(grid, 1);
-
+    // Two forms of the same loop (DESIGN.md "Kernels"): measured on MI355X the lane-owns-a-path form wins on shallow
+    // scenes (cornell_box, final_scene: <= ~1k nodes), the decoupled form on deep BVHs where traversal lengths vary
+    // most (1M spheres).  RTTNW_KERNEL=plain|wave overrides the choice (experiments only).
+    const char* kv = getenv("RTTNW_KERNEL");
+    bool plain = s->flat.nodes.size() < 65536;
+    if (kv && std::strcmp(kv, "plain") == 0) plain = true;
+    if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
     DeviceCounters* dc = reinterpret_cast<DeviceCounters*>(d->job_counter + 1);
-    if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
-    if (n_jobs > 0) {
-        hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
-                           R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc);
-        HIP_TRY(hipGetLastError());
+    auto persistent_grid = [&](const void* kernel, size_t lds_bytes, size_t waves_needed, size_t& grid) -> int {
+        if (lds_bytes > 160 * 1024) { set_last_error("render: queues + traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        int blocks_per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, TRACE_BLOCK, lds_bytes));
+        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+        // what the chip holds at once (no inter-workgroup dependency, so a little over-subscription is harmless),
+        // but never more waves than there is work for
+        grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + 3) / 4));
+        return 0;
+    };
+    if (plain) {
+        auto kernel = count ? trace_kernel_plain<R, true> : trace_kernel_plain<R, false>;
+        const size_t lds_bytes = size_t(rc.stack_depth) * TRACE_BLOCK * sizeof(int32_t);
+        size_t grid = 1;
+        if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + 63) / 64, grid)) return g;
+        if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
+        if (n_jobs > 0) {
+            hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
+                               R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        auto kernel = count ? trace_kernel<R, true> : trace_kernel<R, false>;
+        const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
+        size_t grid = 1;
+        if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
+        const size_t n_slots = grid * (TRACE_BLOCK / 64) * SLOTS_PER_WAVE;
+        if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
+        if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
+        if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
+        if (n_jobs > 0) {
+            hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
+                               R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
+                               (uint32_t*)d->pool_u, uint32_t(n_slots));
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (stats) HIP_TRY(hipEventRecord(d->ev1, stream));
     hipLaunchKernelGGL(resolve_kernel<R>, dim3((L.pixels_per_rank + 255) / 256), dim3(256), 0, stream, (const R*)d->partial,
@@ -513,24 +775,18 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             HIP_TRY(hipMemcpy(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
             stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
             if (getenv("RTTNW_DEBUG_SCHED")) {
-                static const char* names[] = {"NODE", "SPHERE", "BOX", "MISC", "POST", "NEW"};
-                unsigned long long te = 0;
-                for (int k = 0; k < 6; ++k) te += hc.stage_execs[k];
-                for (int k = 0; k < 6; ++k)
-                    fprintf(stderr, "[sched] %-6s execs %12llu (%.1f%%)  lanes/exec %.2f  lane-steps/sample %.2f\n", names[k], hc.stage_execs[k],
-                            100.0 * hc.stage_execs[k] / double(te ? te : 1), hc.stage_execs[k] ? double(hc.stage_lanes[k]) / hc.stage_execs[k] : 0.0,
-                            double(hc.stage_lanes[k]) / double(stats->samples ? stats->samples : 1));
-                fprintf(stderr, "[sched] waves %llu mean final thresholds:", hc.waves);
-                for (int k = 0; k < 6; ++k) fprintf(stderr, " %s %.1f", names[k], double(hc.thr_sum[k]) / double(hc.waves ? hc.waves : 1));
-                fprintf(stderr, "\n[sched] time-average queue population:");
-                double tp = 0;
-                for (int k = 0; k < 6; ++k) { fprintf(stderr, " %s %.1f", names[k], double(hc.pop_sum[k]) / double(te ? te : 1)); tp += double(hc.pop_sum[k]) / double(te ? te : 1); }
-                fprintf(stderr, "  total live %.1f\n", tp);
+                static const char* names[] = {"NODE", "SPHERE", "BOX", "MISC"};
+                const double w64 = double(stats->samples) / 64.0;
+                for (int k = 0; k < 4; ++k)
+                    fprintf(stderr, "[sched] %-6s execs/64smp %8.1f  lanes/exec %5.1f\n", names[k], hc.dbg[k] / w64, hc.dbg[k] ? double(hc.dbg[4 + k]) / hc.dbg[k] : 0.0);
+                fprintf(stderr, "[sched] bursts/64smp %.1f  shades/64smp %.2f (lanes %.1f)  refills/64smp %.1f (lanes %.1f)\n", hc.dbg[8] / w64, hc.dbg[9] / w64,
+                        hc.dbg[9] ? double(hc.dbg[10]) / hc.dbg[9] : 0.0, hc.dbg[11] / w64, hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
             }
         }
         stats->n_nodes = uint32_t(s->flat.nodes.size());
         stats->n_prims = s->flat.n_prims_in_bvh;
         stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
+        stats->reserved = plain ? 0u : 1u; // which kernel form ran: 0 lane-owns-path, 1 decoupled
     }
     return RTTNW_OK;
 }

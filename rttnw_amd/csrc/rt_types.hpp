@@ -136,8 +136,7 @@ struct RenderConsts {
 
 struct DeviceCounters {
     unsigned long long rays, nodes, prims, texels;
-    unsigned long long stage_execs[8], stage_lanes[8]; // scheduler statistics (counting variant only)
-    unsigned long long thr_sum[8], pop_sum[8], waves;               // final thresholds summed over waves
+    unsigned long long dbg[16]; // scheduler statistics of the counting variant: [k] stage execs, [4+k] lanes served, [8] bursts, [9] shades, [10] shade lanes, [11] refills, [12] refill lanes
 };
 
 } // namespace rt

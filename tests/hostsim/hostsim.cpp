@@ -4,7 +4,6 @@
 // no CPU fallback.  Job order and per-job accumulation mirror render.hip's trace kernel exactly.
 #include "../../include/rttnw_hip.h"
 #include "../../rttnw_amd/csrc/rt_core.hpp"
-#include "../../rttnw_amd/csrc/rt_sched.hpp"
 #include "../../rttnw_amd/csrc/scene_handle.hpp"
 
 #include <atomic>
@@ -174,87 +173,6 @@ static int probe_path_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttn
     return int(n);
 }
 
-// Wave-scheduler simulator: `n_waves` virtual wave64s run the trace kernel's lane state machine and stage
-// policy (rt_sched.hpp) over the real scene, jobs handed out from one shared counter exactly like the kernel's
-// wave-aggregated atomic.  Produces the image (through the same partial-sum + resolve order) and, per stage,
-// how often it ran and how many lanes it served — the inputs for tuning SchedPolicy offline.
-template <typename R>
-int sched_sim_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, const uint32_t* thresholds, uint32_t n_waves,
-                double* out_linear, uint64_t* execs, uint64_t* lanes_served) {
-    HostScene<R> hs(s->flat);
-    CameraRec<double> cam64;
-    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
-                cam->focus_distance, cam->open_time, cam->close_time, cam64);
-    const CameraRec<R> camr = narrow_camera<R>(cam64);
-    RenderConsts rc{};
-    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 63) / 64;
-    rc.n_chunks = (p->spp + rc.spp_chunk - 1) / rc.spp_chunk;
-    rc.tiles_x = (p->width + 7) / 8; rc.tiles_y = (p->height + 7) / 8; rc.n_tiles = rc.tiles_x * rc.tiles_y;
-    rc.tile_rank = 0; rc.tile_world = 1; rc.my_tiles = rc.n_tiles;
-    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
-    const V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));
-    const R t_min = R(p->t_min);
-    SchedPolicy pol = default_policy();
-    const bool adaptive = !thresholds || thresholds[0] == 0; // thresholds[0] == 0: adapt like the kernel does
-    if (thresholds && !adaptive) for (uint32_t k = 0; k < ST_COUNT; ++k) pol.threshold[k] = thresholds[k];
-    const unsigned long long n_jobs = (unsigned long long)rc.my_tiles * 64ull * rc.n_chunks;
-    std::vector<R> partial(size_t(n_jobs) * 3, R(0));
-    unsigned long long job_counter = 0;
-    struct Wave {
-        std::vector<Lane<R>> lane; std::vector<HostStack> stack; bool done = false;
-        SchedPolicy pol; uint32_t served[ST_COUNT] = {0, 0, 0, 0, 0, 0}; uint32_t iter = 0;
-    };
-    std::vector<Wave> waves(n_waves);
-    for (auto& w : waves) { w.lane.resize(64); w.stack.resize(64); w.pol = pol; for (auto& l : w.lane) l.init(); }
-    NoCounters cnt;
-    for (uint32_t k = 0; k < ST_COUNT; ++k) { execs[k] = 0; lanes_served[k] = 0; }
-    size_t alive_waves = n_waves;
-    while (alive_waves) {
-        for (auto& w : waves) {
-            if (w.done) continue;
-            uint32_t n[ST_COUNT] = {0, 0, 0, 0, 0, 0};
-            for (auto& l : w.lane) if (l.st < ST_COUNT) n[l.st]++;
-            const uint32_t pick = sched_pick(n, w.pol);
-            if (pick == ST_DONE) { w.done = true; --alive_waves; continue; }
-            execs[pick]++; lanes_served[pick] += n[pick];
-            w.served[pick] += n[pick];
-            if (adaptive && (++w.iter & 127u) == 0) adapt_policy(w.pol, w.served);
-            for (int i = 0; i < 64; ++i) {
-                Lane<R>& l = w.lane[i];
-                if (l.st != pick) continue;
-                if (pick == ST_NODE) l.step_node(hs.view, t_min, w.stack[i], cnt);
-                else if (pick == ST_SPHERE || pick == ST_BOX || pick == ST_MISC) l.step_leaf(hs.view, t_min, w.stack[i], cnt);
-                else if (pick == ST_POST) l.step_post(hs.view, rc, background, t_min, cnt);
-                else { // ST_NEW
-                    if (l.needs_job()) {
-                        if (l.has_job) { R* d = &partial[size_t(l.job) * 3]; d[0] = l.acc.x; d[1] = l.acc.y; d[2] = l.acc.z; l.has_job = false; }
-                        l.take_job(job_counter++, n_jobs, rc);
-                    }
-                    if (l.st == ST_NEW && l.s < l.s_end) l.step_new(hs.view, camr, rc, cnt);
-                }
-            }
-        }
-    }
-    if (out_linear) { // resolve: chunk partials in chunk order, then un-tile
-        const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
-        for (uint32_t row = 0; row < rc.height; ++row)
-            for (uint32_t px = 0; px < rc.width; ++px) {
-                const uint32_t permuted = tile_permuted(px >> 3, row >> 3, rc.tiles_x);
-                const unsigned long long pidx = (unsigned long long)permuted * 64ull + ((row & 7u) << 3) + (px & 7u);
-                R r = 0, g = 0, b = 0;
-                for (uint32_t c = 0; c < rc.n_chunks; ++c) {
-                    const R* src = &partial[size_t(c * jobs_per_chunk + pidx) * 3];
-                    r = r + src[0]; g = g + src[1]; b = b + src[2];
-                }
-                const R spp = R(rc.spp);
-                const size_t o = (size_t(row) * rc.width + px) * 3;
-                out_linear[o] = double(r / spp); out_linear[o + 1] = double(g / spp); out_linear[o + 2] = double(b / spp);
-            }
-    }
-    return RTTNW_OK;
-}
-
 extern "C" {
 int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
                    rttnw_stats* stats, int n_threads) {
@@ -273,11 +191,5 @@ int hostsim_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
                        uint32_t sample, double* out, uint32_t max_out) {
     return p->precision == RTTNW_F32 ? probe_path_t<float>(s, cam, p, px, row, sample, out, max_out)
                                      : probe_path_t<double>(s, cam, p, px, row, sample, out, max_out);
-}
-int hostsim_sched_sim(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, const uint32_t* thresholds, uint32_t n_waves,
-                      double* out_linear, uint64_t* execs, uint64_t* lanes_served) {
-    if (!s || !s->committed || !cam || !p || !execs || !lanes_served || !n_waves) return RTTNW_ERR_INVALID;
-    return p->precision == RTTNW_F32 ? sched_sim_t<float>(s, cam, p, thresholds, n_waves, out_linear, execs, lanes_served)
-                                     : sched_sim_t<double>(s, cam, p, thresholds, n_waves, out_linear, execs, lanes_served);
 }
 }

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override width = height")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--counter-spp", type=int, default=8)
+    ap.add_argument("--no-f64", action="store_true", help="skip the one-step F64 cross-check line")
     args = ap.parse_args()
 
     import numpy as np
@@ -130,17 +131,31 @@ def main():
     value = samples_total / (ms_per_step * 1e-3) / 1e6
     achieved = b_alg * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
+    # ---- the same workload through the F64 kernels (the reference's arithmetic type), one step, N = 1 only
+    f64 = None
+    if world == 1 and precision == abi.F32 and not args.no_f64:
+        cam64, p64 = util.params_for(setup, W, H, spp, precision=abi.F64, seed=1)
+        r64 = render.DeviceRenderer(sc, cam64, p64)
+        r64.step()
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        r64.step()
+        torch.cuda.synchronize()
+        dq = time.perf_counter() - tq
+        f64 = {"value": round(samples_total / dq / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dq * 1e3, 3), "steps": 1}
+        del r64
+
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import rto
         so, _ = util.build(rto.binding(), scenes, scene_name, earth, min(param, 20000) if scene_name == "spheres_1m" else param)
         cores = os.cpu_count() or 1
-        camc, pcal = util.params_for(setup, W // 4, H // 4, 1, seed=1)
+        camc, pcal = util.params_for(setup, W, H, 1, seed=1)
         tc = time.perf_counter()
-        rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)
-        rate = (W // 4) * (H // 4) / max(1e-6, time.perf_counter() - tc)   # samples/s, calibration
-        cspp = int(max(1, min(64, round(rate * args.cpu_seconds / (W * H)))))
+        rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)      # calibration: 1 spp at full size
+        rate = W * H / max(1e-6, time.perf_counter() - tc)
+        cspp = int(max(1, min(256, round(rate * args.cpu_seconds / (W * H)))))
         camc, pcpu = util.params_for(setup, W, H, cspp, seed=1)
         tc = time.perf_counter()
         rto.render(so, camc, pcpu, n_threads=cores, want_rgba8=False)
@@ -168,6 +183,7 @@ def main():
                          "per_sample": {k: round(v, 3) for k, v in per_sample.items()},
                          "note": "scene is L2/MALL-resident; achieved = counted algorithmic bytes / kernel time"},
             "cpu_baseline": cpu,
+            "f64_kernels": f64,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -994,16 +994,21 @@ int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
     V3 background(p->background[0], p->background[1], p->background[2]);
     if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());
     if (n_threads <= 0) n_threads = 1;
-    std::atomic<uint32_t> next_row{0};
+    // work unit = 16 consecutive pixels of a row (finer than the reference's rayon row/column split needs, but it
+    // keeps hundreds of host threads busy to the end)
+    const uint32_t SEG = 16, segs_per_row = (W + SEG - 1) / SEG;
+    std::atomic<uint32_t> next_unit{0};
     std::vector<Counters> counters(n_threads);
     const List& world_list = *s->world;
     auto worker = [&](int tid) {
         Counters* cnt = p->collect_counters ? &counters[tid] : nullptr;
         for (;;) {
-            uint32_t r = next_row.fetch_add(1); // r = 0 is the TOP row == j = height-1 (main.rs:202-205)
-            if (r >= H) break;
+            uint32_t unit = next_unit.fetch_add(1);
+            if (unit >= H * segs_per_row) break;
+            uint32_t r = unit / segs_per_row; // r = 0 is the TOP row == j = height-1 (main.rs:202-205)
+            uint32_t i0 = (unit % segs_per_row) * SEG, i1 = std::min(W, i0 + SEG);
             uint32_t j = H - 1 - r;
-            for (uint32_t i = 0; i < W; ++i) {
+            for (uint32_t i = i0; i < i1; ++i) {
                 if (world > 1 && oracle_tile_owner(i / 8, r / 8, tiles_x, world) != p->tile_rank) continue;
                 uint64_t pixel = uint64_t(r) * W + i;
                 V3 total(0, 0, 0);

@@ -164,6 +164,21 @@ def main():
                "sample": "%s %dx%d spp=%d (%.1f s), f64 CPU oracle (reference-shaped: list scan + reference BVH builder)"
                          % (scene_name, W, H, cspp, dt)}
 
+    # HBM traffic of one launch of the dominant kernel: PMC counters can only be collected under rocprofv3, so the
+    # figure is read from the committed summary of `profiles/collect_pmc.sh` for this workload and kernel
+    # (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, both in KB), or null when there is none.
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_%s_%s.txt" % (scene_name, args.precision))
+    if world == 1 and not args.spp and not args.size and os.path.exists(pmc):
+        vals = {}
+        for line in open(pmc):
+            f = line.split()
+            if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[f[0]] = float(f[1])
+        if len(vals) == 2:
+            traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
+            traffic_src = "profiles/r01/" + os.path.basename(pmc)
+
     if rank == 0:
         out = {
             "metric": "Msamples/sec on final_scene 800x800 spp=1000; achieved HBM GB/s vs peak",
@@ -176,7 +191,7 @@ def main():
                        "scene_nodes": info.n_nodes, "scene_prims": info.n_prims, "scene_bytes_f32": info.scene_bytes,
                        "scene_build_s": round(build_s, 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if st.reserved == 0 else "", "float" if precision == abi.F32 else "double"),
                          "kernel_ms": round(kernel_ms, 3),
                          "alg_bytes_per_sample": round(b_alg, 2),

@@ -578,8 +578,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         Ray<R> bray = md.inst >= 0 ? to_object(sc.insts[md.inst], ray) : ray;
         const uint32_t bk = ref_kind(md.boundary), bi = ref_index(md.boundary);
         R t1, t2;
-        cnt.prim();
-        cnt.prim();
+        cnt.prim(); // first boundary query; the second is counted once the first has hit, as the reference would call it
         if (bk == PRIM_SPHERE) {
             // boundary.hit(ray, -inf, +inf) then boundary.hit(ray, t1 + 0.0001, +inf) (hittable.rs:745-751) are two
             // evaluations of ONE quadratic: same discriminant, near root first, far root if the near one is out of
@@ -596,6 +595,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
                 t1 = far_root;
                 if (t1 < -Lim<R>::inf() || Lim<R>::inf() < t1) continue;
             }
+            cnt.prim();
             const R lo2 = t1 + medium_sep(t1);
             t2 = near_root;
             if (t2 < lo2 || Lim<R>::inf() < t2) {
@@ -605,6 +605,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         } else {
             int aux;
             if (!prim_t(sc, bk, bi, bray, -Lim<R>::inf(), Lim<R>::inf(), t1, aux)) continue;
+            cnt.prim();
             if (!prim_t(sc, bk, bi, bray, t1 + medium_sep(t1), Lim<R>::inf(), t2, aux)) continue;
         }
         t1 = rt_max(t1, t_min);

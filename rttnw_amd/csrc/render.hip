@@ -304,13 +304,25 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
 // bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
 // bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
 // decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
-template <typename R, bool COUNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+template <typename R, bool COUNT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters) {
-    extern __shared__ int32_t lds_stack[];
-    LdsStack stack{lds_stack + threadIdx.x, blockDim.x};
+    // rc.lds_nodes != 0: the whole node array is copied into LDS in front of the stacks (small scenes: one
+    // dependent ~100-cycle LDS read per node visit instead of an L1/L2 round trip)
+    extern __shared__ __align__(16) int32_t lds_stack[];
+    int32_t* stack_mem = lds_stack;
+    if (rc.lds_nodes) {
+        const uint32_t n_words = rc.lds_nodes * uint32_t(sizeof(BvhNode) / 4);
+        const int4* src = reinterpret_cast<const int4*>(sc.nodes);
+        int4* dst = reinterpret_cast<int4*>(lds_stack);
+        for (uint32_t i = threadIdx.x; i < n_words / 4; i += blockDim.x) dst[i] = src[i];
+        sc.nodes = reinterpret_cast<const BvhNode*>(lds_stack);
+        stack_mem = lds_stack + n_words;
+        __syncthreads();
+    }
+    LdsStack stack{stack_mem + threadIdx.x, blockDim.x};
     typename CounterSel<COUNT>::type cnt;
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -708,7 +720,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     // most (1M spheres).  RTTNW_KERNEL=plain|wave overrides the choice (experiments only).
     const char* kv = getenv("RTTNW_KERNEL");
     bool plain = s->flat.nodes.size() < 65536;
-    if (kv && std::strcmp(kv, "plain") == 0) plain = true;
+    if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
     DeviceCounters* dc = reinterpret_cast<DeviceCounters*>(d->job_counter + 1);
@@ -724,15 +736,31 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
         return 0;
     };
     if (plain) {
-        auto kernel = count ? trace_kernel_plain<R, true> : trace_kernel_plain<R, false>;
-        const size_t lds_bytes = size_t(rc.stack_depth) * TRACE_BLOCK * sizeof(int32_t);
-        size_t grid = 1;
-        if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + 63) / 64, grid)) return g;
+        // Small scenes: node array in LDS, 1024-thread blocks (one per CU) so that nodes + 1024 stacks fit in 160 KB
+        const size_t node_bytes = s->flat.nodes.size() * sizeof(BvhNode);
+        const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && sizeof(R) == 4 &&
+                              node_bytes + size_t(rc.stack_depth) * 1024 * 4 <= 160 * 1024;
+        rc.lds_nodes = want_lds ? uint32_t(s->flat.nodes.size()) : 0u;
+        const int block = want_lds ? 1024 : TRACE_BLOCK;
+        const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, 1024> : (const void*)trace_kernel_plain<R, false, 1024>)
+                                      : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK>);
+        const size_t lds_bytes = (want_lds ? node_bytes : 0) + size_t(rc.stack_depth) * block * sizeof(int32_t);
+        if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        int blocks_per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, lds_bytes));
+        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+        const size_t waves_per_block = size_t(block) / 64;
+        const size_t grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, ((n_jobs + 63) / 64 + waves_per_block - 1) / waves_per_block));
         if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
         if (n_jobs > 0) {
-            hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
-                               R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc);
-            HIP_TRY(hipGetLastError());
+            R bg0 = R(p->background[0]), bg1 = R(p->background[1]), bg2 = R(p->background[2]), tmin = R(p->t_min);
+            R* part = (R*)d->partial;
+            unsigned long long* jc = d->job_counter;
+            SceneView<R> view = ds.view;
+            CameraRec<R> camv = camr;
+            void* args[] = {&view, &camv, &rc, &bg0, &bg1, &bg2, &tmin, &part, &jc, &dc};
+            HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
         }
     } else {
         auto kernel = count ? trace_kernel<R, true> : trace_kernel<R, false>;

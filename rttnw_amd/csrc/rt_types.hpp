@@ -131,6 +131,7 @@ struct RenderConsts {
     uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
     uint32_t quirks;
     uint32_t stack_depth;
+    uint32_t lds_nodes; // lane-owns-path kernel: number of BVH nodes resident in LDS (0 = nodes read from global memory)
     uint64_t seed;
 };
 

@@ -500,8 +500,10 @@ struct Lowering {
         uint32_t top_depth = 0;
         Box3 wb;
         fs.top_root = build_root(top, top_depth, wb);
-        // far-child pushes: <= one per level; + the instance sentinel; + slack
-        fs.stack_depth = top_depth + inst_depth + 3;
+        // Entries a lane's stack can hold at once: one pending far child per level of INNER nodes of the top tree
+        // (build depth counts the leaf level too, and build_root adds one), one sentinel while inside an instance,
+        // and the same for the instance's tree.  +1 spare.
+        fs.stack_depth = top_depth + inst_depth + 1;
         return 0;
     }
 };

@@ -167,12 +167,19 @@ RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key) {
 // ---------------------------------------------------------------- AABB slab test (bound.rs:13-32)
 // The three per-axis early-outs of the reference collapse into one comparison: tmin only grows and
 // tmax only shrinks, so `tmax < tmin` at the end <=> it held at some axis.
-template <typename R> struct SlabSlack { static RT_HD R widen(R tmax) { return tmax; } };
-template <> struct SlabSlack<float> { // f32: absorb rounding of (bound - o) * inv (boxes are already padded)
-    static RT_HD float widen(float tmax) { return tmax > 0.f ? tmax * 1.0000005f : tmax; }
+// (The FMA form t = bound*inv - o*inv was tried for f32 and rejected: its error is absolute, ~eps*|o*inv|, which
+// for a far-away origin and a small direction component — spheres_1m's primary rays — is larger than a leaf.)
+template <typename R> struct SlabRay { // what a ray contributes to every slab test of its walk
+    V3<R> inv; // 1 / d
 };
+template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
+    SlabRay<R> sr;
+    sr.inv = V3<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+    return sr;
+}
 template <typename R>
-RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, V3<R> inv, R tmin, R tmax, R& t_enter) {
+RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, const SlabRay<R>& sr, R tmin, R tmax, R& t_enter) {
+    const V3<R> inv = sr.inv;
     R t0x = (R(lo[0]) - o.x) * inv.x, t1x = (R(hi[0]) - o.x) * inv.x;
     R t0y = (R(lo[1]) - o.y) * inv.y, t1y = (R(hi[1]) - o.y) * inv.y;
     R t0z = (R(lo[2]) - o.z) * inv.z, t1z = (R(hi[2]) - o.z) * inv.z;
@@ -182,7 +189,9 @@ RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, V3<R> inv, R tmin
     tmin = rt_max(nz, rt_max(ny, rt_max(nx, tmin)));
     tmax = rt_min(fz, rt_min(fy, rt_min(fx, tmax)));
     t_enter = tmin;
-    return !(SlabSlack<R>::widen(tmax) < tmin);
+    // f32: absorb the rounding of (bound - o) * inv and of the 1-2 ulp reciprocal (boxes are already padded)
+    if constexpr (sizeof(R) == 4) return !((tmax > R(0) ? tmax * R(1.0000005) : tmax) < tmin);
+    else return !(tmax < tmin);
 }
 
 // ---------------------------------------------------------------- primitive tests: t only
@@ -338,7 +347,7 @@ constexpr int32_t TRAV_DONE = INT32_MIN + 2; // Trav::node once the stack has ru
 
 template <typename R> struct Trav {
     Ray<R> ray;       // the ray in the current space (world, or an instance's object space)
-    V3<R> inv;        // 1 / ray.d
+    SlabRay<R> sr;    // 1 / ray.d (and the f32 FMA-form products)
     R closest;
     HitRef best;
     int32_t node;     // >= 0: inner node to visit; < 0: leaf bits (or CHILD_EMPTY); TRAV_DONE: finished
@@ -348,11 +357,10 @@ template <typename R> struct Trav {
     bool found;
 };
 
-template <typename R> RT_HD V3<R> inv_dir(V3<R> d) { return V3<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z); }
 
 template <typename R> RT_HD void trav_begin(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray) {
     tr.ray = wray;
-    tr.inv = inv_dir(wray.d);
+    tr.sr = slab_ray(wray.o, wray.d);
     tr.closest = Lim<R>::max(); // world.hit(ray, t_min, f64::MAX) — main.rs:33
     tr.best.prim = make_ref(PRIM_NONE, 0);
     tr.best.inst = -1;
@@ -371,7 +379,7 @@ template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray
     int32_t node = stack.get(--tr.sp);
     if (node == STACK_SENTINEL) {
         tr.ray = wray;
-        tr.inv = inv_dir(wray.d);
+        tr.sr = slab_ray(wray.o, wray.d);
         tr.cur_inst = -1;
         if (tr.sp == 0) { tr.node = TRAV_DONE; return; }
         node = stack.get(--tr.sp);
@@ -385,8 +393,8 @@ RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     const BvhNode nd = sc.nodes[tr.node];
     cnt.node();
     R e0, e1;
-    const bool h0 = slab_hit(nd.lo0, nd.hi0, tr.ray.o, tr.inv, t_min, tr.closest, e0);
-    const bool h1 = slab_hit(nd.lo1, nd.hi1, tr.ray.o, tr.inv, t_min, tr.closest, e1);
+    const bool h0 = slab_hit(nd.lo0, nd.hi0, tr.ray.o, tr.sr, t_min, tr.closest, e0);
+    const bool h1 = slab_hit(nd.lo1, nd.hi1, tr.ray.o, tr.sr, t_min, tr.closest, e1);
     if (h0 && h1) {
         const bool swap = e1 < e0; // nearer child first
         stack.set(tr.sp++, swap ? nd.child0 : nd.child1);
@@ -410,7 +418,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
         const InstanceRec<R>& in = sc.insts[first];
         stack.set(tr.sp++, STACK_SENTINEL);
         tr.ray = to_object(in, wray);
-        tr.inv = inv_dir(tr.ray.d);
+        tr.sr = slab_ray(tr.ray.o, tr.ray.d);
         tr.cur_inst = int32_t(first);
         tr.node = in.root;
         return;
@@ -734,21 +742,24 @@ RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, 
                  V3<R>& emitted, Cnt& cnt) {
     const MaterialRec<R> m = sc.mats[rec.mat];
     emitted = V3<R>();
+    // albedo / emission texture of the three textured kinds, evaluated in ONE place (Perlin is ~350 instructions)
+    V3<R> colour;
+    if (m.type == MAT_DIFFUSE_LIGHT || m.type == MAT_LAMBERTIAN || m.type == MAT_ISOTROPIC) colour = material_color(sc, m, rec, cnt);
     if (m.type == MAT_DIFFUSE_LIGHT) { // material.rs:242-250
-        emitted = material_color(sc, m, rec, cnt);
+        emitted = colour;
         return false;
     }
     if (m.type == MAT_LAMBERTIAN) { // material.rs:89-100
         V3<R> target = rec.p + rec.normal + random_in_unit_space<R>(key, bounce);
         ray.d = target - rec.p;
         ray.o = rec.p;
-        att = material_color(sc, m, rec, cnt);
+        att = colour;
         return true;
     }
     if (m.type == MAT_ISOTROPIC) { // material.rs:256-265
         ray.o = rec.p;
         ray.d = random_in_unit_space<R>(key, bounce);
-        att = material_color(sc, m, rec, cnt);
+        att = colour;
         return true;
     }
     if (m.type == MAT_METAL) { // material.rs:134-149

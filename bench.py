@@ -150,7 +150,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import rto
         so, _ = util.build(rto.binding(), scenes, scene_name, earth, min(param, 20000) if scene_name == "spheres_1m" else param)
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         camc, pcal = util.params_for(setup, W, H, 1, seed=1)
         tc = time.perf_counter()
         rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)      # calibration: 1 spp at full size

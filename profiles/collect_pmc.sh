@@ -7,7 +7,7 @@ mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-f64 $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
 }
 BENCH_ARGS="$*"
 if [ -n "$PMC_QUICK" ]; then
@@ -35,12 +35,12 @@ for d in sorted(glob.glob(os.path.join(out, "*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "trace_kernel" not in r.get("Kernel_Name", ""): continue
-            if ", true>" in r["Kernel_Name"]: continue          # skip the counting variant (untimed pre-pass)
+            if ", true" in r["Kernel_Name"]: continue           # skip the counting variant (untimed pre-pass)
             key = r["Counter_Name"]
             summ.setdefault(key, []).append(float(r["Counter_Value"]))
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "trace_kernel" in r["Kernel_Name"] and ", true>" not in r["Kernel_Name"]:
+            if "trace_kernel" in r["Kernel_Name"] and ", true" not in r["Kernel_Name"]:
                 summ.setdefault("duration_ns[%s]" % os.path.basename(d), []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
                 summ["VGPR/SGPR/LDS/scratch/grid/wg"] = ["%s/%s/%s/%s/%s/%s" % (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Grid_Size_X"], r["Workgroup_Size_X"])]
 with open(os.path.join(out, "summary.txt"), "w") as fo:

@@ -66,7 +66,7 @@ class DeviceRenderer:
         if self.world > 1:
             import torch.distributed as dist
             glist = list(self.gathered.unbind(0)) if self.rank == 0 else None
-            dist.gather(self.packed, glist, dst=0, group=self.group)
+            dist.gather(self.packed, glist, dst=0, group=self.group)   # RCCL: grouped send/recv into rank 0
             src = self.gathered
         if self.rank == 0:
             p = self.params

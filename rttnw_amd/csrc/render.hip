@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,11 +33,34 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // device-side helpers
 // ---------------------------------------------------------------------------------------------
+// Traversal memory of a lane: its BVH stack in LDS (entry e of lane l at e*stride + l: conflict-free b32 accesses) and
+// the way it reads node records.
 struct LdsStack {
     int32_t* base;   // &lds[threadIdx.x]
     uint32_t stride; // blockDim.x
     __device__ __forceinline__ void set(int i, int32_t v) { base[uint32_t(i) * stride] = v; }
     __device__ __forceinline__ int32_t get(int i) const { return base[uint32_t(i) * stride]; }
+    template <typename R> __device__ __forceinline__ BvhNode node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
+};
+// Same, with the whole node array resident in LDS in QUARTER-MAJOR order: the q-th 16 bytes of node i at
+// quarter[q*n_nodes + i].  64 lanes fetching the same quarter of 64 unrelated nodes then spread over all sixteen
+// 16-byte bank slots (i mod 16); in node-major order they would share four (the 64-byte records start at 0/64/128/
+// 192 mod 256) — measured 31 % of the LDS cycles were bank conflicts that way.
+struct LdsStackNodes {
+    int32_t* base;
+    uint32_t stride;
+    const int4* quarter; // LDS
+    uint32_t n_nodes;
+    __device__ __forceinline__ void set(int i, int32_t v) { base[uint32_t(i) * stride] = v; }
+    __device__ __forceinline__ int32_t get(int i) const { return base[uint32_t(i) * stride]; }
+    template <typename R> __device__ __forceinline__ BvhNode node(const SceneView<R>&, int32_t i) const {
+        union { int4 q[4]; BvhNode n; } u;
+        u.q[0] = quarter[uint32_t(i)];
+        u.q[1] = quarter[n_nodes + uint32_t(i)];
+        u.q[2] = quarter[2u * n_nodes + uint32_t(i)];
+        u.q[3] = quarter[3u * n_nodes + uint32_t(i)];
+        return u.n;
+    }
 };
 
 template <bool COUNT> struct CounterSel { using type = NoCounters; };
@@ -46,6 +70,30 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// Hands a distinct job index to every lane of `mask` (wave-uniform).  Jobs come from the batch [next, end) the wave
+// has reserved; when it runs short the wave leader reserves JOB_BATCH more with ONE atomic on the global counter.
+// (One atomic per refill event saturated the single counter address at ~10^8 small jobs per second.)
+constexpr unsigned long long JOB_BATCH = 256;
+__device__ __forceinline__ unsigned long long wave_take_jobs(unsigned long long mask, uint32_t lane, unsigned long long& next,
+                                                              unsigned long long& end, unsigned long long* __restrict__ job_counter) {
+    const uint32_t want = uint32_t(__popcll(mask)), rank = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+    const unsigned long long avail = end - next;
+    if (avail >= want) {
+        const unsigned long long job = next + rank;
+        next += want;
+        return job;
+    }
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (int(lane) == leader) base = atomicAdd(job_counter, JOB_BATCH);
+    const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
+    base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+    const unsigned long long job = rank < avail ? next + rank : base + (rank - avail);
+    next = base + (want - avail);
+    end = base + JOB_BATCH;
+    return job;
 }
 
 constexpr int TRACE_BLOCK = 256;
@@ -105,6 +153,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
     hq_meta[lane] = lane | HIT_FRESH;
     hq_meta[lane + 64u] = (lane + 64u) | HIT_FRESH;
     uint32_t ray_n = 0, hit_n = SLOTS_PER_WAVE; // wave-uniform queue fill levels
+    unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
 
     SchedPolicy pol = default_policy();
     uint32_t served[ST_COUNT] = {0, 0, 0, 0}; // lane-steps per traversal stage so far (wave-uniform)
@@ -176,20 +225,15 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                     R* dst = partial + job * 3ull;
                     dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
                 }
-                const int leader = __ffsll((long long)jm) - 1;
-                unsigned long long base = 0;
-                if (int(lane) == leader) base = atomicAdd(job_counter, (unsigned long long)__popcll(jm));
-                const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
-                base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+                const unsigned long long mine = wave_take_jobs(jm, lane, batch_next, batch_end, job_counter);
                 if (need_job) {
-                    job = base + (unsigned long long)__popcll(jm & lanes_below);
+                    job = mine;
                     if (job >= n_jobs) {
                         slot_done = true; // no jobs left: this slot retires
                     } else {
-                        const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
-                        const uint32_t chunk = uint32_t(job / jobs_per_chunk), rem = uint32_t(job % jobs_per_chunk);
-                        uint32_t tx, ty;
-                        tile_unpermute(rc.tile_rank + (rem >> 6) * rc.tile_world, rc.tiles_x, tx, ty);
+                        uint32_t chunk, rem, tx, ty;
+                        job_split(job, rc.div_jobs_per_chunk, chunk, rem);
+                        tile_unpermute(rc.tile_rank + (rem >> 6) * rc.tile_world, rc.div_tiles_x, tx, ty);
                         const uint32_t px = tx * 8u + (rem & 7u), row = ty * 8u + ((rem & 63u) >> 3);
                         pxrow = px | (row << 16);
                         smp = chunk * rc.spp_chunk;
@@ -304,25 +348,29 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
 // bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
 // bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
 // decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
-template <typename R, bool COUNT, int BLOCK>
+template <typename R, bool COUNT, int BLOCK, bool LDSN>
 __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters) {
-    // rc.lds_nodes != 0: the whole node array is copied into LDS in front of the stacks (small scenes: one
-    // dependent ~100-cycle LDS read per node visit instead of an L1/L2 round trip)
+    // LDSN: the whole node array is copied into LDS (quarter-major, see LdsStackNodes) in front of the stacks — small
+    // scenes: one dependent ~100-cycle LDS read per node visit instead of an L1/L2 round trip
     extern __shared__ __align__(16) int32_t lds_stack[];
-    int32_t* stack_mem = lds_stack;
-    if (rc.lds_nodes) {
-        const uint32_t n_words = rc.lds_nodes * uint32_t(sizeof(BvhNode) / 4);
+    typename std::conditional<LDSN, LdsStackNodes, LdsStack>::type stack;
+    if constexpr (LDSN) {
+        const uint32_t n = rc.lds_nodes;
         const int4* src = reinterpret_cast<const int4*>(sc.nodes);
         int4* dst = reinterpret_cast<int4*>(lds_stack);
-        for (uint32_t i = threadIdx.x; i < n_words / 4; i += blockDim.x) dst[i] = src[i];
-        sc.nodes = reinterpret_cast<const BvhNode*>(lds_stack);
-        stack_mem = lds_stack + n_words;
+        for (uint32_t i = threadIdx.x; i < n * 4u; i += blockDim.x) dst[(i & 3u) * n + (i >> 2)] = src[i];
         __syncthreads();
+        stack.base = lds_stack + n * uint32_t(sizeof(BvhNode) / 4) + threadIdx.x;
+        stack.stride = blockDim.x;
+        stack.quarter = dst;
+        stack.n_nodes = n;
+    } else {
+        stack.base = lds_stack + threadIdx.x;
+        stack.stride = blockDim.x;
     }
-    LdsStack stack{stack_mem + threadIdx.x, blockDim.x};
     typename CounterSel<COUNT>::type cnt;
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -331,6 +379,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
     const V3<R> background(bg_r, bg_g, bg_b);
 
     bool has_job = false, alive = false, done = false;
+    unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
     unsigned long long job = 0;
     uint32_t px = 0, row = 0, s = 0, s_end = 0;
     V3<R> acc;
@@ -346,21 +395,16 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                 dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
                 has_job = false;
             }
-            const int leader = __ffsll((long long)mask) - 1;
-            unsigned long long base = 0;
-            if (int(lane) == leader) base = atomicAdd(job_counter, (unsigned long long)__popcll(mask));
-            const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
-            base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+            const unsigned long long mine = wave_take_jobs(mask, lane, batch_next, batch_end, job_counter);
             if (need) {
-                job = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+                job = mine;
                 if (job >= n_jobs) {
                     done = true;
                 } else {
-                    const uint32_t chunk = uint32_t(job / jobs_per_chunk);
-                    const uint32_t rem = uint32_t(job % jobs_per_chunk);
+                    uint32_t chunk, rem, tx, ty;
+                    job_split(job, rc.div_jobs_per_chunk, chunk, rem);
                     const uint32_t local_tile = rem >> 6, l = rem & 63u;
-                    uint32_t tx, ty;
-                    tile_unpermute(rc.tile_rank + local_tile * rc.tile_world, rc.tiles_x, tx, ty);
+                    tile_unpermute(rc.tile_rank + local_tile * rc.tile_world, rc.div_tiles_x, tx, ty);
                     px = tx * 8u + (l & 7u);
                     row = ty * 8u + (l >> 3);
                     s = chunk * rc.spp_chunk;
@@ -707,6 +751,9 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
+    if (n_jobs >= (size_t(1) << 32)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
+    rc.div_jobs_per_chunk = make_fastdiv(std::max<uint32_t>(1u, rc.my_tiles * 64u));
+    rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
     if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(n_jobs, 1) * 3 * sizeof(R))) return g;
 
     CameraRec<double> cam64;
@@ -742,8 +789,8 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
                               node_bytes + size_t(rc.stack_depth) * 1024 * 4 <= 160 * 1024;
         rc.lds_nodes = want_lds ? uint32_t(s->flat.nodes.size()) : 0u;
         const int block = want_lds ? 1024 : TRACE_BLOCK;
-        const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, 1024> : (const void*)trace_kernel_plain<R, false, 1024>)
-                                      : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK>);
+        const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, 1024, true> : (const void*)trace_kernel_plain<R, false, 1024, true>)
+                                      : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false>);
         const size_t lds_bytes = (want_lds ? node_bytes : 0) + size_t(rc.stack_depth) * block * sizeof(int32_t);
         if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));

@@ -390,7 +390,7 @@ template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray
 // One inner node (tr.node >= 0): test both child boxes, descend into the nearer hit child, push the other.
 template <typename R, typename Stack, typename Cnt>
 RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
-    const BvhNode nd = sc.nodes[tr.node];
+    const BvhNode nd = stack.node(sc, tr.node); // from global memory, or from LDS when the kernel keeps the tree there
     cnt.node();
     R e0, e1;
     const bool h0 = slab_hit(nd.lo0, nd.hi0, tr.ray.o, tr.sr, t_min, tr.closest, e0);
@@ -865,6 +865,20 @@ RT_HD void tile_unpermute(uint32_t permuted, uint32_t tiles_x, uint32_t& tx, uin
     ty = permuted / tiles_x;
     uint32_t c = permuted % tiles_x;
     tx = (c + tiles_x - ty % tiles_x) % tiles_x;
+}
+// The same with the divisions by tiles_x done by multiply-shift (kernels: once per job).
+RT_HD void tile_unpermute(uint32_t permuted, FastDiv div_tiles_x, uint32_t& tx, uint32_t& ty) {
+    const uint32_t tiles_x = div_tiles_x.d;
+    ty = fdiv(permuted, div_tiles_x);
+    const uint32_t c = permuted - ty * tiles_x;
+    const uint32_t r = ty - fdiv(ty, div_tiles_x) * tiles_x; // ty % tiles_x
+    tx = c >= r ? c - r : c + tiles_x - r;
+}
+// Job index -> (chunk, index inside the chunk) with jobs_per_chunk = my_tiles * 64.
+RT_HD void job_split(unsigned long long job, FastDiv div_jobs_per_chunk, uint32_t& chunk, uint32_t& rem) {
+    const uint32_t j = uint32_t(job); // the launchers refuse renders with 2^32 or more jobs
+    chunk = fdiv(j, div_jobs_per_chunk);
+    rem = j - chunk * div_jobs_per_chunk.d;
 }
 
 } // namespace rt

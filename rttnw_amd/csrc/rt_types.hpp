@@ -124,6 +124,27 @@ template <typename R> struct SceneView {
     int32_t n_media;
 };
 
+// Division of a 32-bit value by a run-time constant as multiply-high + shifts (Granlund-Montgomery, the branch-free
+// form): q = (t + ((n - t) >> 1)) >> sh,  t = mulhi(n, mul).  Set up on the host (make_fastdiv).
+struct FastDiv { uint32_t mul, sh, d, pad; };
+RT_HD uint32_t fdiv(uint32_t n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(n, f.mul);
+#else
+    const uint32_t t = uint32_t((uint64_t(n) * f.mul) >> 32);
+#endif
+    return f.d == 1u ? n : (t + ((n - t) >> 1)) >> f.sh;
+}
+inline FastDiv make_fastdiv(uint32_t d) { // d >= 1
+    FastDiv f{0, 0, d, 0};
+    if (d == 1) return f; // fdiv() returns n itself
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                 // l = ceil(log2 d)
+    f.mul = uint32_t(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh = l - 1;
+    return f;
+}
+
 struct RenderConsts {
     uint32_t width, height, spp, max_depth;
     uint32_t spp_chunk, n_chunks;
@@ -131,6 +152,7 @@ struct RenderConsts {
     uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
     uint32_t quirks;
     uint32_t stack_depth;
+    FastDiv div_jobs_per_chunk, div_tiles_x; // job index -> (chunk, tile, pixel) without integer division
     uint32_t lds_nodes; // lane-owns-path kernel: number of BVH nodes resident in LDS (0 = nodes read from global memory)
     uint64_t seed;
 };

@@ -23,6 +23,7 @@ struct HostStack {
     int32_t data[256];
     void set(int i, int32_t v) { data[i] = v; }
     int32_t get(int i) const { return data[i]; }
+    template <typename R> BvhNode node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
 };
 
 template <typename R> struct HostScene {

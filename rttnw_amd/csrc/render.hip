@@ -744,7 +744,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     fill_layout(p->width, p->height, p->tile_world, L);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 127u) / 128u; // default: <= 128 chunks per pixel (fine jobs: short tail)
+    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 255u) / 256u; // default: <= 256 chunks per pixel (the end-of-launch tail is one job long)
     rc.n_chunks = (p->spp + rc.spp_chunk - 1) / rc.spp_chunk;
     rc.tiles_x = L.tiles_x; rc.tiles_y = L.tiles_y; rc.n_tiles = L.n_tiles;
     rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;

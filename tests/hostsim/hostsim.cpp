@@ -95,7 +95,7 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
     CameraRec<R> camr = narrow_camera<R>(cam64);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 127) / 128;
+    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 255) / 256;
     rc.n_chunks = (p->spp + rc.spp_chunk - 1) / rc.spp_chunk;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));

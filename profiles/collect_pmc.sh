@@ -27,7 +27,7 @@ run tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATEN
 fi
 # summarise: counter values of the trace kernel dispatches
 python3 - "$ROOT/$OUT" <<'PY'
-import csv, glob, os, sys, collections
+import csv, glob, os, re, sys, collections
 out = sys.argv[1]
 summ = collections.OrderedDict()
 for d in sorted(glob.glob(os.path.join(out, "*"))):
@@ -35,12 +35,12 @@ for d in sorted(glob.glob(os.path.join(out, "*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if "trace_kernel" not in r.get("Kernel_Name", ""): continue
-            if ", true" in r["Kernel_Name"]: continue           # skip the counting variant (untimed pre-pass)
+            if re.search(r"<(float|double), true", r["Kernel_Name"]): continue   # skip the counting variant (untimed pre-pass)
             key = r["Counter_Name"]
             summ.setdefault(key, []).append(float(r["Counter_Value"]))
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "trace_kernel" in r["Kernel_Name"] and ", true" not in r["Kernel_Name"]:
+            if "trace_kernel" in r["Kernel_Name"] and not re.search(r"<(float|double), true", r["Kernel_Name"]):
                 summ.setdefault("duration_ns[%s]" % os.path.basename(d), []).append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
                 summ["VGPR/SGPR/LDS/scratch/grid/wg"] = ["%s/%s/%s/%s/%s/%s" % (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"], r["Grid_Size_X"], r["Workgroup_Size_X"])]
 with open(os.path.join(out, "summary.txt"), "w") as fo:

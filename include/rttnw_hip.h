@@ -149,7 +149,7 @@ typedef struct rttnw_params {
                             per-pixel sum is chunk sums added in chunk order (deterministic). */
     uint32_t tile_rank;  /* this GPU's rank in the tile partition (0 for a single GPU) */
     uint32_t tile_world; /* number of GPUs sharing the framebuffer (>= 1) */
-    uint32_t collect_counters; /* 1: run the counting kernel variant and fill rttnw_stats */
+    uint32_t collect_counters; /* 1: run the counting kernel variant and fill rttnw_stats (2: plus per-record-kind timing, debugging) */
 } rttnw_params;
 
 typedef struct rttnw_stats {

@@ -125,6 +125,19 @@ constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH |
 //     one 8x8 tile) from the global counter with one wave-aggregated atomic.
 // Results do not depend on any of this scheduling: every draw is keyed by (pixel, sample, bounce), every job is a
 // sequential fold, and the resolve kernel adds a pixel's jobs in chunk order.
+// Re-read a by-value kernel argument from the kernarg segment at its (cold) point of use, so that it does not hold
+// SGPRs for the whole kernel: the trace kernels are at the 102-SGPR limit and spill to VGPR lanes otherwise.  The
+// pointer is passed through an empty asm so that the loads stay where they are written.
+template <typename T> __device__ __forceinline__ T kernarg_reload(uint32_t offset) {
+    typedef const char __attribute__((address_space(4)))* KPtr;
+    KPtr p = (KPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    T v;
+    __builtin_memcpy(&v, p + offset, sizeof(T));
+    return v;
+}
+template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; }; // layout of the first three kernel arguments
+
 template <typename R, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                 }
             }
             if (need_sample && !slot_done) { // main.rs:212-215: the job's next sample
-                path_begin(ps, cam, rc, pxrow & 0xFFFFu, pxrow >> 16, smp);
+                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, pxrow & 0xFFFFu, pxrow >> 16, smp);
                 pu[size_t(PU_KEY_LO) * n_slots] = uint32_t(ps.key);
                 pu[size_t(PU_KEY_HI) * n_slots] = uint32_t(ps.key >> 32);
                 pu[size_t(PU_PXROW) * n_slots] = pxrow;
@@ -385,7 +398,13 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
     V3<R> acc;
     PathState<R> ps;
 
+    // counting variant only: where a wave's time and lanes go (RTTNW_DEBUG_SCHED prints it) — wave clock per phase
+    // [0..3], lockstep iterations of the BVH walk [4] (with a node lane [7], with a leaf lane [8]) against the lane
+    // steps they served [5] node / [6] leaf, bounce rounds [9] and the lanes alive in them [10], regenerations [11,12]
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
+        long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        if constexpr (COUNT) tk0 = clock64();
         // ---- job hand-out: wave-aggregated, one atomic per refill event
         const bool need = !done && !alive && s >= s_end;
         const unsigned long long mask = __ballot(need);
@@ -418,17 +437,87 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
         if (__ballot(!done) == 0ull) break;
 
         // ---- one path per lane: regenerate or advance by one bounce
-        if (!done) {
-            if (!alive && s < s_end) {
+        if constexpr (!COUNT) {
+            if (!done) {
+                if (!alive && s < s_end) {
+                    path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, px, row, s);
+                    alive = true;
+                }
+                if (alive) {
+                    alive = path_step(ps, sc, rc, background, t_min, stack, cnt);
+                    if (!alive) { // main.rs:216: acc + color(...)
+                        acc = acc + ps.radiance;
+                        ++s;
+                    }
+                }
+            }
+        } else { // the same steps, with the wave clock read between the phases and the lockstep loop tallied
+            tk1 = clock64();
+            const bool begin = !done && !alive && s < s_end;
+            const unsigned long long bm = __ballot(begin);
+            if (begin) {
                 path_begin(ps, cam, rc, px, row, s);
                 alive = true;
             }
+            tk2 = clock64();
+            const unsigned long long am = __ballot(alive);
+            bool found = false;
+            R closest = R(0);
+            HitRef best;
+            best.prim = 0; best.inst = -1; best.aux = 0;
             if (alive) {
-                alive = path_step(ps, sc, rc, background, t_min, stack, cnt);
-                if (!alive) { // main.rs:216: acc + color(...)
+                cnt.ray();
+                Trav<R> tr;
+                trav_begin(tr, sc, ps.ray);
+                while (tr.node != TRAV_DONE) {
+                    const unsigned long long act = __ballot(true);
+                    const bool is_node = tr.node >= 0;
+                    const unsigned long long nm = __ballot(is_node);
+                    if (lane == uint32_t(__ffsll((long long)act) - 1)) {
+                        prof[4] += 1;
+                        prof[7] += nm != 0ull;
+                        prof[8] += (act & ~nm) != 0ull;
+                    }
+                    uint32_t kmask = 0; // kinds among the leaf lanes: bit k = record kind k, bit 5 = empty slot
+                    {
+                        const uint32_t kd = tr.node == CHILD_EMPTY ? 5u : leaf_kind(tr.node);
+#pragma unroll
+                        for (uint32_t k = 0; k < 6; ++k) kmask |= __ballot(!is_node && kd == k) != 0ull ? (1u << k) : 0u;
+                    }
+                    const long long q0 = clock64();
+                    if (is_node) { prof[5] += 1; trav_node_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    const long long q1 = clock64();
+                    if (!is_node) { prof[6] += 1; trav_leaf_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    const long long q2 = clock64();
+                    if (lane == uint32_t(__ffsll((long long)act) - 1)) {
+                        prof[13] += (unsigned long long)(q1 - q0);
+                        prof[14] += (unsigned long long)(q2 - q1);
+                        if (kmask && rc.profile >= 2u) { // leaf time by the set of record kinds the iteration served: dbg[16+set], count dbg[80+set]
+                            atomicAdd(&counters->dbg[16 + kmask], (unsigned long long)(q2 - q1));
+                            atomicAdd(&counters->dbg[80 + kmask], 1ull);
+                        }
+                    }
+                }
+                found = tr.found; closest = tr.closest; best = tr.best;
+            }
+            tk3 = clock64();
+            if (alive) {
+                alive = path_shade(ps, sc, rc, background, t_min, found, closest, best, cnt);
+                if (!alive) {
                     acc = acc + ps.radiance;
                     ++s;
                 }
+            }
+            const long long tk4 = clock64();
+            if (lane == 0) {
+                prof[0] += (unsigned long long)(tk1 - tk0);
+                prof[1] += (unsigned long long)(tk2 - tk1);
+                prof[2] += (unsigned long long)(tk3 - tk2);
+                prof[3] += (unsigned long long)(tk4 - tk3);
+                prof[9] += 1;
+                prof[10] += (unsigned long long)__popcll(am);
+                prof[11] += bm != 0ull;
+                prof[12] += (unsigned long long)__popcll(bm);
             }
         }
     }
@@ -441,6 +530,9 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
             atomicAdd(&counters->prims, (unsigned long long)p);
             atomicAdd(&counters->texels, (unsigned long long)t);
         }
+#pragma unroll
+        for (int k = 0; k < 15; ++k)
+            if (prof[k]) atomicAdd(&counters->dbg[k], prof[k]);
     }
 }
 
@@ -580,7 +672,7 @@ template <typename R> struct DeviceScene {
             mv.push_back(o);
         }
         std::vector<RectRec<R>> rc_;
-        for (auto& r : f.rects) rc_.push_back({R(r.a0), R(r.a1), R(r.b0), R(r.b1), R(r.k), r.plane, r.mat, r.seq, 0});
+        for (auto& r : f.rects) rc_.push_back({R(r.a0), R(r.a1), R(r.b0), R(r.b1), R(r.k), r.plane, r.mat, r.seq});
         std::vector<BoxRec<R>> bx;
         for (auto& b : f.boxes) {
             BoxRec<R> o{};
@@ -750,6 +842,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    rc.profile = p->collect_counters;
     const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
     if (n_jobs >= (size_t(1) << 32)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
     rc.div_jobs_per_chunk = make_fastdiv(std::max<uint32_t>(1u, rc.my_tiles * 64u));
@@ -849,7 +942,24 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             DeviceCounters hc;
             HIP_TRY(hipMemcpy(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
             stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
-            if (getenv("RTTNW_DEBUG_SCHED")) {
+            if (getenv("RTTNW_DEBUG_SCHED") && plain) {
+                const double tot = double(hc.dbg[0] + hc.dbg[1] + hc.dbg[2] + hc.dbg[3]);
+                fprintf(stderr, "[plain] wave clock: hand-out %.1f%%  begin %.1f%%  walk %.1f%%  shade %.1f%%\n", 100 * hc.dbg[0] / tot,
+                        100 * hc.dbg[1] / tot, 100 * hc.dbg[2] / tot, 100 * hc.dbg[3] / tot);
+                fprintf(stderr, "[plain] walk: %.1f lockstep iterations/round (%.1f with node lanes, %.1f with leaf lanes); lanes served per iteration %.1f of 64\n",
+                        double(hc.dbg[4]) / hc.dbg[9], double(hc.dbg[7]) / hc.dbg[9], double(hc.dbg[8]) / hc.dbg[9],
+                        double(hc.dbg[5] + hc.dbg[6]) / hc.dbg[4]);
+                fprintf(stderr, "[plain] walk clock: node steps %.1f%%, leaf steps %.1f%% of the walk\n", 100.0 * hc.dbg[13] / hc.dbg[2], 100.0 * hc.dbg[14] / hc.dbg[2]);
+                for (uint32_t m = 1; m < 64; ++m)
+                    if (hc.dbg[80 + m] * 200 > hc.dbg[8])
+                        fprintf(stderr, "[plain]   leaf iterations serving {%s%s%s%s%s%s}: %.1f%% of them, %.1f%% of the leaf clock, %.0f clocks each\n", m & 1 ? "sphere " : "",
+                                m & 2 ? "moving " : "", m & 4 ? "rect " : "", m & 8 ? "box " : "", m & 16 ? "instance " : "", m & 32 ? "empty " : "",
+                                100.0 * hc.dbg[80 + m] / hc.dbg[8], 100.0 * hc.dbg[16 + m] / hc.dbg[14], double(hc.dbg[16 + m]) / hc.dbg[80 + m]);
+                fprintf(stderr, "[plain]   node iterations: %.0f clocks each\n", double(hc.dbg[13]) / hc.dbg[7]);
+                fprintf(stderr, "[plain] node lanes per node iteration %.1f, leaf lanes per leaf iteration %.1f; rounds/sample %.2f, lanes alive per round %.1f; begin in %.0f%% of rounds, %.1f lanes each\n",
+                        double(hc.dbg[5]) / hc.dbg[7], double(hc.dbg[6]) / hc.dbg[8], double(hc.dbg[9]) * 64 / stats->samples,
+                        double(hc.dbg[10]) / hc.dbg[9], 100.0 * hc.dbg[11] / hc.dbg[9], hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
+            } else if (getenv("RTTNW_DEBUG_SCHED")) {
                 static const char* names[] = {"NODE", "SPHERE", "BOX", "MISC"};
                 const double w64 = double(stats->samples) / 64.0;
                 for (int k = 0; k < 4; ++k)

@@ -33,6 +33,25 @@ RT_HD float rt_min(float a, float b) { return fminf(a, b); }
 RT_HD double rt_min(double a, double b) { return fmin(a, b); }
 RT_HD float rt_max(float a, float b) { return fmaxf(a, b); }
 RT_HD double rt_max(double a, double b) { return fmax(a, b); }
+// 1/x and a/b.  f64: IEEE division, as the reference.  f32 on the device: v_rcp_f32 (1 ulp) and one multiply — the
+// compiler's own f32 `/` wraps the same v_rcp_f32 in 5 more instructions of range scaling for denormal divisors,
+// which a ray tracer does not need (a denormal direction component is an axis-parallel ray either way).
+RT_HD float rt_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+RT_HD double rt_rcp(double x) { return 1.0 / x; }
+RT_HD float rt_div(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return a * __builtin_amdgcn_rcpf(b);
+#else
+    return a / b;
+#endif
+}
+RT_HD double rt_div(double a, double b) { return a / b; }
 
 template <typename R> struct Lim;
 template <> struct Lim<float> {
@@ -57,7 +76,10 @@ template <typename R> RT_HD V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.
 template <typename R> RT_HD V3<R> operator*(V3<R> a, V3<R> b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 template <typename R> RT_HD V3<R> operator*(V3<R> a, R k) { return {a.x * k, a.y * k, a.z * k}; }
 template <typename R> RT_HD V3<R> operator*(R k, V3<R> a) { return {a.x * k, a.y * k, a.z * k}; }
-template <typename R> RT_HD V3<R> operator/(V3<R> a, R k) { return {a.x / k, a.y / k, a.z / k}; }
+template <typename R> RT_HD V3<R> operator/(V3<R> a, R k) {
+    if constexpr (sizeof(R) == 4) { const R inv = rt_rcp(k); return {a.x * inv, a.y * inv, a.z * inv}; }
+    else return {a.x / k, a.y / k, a.z / k};
+}
 template <typename R> RT_HD V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
 template <typename R> RT_HD R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // vec3.rs:77
 template <typename R> RT_HD R squared_length(V3<R> a) { return a.x * a.x + a.y * a.y + a.z * a.z; } // vec3.rs:93
@@ -174,7 +196,7 @@ template <typename R> struct SlabRay { // what a ray contributes to every slab t
 };
 template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     SlabRay<R> sr;
-    sr.inv = V3<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+    sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     return sr;
 }
 template <typename R>
@@ -202,7 +224,7 @@ RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, const SlabRay<R>&
 // instantiation uses the algebraically identical, cancellation-free form  a*(r^2 - |oc - (hb/a) d|^2).
 template <typename R> RT_HD R sphere_discriminant(V3<R> oc, V3<R> d, R a, R half_b, R radius) {
     if constexpr (sizeof(R) == 4) {
-        V3<R> l = oc - (half_b / a) * d; // from the centre to the closest point of the ray's line
+        V3<R> l = oc - rt_div(half_b, a) * d; // from the centre to the closest point of the ray's line
         return a * (radius * radius - dot(l, l));
     } else {
         R c = dot(oc, oc) - radius * radius;
@@ -217,9 +239,9 @@ RT_HD bool sphere_t(V3<R> center, R radius, const Ray<R>& ray, R t_min, R t_max,
     R disc = sphere_discriminant(oc, ray.d, a, half_b, radius);
     if (disc < R(0)) return false;
     R sqrtd = rt_sqrt(disc);
-    R root = (-half_b - sqrtd) / a;
+    R root = rt_div(-half_b - sqrtd, a);
     if (root < t_min || t_max < root) {
-        root = (-half_b + sqrtd) / a;
+        root = rt_div(-half_b + sqrtd, a);
         if (root < t_min || t_max < root) return false;
     }
     t_out = root;
@@ -240,34 +262,38 @@ RT_HD bool rect_t(int plane, R a0, R a1, R b0, R b1, R k, const Ray<R>& ray, R t
     const R dk = plane == 0 ? dz : (plane == 1 ? dy : dx);
     const R oa = plane == 2 ? oy : ox, da = plane == 2 ? dy : dx;
     const R ob = plane == 0 ? oy : oz, db = plane == 0 ? dy : dz;
-    R t = (k - ok) / dk;
-    if (t < t_min || t > t_max) return false;
-    R a = oa + t * da;
-    R b = ob + t * db;
-    if (!(a0 <= a && a < a1) || !(b0 <= b && b < b1)) return false;
-    t_out = t; a_out = a; b_out = b;
-    return true;
+    // straight-line: `t < t_min || t > t_max` and the half-open extents as one predicate (a NaN t passes the range
+    // test and fails the extents, as in the reference)
+    const R t = rt_div(k - ok, dk);
+    const R a = oa + t * da;
+    const R b = ob + t * db;
+    const bool hit = !(t < t_min) & !(t > t_max) & (a0 <= a) & (a < a1) & (b0 <= b) & (b < b1);
+    if (hit) { t_out = t; a_out = a; b_out = b; }
+    return hit;
 }
 // Cube::hit = List::hit over its six rectangles in the order xy@min.z, xy@max.z, xz@min.y, xz@max.y,
 // yz@min.x, yz@max.x with a shrinking `closest` (hittable.rs:560-569,153-163).  Returns the winning
 // face index in `face` (later face wins exact ties, like the List).
 template <typename R>
-RT_HD bool box_t(const BoxRec<R>& bx, const Ray<R>& ray, R t_min, R t_max, R& t_out, int& face, R& a_out, R& b_out) {
+RT_HD bool box_t(const BoxRec<R>& bx, const Ray<R>& ray, R t_min, R t_max, R& t_out, int& face) {
     bool any = false;
     R closest = t_max;
+    int fc = 0;
+    const R o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
-        const int plane = f >> 1; // 0 XY, 1 XZ, 2 YZ
-        R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
-        R b0 = plane == 0 ? bx.mn[1] : bx.mn[2], b1 = plane == 0 ? bx.mx[1] : bx.mx[2];
-        const int kaxis = plane == 0 ? 2 : (plane == 1 ? 1 : 0);
-        R k = (f & 1) ? bx.mx[kaxis] : bx.mn[kaxis];
-        R t, a, b;
-        if (rect_t(plane, a0, a1, b0, b1, k, ray, t_min, closest, t, a, b)) {
-            closest = t; face = f; a_out = a; b_out = b; any = true;
-        }
+        const int plane = f >> 1;                            // 0 XY, 1 XZ, 2 YZ
+        const int ia = plane == 2 ? 1 : 0, ib = plane == 0 ? 1 : 2, ik = plane == 0 ? 2 : (plane == 1 ? 1 : 0);
+        const R k = (f & 1) ? bx.mx[ik] : bx.mn[ik];
+        const R t = rt_div(k - o[ik], d[ik]);                // Rectangle::hit, hittable.rs:503-513
+        const R a = o[ia] + t * d[ia], b = o[ib] + t * d[ib];
+        const bool hit = !(t < t_min) & !(t > closest) & (bx.mn[ia] <= a) & (a < bx.mx[ia]) & (bx.mn[ib] <= b) & (b < bx.mx[ib]);
+        closest = hit ? t : closest;
+        fc = hit ? f : fc;
+        any |= hit;
     }
     t_out = closest;
+    if (any) face = fc;
     return any;
 }
 
@@ -305,14 +331,14 @@ RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray
         SphereRec<R> s = sc.spheres[idx];
         return sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, ray, t_min, t_max, t);
     } else if (kind == PRIM_BOX) {
-        R a, b;
-        return box_t(sc.boxes[idx], ray, t_min, t_max, t, aux, a, b);
+        const BoxRec<R> bx = sc.boxes[idx];
+        return box_t(bx, ray, t_min, t_max, t, aux);
     } else if (kind == PRIM_RECT) {
-        const RectRec<R>& r = sc.rects[idx];
+        const RectRec<R> r = sc.rects[idx];
         R a, b;
         return rect_t(r.plane, r.a0, r.a1, r.b0, r.b1, r.k, ray, t_min, t_max, t, a, b);
     } else if (kind == PRIM_MOVING_SPHERE) {
-        const MovingSphereRec<R>& m = sc.moving[idx];
+        const MovingSphereRec<R> m = sc.moving[idx];
         return sphere_t(moving_center(m, ray.time), m.r, ray, t_min, t_max, t);
     }
     return false;
@@ -415,7 +441,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     const uint32_t kind = leaf_kind(tr.node), count = leaf_count(tr.node), first = leaf_first(tr.node);
     cnt.prim();
     if (kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
-        const InstanceRec<R>& in = sc.insts[first];
+        const InstanceRec<R> in = sc.insts[first];
         stack.set(tr.sp++, STACK_SENTINEL);
         tr.ray = to_object(in, wray);
         tr.sr = slab_ray(tr.ray.o, tr.ray.d);
@@ -478,7 +504,8 @@ template <typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim), idx = ref_index(ref.prim);
     Ray<R> ray = wray;
-    if (ref.inst >= 0) ray = to_object(sc.insts[ref.inst], wray);
+    InstanceRec<R> in{};
+    if (ref.inst >= 0) { in = sc.insts[ref.inst]; ray = to_object(in, wray); }
     rec.t = t;
     V3<R> outward;
     if (kind == PRIM_SPHERE) { // hittable.rs:109-113
@@ -493,13 +520,13 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         rec.u = R(0); rec.v = R(0);
         if (tex >= 0 && (sc.texs[tex].type == TEX_IMAGE || sc.texs[tex].type == TEX_CHECKER)) sphere_uv(outward, rec.u, rec.v);
     } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
-        const MovingSphereRec<R>& m = sc.moving[idx];
+        const MovingSphereRec<R> m = sc.moving[idx];
         rec.p = ray.at(t);
         outward = (rec.p - moving_center(m, ray.time)) / m.r;
         rec.u = R(0); rec.v = R(0);
         rec.mat = m.mat;
     } else if (kind == PRIM_RECT) { // hittable.rs:515-519
-        const RectRec<R>& r = sc.rects[idx];
+        const RectRec<R> r = sc.rects[idx];
         R a, b;
         rect_ab(r.plane, ray, t, a, b);
         rec.u = (a - r.a0) / (r.a1 - r.a0);
@@ -508,7 +535,7 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         rec.p = ray.at(t);
         rec.mat = r.mat;
     } else { // PRIM_BOX: the winning face's rectangle record
-        const BoxRec<R>& bx = sc.boxes[idx];
+        const BoxRec<R> bx = sc.boxes[idx];
         const int plane = ref.aux >> 1;
         R a, b;
         rect_ab(plane, ray, t, a, b);
@@ -525,7 +552,6 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
     if (ref.inst >= 0) {
         // Unwind the wrappers innermost-first.  Level i's face_normal uses the ray as it was AFTER
         // ops[0..i] were applied (Translate: `moved_ray` :607; YRotate: the rotated `ray` :706).
-        const InstanceRec<R>& in = sc.insts[ref.inst];
         V3<R> dirs[MAX_INSTANCE_OPS];
         {
             Ray<R> r = wray;
@@ -582,8 +608,9 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
                             bool found, R closest, HitRef best, HitRecord<R>& rec, Cnt& cnt) {
     int32_t medium = -1;
     for (int32_t m = 0; m < sc.n_media; ++m) {
-        const MediumRec<R>& md = sc.media[m];
-        Ray<R> bray = md.inst >= 0 ? to_object(sc.insts[md.inst], ray) : ray;
+        const MediumRec<R> md = sc.media[m];
+        Ray<R> bray = ray;
+        if (md.inst >= 0) { const InstanceRec<R> in = sc.insts[md.inst]; bray = to_object(in, ray); }
         const uint32_t bk = ref_kind(md.boundary), bi = ref_index(md.boundary);
         R t1, t2;
         cnt.prim(); // first boundary query; the second is counted once the first has hit, as the reference would call it
@@ -597,7 +624,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
             const R disc = sphere_discriminant(oc, bray.d, a, half_b, sp.r);
             if (disc < R(0)) continue;
             const R sqrtd = rt_sqrt(disc);
-            const R near_root = (-half_b - sqrtd) / a, far_root = (-half_b + sqrtd) / a;
+            const R near_root = rt_div(-half_b - sqrtd, a), far_root = rt_div(-half_b + sqrtd, a);
             t1 = near_root;
             if (t1 < -Lim<R>::inf() || Lim<R>::inf() < t1) {
                 t1 = far_root;

@@ -59,14 +59,16 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 // ties are resolved by the larger seq.
 template <typename R> struct alignas(sizeof(R) * 4) SphereRec { R cx, cy, cz, r; };
 template <typename R> struct MovingSphereRec { R c0[3], r, c1[3], t0, t1; int32_t mat; int32_t seq; };
-template <typename R> struct RectRec { R a0, a1, b0, b1, k; int32_t plane; int32_t mat; int32_t seq; int32_t pad; };
-template <typename R> struct BoxRec { R mn[3], mx[3]; int32_t mat; int32_t seq; };
+// Records are aligned so that ONE by-value copy at the top of a test is a couple of 16-byte loads issued together
+// (field-by-field reads through a reference end up as dependent loads inside the test's branches).
+template <typename R> struct alignas(sizeof(R) * 4) RectRec { R a0, a1, b0, b1, k; int32_t plane; int32_t mat; int32_t seq; };
+template <typename R> struct alignas(sizeof(R) * 4) BoxRec { R mn[3], mx[3]; int32_t mat; int32_t seq; };
 
 enum : int32_t { OP_TRANSLATE = 0, OP_ROTATE_Y = 1 };
 constexpr int MAX_INSTANCE_OPS = 3;
 // ops[0] is the OUTERMOST wrapper (applied to the ray first): `x.rotate_y(a).translate(v)`
 // = Translate(YRotate(x)) lowers to ops = { translate v, rotate a }.
-template <typename R> struct InstanceRec {
+template <typename R> struct alignas(16) InstanceRec {
     int32_t n_ops;
     int32_t root; // sub-BVH root node
     struct Op { int32_t type; int32_t pad; R v[3]; } ops[MAX_INSTANCE_OPS]; // translate: offset; rotate: {sin, cos, -}
@@ -153,13 +155,14 @@ struct RenderConsts {
     uint32_t quirks;
     uint32_t stack_depth;
     FastDiv div_jobs_per_chunk, div_tiles_x; // job index -> (chunk, tile, pixel) without integer division
+    uint32_t profile;   // counting variant: 2 = also bucket the leaf clock by record kinds (atomics: perturbs the other clocks)
     uint32_t lds_nodes; // lane-owns-path kernel: number of BVH nodes resident in LDS (0 = nodes read from global memory)
     uint64_t seed;
 };
 
 struct DeviceCounters {
     unsigned long long rays, nodes, prims, texels;
-    unsigned long long dbg[16]; // scheduler statistics of the counting variant: [k] stage execs, [4+k] lanes served, [8] bursts, [9] shades, [10] shade lanes, [11] refills, [12] refill lanes
+    unsigned long long dbg[160]; // statistics of the counting variants (RTTNW_DEBUG_SCHED prints them; meaning per kernel in render.hip)
 };
 
 } // namespace rt

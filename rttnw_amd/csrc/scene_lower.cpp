@@ -166,7 +166,7 @@ struct Lowering {
             return uint32_t(fs.moving.size() - 1);
         }
         case PRIM_RECT: {
-            RectRec<double> r{o.v[0], o.v[1], o.v[2], o.v[3], o.v[4], o.c, mat_index[o.a], it.seq, 0};
+            RectRec<double> r{o.v[0], o.v[1], o.v[2], o.v[3], o.v[4], o.c, mat_index[o.a], it.seq};
             fs.rects.push_back(r);
             return uint32_t(fs.rects.size() - 1);
         }

@@ -45,7 +45,7 @@ template <typename R> struct HostScene {
             o.r = R(m.r); o.t0 = R(m.t0); o.t1 = R(m.t1); o.mat = m.mat; o.seq = m.seq;
             moving.push_back(o);
         }
-        for (auto& r : f.rects) rects.push_back({R(r.a0), R(r.a1), R(r.b0), R(r.b1), R(r.k), r.plane, r.mat, r.seq, 0});
+        for (auto& r : f.rects) rects.push_back({R(r.a0), R(r.a1), R(r.b0), R(r.b1), R(r.k), r.plane, r.mat, r.seq});
         for (auto& b : f.boxes) {
             BoxRec<R> o{};
             for (int k = 0; k < 3; ++k) { o.mn[k] = R(b.mn[k]); o.mx[k] = R(b.mx[k]); }

@@ -138,6 +138,15 @@ template <typename T> __device__ __forceinline__ T kernarg_reload(uint32_t offse
 }
 template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; }; // layout of the first three kernel arguments
 
+// The decoupled kernel calls the shade half of a bounce as a real function: its code (media, hit record, textures,
+// scatter) is by far the largest part of the kernel but runs once per 64 hits; out of line it neither competes for
+// the traversal loop's scalar registers (the kernel sits at the 102-SGPR limit) nor bloats the loop's code.
+template <typename R, typename Cnt>
+__device__ __attribute__((noinline)) bool path_shade_call(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min,
+                                                          bool found, R closest, HitRef best, Cnt& cnt) {
+    return path_shade(ps, sc, rc, background, t_min, found, closest, best, cnt);
+}
+
 template <typename R, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                 best.inst = hq_inst[e];
                 best.aux = int32_t((meta >> 8) & 7u);
                 const bool found = ref_kind(best.prim) != PRIM_NONE;
-                if (path_shade(ps, sc, rc, background, t_min, found, hq_t[e], best, cnt)) {
+                if (path_shade_call(ps, sc, rc, background, t_min, found, hq_t[e], best, cnt)) {
                     emit = true; // next world.hit of the same path
                 } else {         // main.rs:216: acc + color(...)
                     pxrow = pu[size_t(PU_PXROW) * n_slots];

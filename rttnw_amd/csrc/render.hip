@@ -510,8 +510,21 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                 found = tr.found; closest = tr.closest; best = tr.best;
             }
             tk3 = clock64();
-            if (alive) {
-                alive = path_shade(ps, sc, rc, background, t_min, found, closest, best, cnt);
+            long long tk3b = tk3;
+            if (alive) { // path_shade(), with the wave clock read between its two halves
+                HitRecord<R> rec;
+                const bool hit = world_hit_finish(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, found, closest, best, rec, cnt);
+                tk3b = clock64();
+                if (!hit) {
+                    ps.radiance = ps.radiance + ps.throughput * background;
+                    alive = false;
+                } else {
+                    V3<R> att, emitted;
+                    const bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, emitted, cnt);
+                    ps.radiance = ps.radiance + ps.throughput * emitted;
+                    if (cont) { ps.throughput = ps.throughput * att; ps.bounce += 1; }
+                    alive = cont && ps.bounce < rc.max_depth;
+                }
                 if (!alive) {
                     acc = acc + ps.radiance;
                     ++s;
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                 prof[1] += (unsigned long long)(tk2 - tk1);
                 prof[2] += (unsigned long long)(tk3 - tk2);
                 prof[3] += (unsigned long long)(tk4 - tk3);
+                prof[15] += (unsigned long long)(tk3b - tk3);
                 prof[9] += 1;
                 prof[10] += (unsigned long long)__popcll(am);
                 prof[11] += bm != 0ull;
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
             atomicAdd(&counters->texels, (unsigned long long)t);
         }
 #pragma unroll
-        for (int k = 0; k < 15; ++k)
+        for (int k = 0; k < 16; ++k)
             if (prof[k]) atomicAdd(&counters->dbg[k], prof[k]);
     }
 }
@@ -953,8 +967,8 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
             if (getenv("RTTNW_DEBUG_SCHED") && plain) {
                 const double tot = double(hc.dbg[0] + hc.dbg[1] + hc.dbg[2] + hc.dbg[3]);
-                fprintf(stderr, "[plain] wave clock: hand-out %.1f%%  begin %.1f%%  walk %.1f%%  shade %.1f%%\n", 100 * hc.dbg[0] / tot,
-                        100 * hc.dbg[1] / tot, 100 * hc.dbg[2] / tot, 100 * hc.dbg[3] / tot);
+                fprintf(stderr, "[plain] wave clock: hand-out %.1f%%  begin %.1f%%  walk %.1f%%  shade %.1f%% (media + hit record %.1f%%, material %.1f%%)\n", 100 * hc.dbg[0] / tot,
+                        100 * hc.dbg[1] / tot, 100 * hc.dbg[2] / tot, 100 * hc.dbg[3] / tot, 100 * hc.dbg[15] / tot, 100 * (hc.dbg[3] - hc.dbg[15]) / tot);
                 fprintf(stderr, "[plain] walk: %.1f lockstep iterations/round (%.1f with node lanes, %.1f with leaf lanes); lanes served per iteration %.1f of 64\n",
                         double(hc.dbg[4]) / hc.dbg[9], double(hc.dbg[7]) / hc.dbg[9], double(hc.dbg[8]) / hc.dbg[9],
                         double(hc.dbg[5] + hc.dbg[6]) / hc.dbg[4]);

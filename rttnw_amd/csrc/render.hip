@@ -138,15 +138,6 @@ template <typename T> __device__ __forceinline__ T kernarg_reload(uint32_t offse
 }
 template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; }; // layout of the first three kernel arguments
 
-// The decoupled kernel calls the shade half of a bounce as a real function: its code (media, hit record, textures,
-// scatter) is by far the largest part of the kernel but runs once per 64 hits; out of line it neither competes for
-// the traversal loop's scalar registers (the kernel sits at the 102-SGPR limit) nor bloats the loop's code.
-template <typename R, typename Cnt>
-__device__ __attribute__((noinline)) bool path_shade_call(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min,
-                                                          bool found, R closest, HitRef best, Cnt& cnt) {
-    return path_shade(ps, sc, rc, background, t_min, found, closest, best, cnt);
-}
-
 template <typename R, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
@@ -223,7 +214,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                 best.inst = hq_inst[e];
                 best.aux = int32_t((meta >> 8) & 7u);
                 const bool found = ref_kind(best.prim) != PRIM_NONE;
-                if (path_shade_call(ps, sc, rc, background, t_min, found, hq_t[e], best, cnt)) {
+                if (path_shade(ps, sc, rc, background, t_min, found, hq_t[e], best, cnt)) {
                     emit = true; // next world.hit of the same path
                 } else {         // main.rs:216: acc + color(...)
                     pxrow = pu[size_t(PU_PXROW) * n_slots];
@@ -479,30 +470,32 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                 Trav<R> tr;
                 trav_begin(tr, sc, ps.ray);
                 while (tr.node != TRAV_DONE) {
+                    // the loop body of closest_solid() (node step, then leaf step for the lanes at a leaf by then), tallied
                     const unsigned long long act = __ballot(true);
                     const bool is_node = tr.node >= 0;
                     const unsigned long long nm = __ballot(is_node);
-                    if (lane == uint32_t(__ffsll((long long)act) - 1)) {
-                        prof[4] += 1;
-                        prof[7] += nm != 0ull;
-                        prof[8] += (act & ~nm) != 0ull;
-                    }
+                    const long long q0 = clock64();
+                    if (is_node) { prof[5] += 1; trav_node_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    const long long q1 = clock64();
+                    const bool is_leaf = tr.node < 0 && tr.node != TRAV_DONE;
+                    const unsigned long long lm = __ballot(is_leaf);
                     uint32_t kmask = 0; // kinds among the leaf lanes: bit k = record kind k, bit 5 = empty slot
                     {
                         const uint32_t kd = tr.node == CHILD_EMPTY ? 5u : leaf_kind(tr.node);
 #pragma unroll
-                        for (uint32_t k = 0; k < 6; ++k) kmask |= __ballot(!is_node && kd == k) != 0ull ? (1u << k) : 0u;
+                        for (uint32_t k = 0; k < 6; ++k) kmask |= __ballot(is_leaf && kd == k) != 0ull ? (1u << k) : 0u;
                     }
-                    const long long q0 = clock64();
-                    if (is_node) { prof[5] += 1; trav_node_step(tr, sc, ps.ray, t_min, stack, cnt); }
-                    const long long q1 = clock64();
-                    if (!is_node) { prof[6] += 1; trav_leaf_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    const long long q1b = clock64();
+                    if (is_leaf) { prof[6] += 1; trav_leaf_step(tr, sc, ps.ray, t_min, stack, cnt); }
                     const long long q2 = clock64();
                     if (lane == uint32_t(__ffsll((long long)act) - 1)) {
+                        prof[4] += 1;
+                        prof[7] += nm != 0ull;
+                        prof[8] += lm != 0ull;
                         prof[13] += (unsigned long long)(q1 - q0);
-                        prof[14] += (unsigned long long)(q2 - q1);
+                        prof[14] += (unsigned long long)(q2 - q1b);
                         if (kmask && rc.profile >= 2u) { // leaf time by the set of record kinds the iteration served: dbg[16+set], count dbg[80+set]
-                            atomicAdd(&counters->dbg[16 + kmask], (unsigned long long)(q2 - q1));
+                            atomicAdd(&counters->dbg[16 + kmask], (unsigned long long)(q2 - q1b));
                             atomicAdd(&counters->dbg[80 + kmask], 1ull);
                         }
                     }

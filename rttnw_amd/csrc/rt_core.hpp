@@ -485,8 +485,10 @@ RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R&
     Trav<R> tr;
     trav_begin(tr, sc, wray);
     while (tr.node != TRAV_DONE) {
+        // node step, then leaf step: a lane whose node step arrives at a leaf tests it in the same trip round the loop,
+        // together with the lanes that were already waiting at theirs
         if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
-        else trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
+        if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
     }
     closest = tr.closest;
     best = tr.best;

@@ -892,13 +892,15 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
         return 0;
     };
     if (plain) {
-        // Small scenes: node array in LDS, 1024-thread blocks (one per CU) so that nodes + 1024 stacks fit in 160 KB
+        // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
+        // 1024 threads (4 waves/SIMD at <= 128 VGPRs) for f32, 512 threads (2 waves/SIMD, all the 256-VGPR f64 code allows)
+        constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : 512;
         const size_t node_bytes = s->flat.nodes.size() * sizeof(BvhNode);
-        const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && sizeof(R) == 4 &&
-                              node_bytes + size_t(rc.stack_depth) * 1024 * 4 <= 160 * 1024;
+        const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) &&
+                              node_bytes + size_t(rc.stack_depth) * LDS_BLOCK * 4 <= 160 * 1024;
         rc.lds_nodes = want_lds ? uint32_t(s->flat.nodes.size()) : 0u;
-        const int block = want_lds ? 1024 : TRACE_BLOCK;
-        const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, 1024, true> : (const void*)trace_kernel_plain<R, false, 1024, true>)
+        const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
+        const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true>)
                                       : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false>);
         const size_t lds_bytes = (want_lds ? node_bytes : 0) + size_t(rc.stack_depth) * block * sizeof(int32_t);
         if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }

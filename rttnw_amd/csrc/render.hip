@@ -214,7 +214,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                 best.inst = hq_inst[e];
                 best.aux = int32_t((meta >> 8) & 7u);
                 const bool found = ref_kind(best.prim) != PRIM_NONE;
-                if (path_shade(ps, sc, rc, background, t_min, found, hq_t[e], best, cnt)) {
+                // (scene view and constants re-read from the kernarg segment: the traversal loop keeps only the pointers it uses)
+                if (path_shade(ps, kernarg_reload<SceneView<R>>(offsetof(TraceArgsHead<R>, sc)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), background, t_min,
+                               found, hq_t[e], best, cnt)) {
                     emit = true; // next world.hit of the same path
                 } else {         // main.rs:216: acc + color(...)
                     pxrow = pu[size_t(PU_PXROW) * n_slots];
@@ -245,19 +247,20 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                         slot_done = true; // no jobs left: this slot retires
                     } else {
                         uint32_t chunk, rem, tx, ty;
-                        job_split(job, rc.div_jobs_per_chunk, chunk, rem);
-                        tile_unpermute(rc.tile_rank + (rem >> 6) * rc.tile_world, rc.div_tiles_x, tx, ty);
+                        const RenderConsts rj = kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)); // cold: keep it out of the SGPRs
+                        job_split(job, rj.div_jobs_per_chunk, chunk, rem);
+                        tile_unpermute(rj.tile_rank + (rem >> 6) * rj.tile_world, rj.div_tiles_x, tx, ty);
                         const uint32_t px = tx * 8u + (rem & 7u), row = ty * 8u + ((rem & 63u) >> 3);
                         pxrow = px | (row << 16);
-                        smp = chunk * rc.spp_chunk;
-                        smp_end = smp + rc.spp_chunk < rc.spp ? smp + rc.spp_chunk : rc.spp;
-                        if (px >= rc.width || row >= rc.height) smp = smp_end; // outside the image: an empty job
+                        smp = chunk * rj.spp_chunk;
+                        smp_end = smp + rj.spp_chunk < rj.spp ? smp + rj.spp_chunk : rj.spp;
+                        if (px >= rj.width || row >= rj.height) smp = smp_end; // outside the image: an empty job
                         acc = V3<R>();
                     }
                 }
             }
             if (need_sample && !slot_done) { // main.rs:212-215: the job's next sample
-                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, pxrow & 0xFFFFu, pxrow >> 16, smp);
+                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), pxrow & 0xFFFFu, pxrow >> 16, smp);
                 pu[size_t(PU_KEY_LO) * n_slots] = uint32_t(ps.key);
                 pu[size_t(PU_KEY_HI) * n_slots] = uint32_t(ps.key >> 32);
                 pu[size_t(PU_PXROW) * n_slots] = pxrow;

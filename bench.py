@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--counter-spp", type=int, default=8)
     ap.add_argument("--no-f64", action="store_true", help="skip the one-step F64 cross-check line")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder at commit: host binned SAH (default) or device LBVH")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,8 +85,9 @@ def main():
     earth = S.load_earth()
 
     t0 = time.time()
-    sc, setup = util.build(gpu, scenes, scene_name, earth, param)
+    sc, setup = util.build(gpu, scenes, scene_name, earth, param, bvh=abi.BVH_DEVICE_LBVH if args.bvh == "lbvh" else None)
     build_s = time.time() - t0
+    binfo = sc.build_info()
     cam, p = util.params_for(setup, W, H, spp, precision=precision, tile_rank=rank, tile_world=world, seed=1)
     info = abi.Stats()
     gpu.scene_info(sc.handle, info)
@@ -189,7 +191,8 @@ def main():
                        "max_depth": 50, "scene_seed": "0x5eed0001", "render_seed": 1, "quirks": "reference",
                        "partition": "8x8 tiles interleaved over %d rank(s), RCCL gather to rank 0" % world,
                        "scene_nodes": info.n_nodes, "scene_prims": info.n_prims, "scene_bytes_f32": info.scene_bytes,
-                       "scene_build_s": round(build_s, 3)},
+                       "scene_build_s": round(build_s, 3), "bvh_builder": args.bvh, "bvh_lower_ms": round(binfo.lower_ms, 2),
+                       "bvh_device_ms": round(binfo.device_ms, 3), "stack_depth": binfo.stack_depth},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if st.reserved == 0 else "", "float" if precision == abi.F32 else "double"),

@@ -116,6 +116,16 @@ rttnw_id rttnw_constant_medium(rttnw_scene* s, rttnw_id boundary, double density
 
 /* The `world: List` handed to `color()` — main.rs:47-55,216. */
 int rttnw_scene_set_world(rttnw_scene* s, rttnw_id world_list);
+/* Which builder `rttnw_scene_commit` uses for the flat BVHs (before commit; default RTTNW_BVH_HOST_SAH).  Replaces the
+ * reference's BvhTree::from / build (hittable.rs:300-353: recursive, random axis per level, full sort per level).
+ *   RTTNW_BVH_HOST_SAH     binned surface-area-heuristic build on the host: best traversal, seconds for 10^6 leaves
+ *   RTTNW_BVH_DEVICE_LBVH  linear BVH built by HIP kernels (Morton order, Karras hierarchy, bottom-up fit):
+ *                          milliseconds for 10^6 leaves, slower traversal; needs a device at commit (no CPU fallback)
+ * Images do not depend on the choice: the closest hit is topology independent and exact ties are resolved by
+ * list order (tests/test_gpu_lbvh.py). */
+#define RTTNW_BVH_HOST_SAH 0u
+#define RTTNW_BVH_DEVICE_LBVH 1u
+int rttnw_scene_set_bvh_builder(rttnw_scene* s, uint32_t builder);
 /* Flatten the graph, build the flat BVHs, upload to the current HIP device.  Idempotent. */
 int rttnw_scene_commit(rttnw_scene* s);
 
@@ -207,6 +217,21 @@ const char* rttnw_last_error(void);
 
 /* Debug/inspection: sizes of the lowered scene (valid after commit). */
 int rttnw_scene_info(rttnw_scene* s, rttnw_stats* out);
+
+/* What rttnw_scene_commit's build cost (valid after commit). */
+typedef struct rttnw_build_info {
+    uint32_t builder;     /* RTTNW_BVH_* */
+    uint32_t n_nodes;     /* 64-byte node records, all trees */
+    uint32_t n_prims;     /* leaves of all trees */
+    uint32_t stack_depth; /* traversal stack entries a lane needs */
+    double lower_ms;      /* host wall time of the lowering, BVH builds included */
+    double device_ms;     /* device time of the build kernels + sort (device builder only) */
+} rttnw_build_info;
+int rttnw_scene_build_info(const rttnw_scene* s, rttnw_build_info* out);
+
+/* Debug/inspection: copy up to max_nodes 64-byte node records (rt_types.hpp BvhNode: lo0[3] hi0[3] lo1[3] hi1[3]
+ * child0 child1 pad pad; child >= 0 inner node, < 0 leaf bits) and the top-level root; returns the node count. */
+int rttnw_debug_scene_nodes(const rttnw_scene* s, void* out_nodes, uint32_t max_nodes, int32_t* top_root);
 
 /* Debug/inspection: walk sample `sample` of pixel (px, row; row 0 = top) on the device with the kernels of
  * `p->precision` and dump every world.hit() of its path, 20 doubles per bounce:

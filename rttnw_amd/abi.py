@@ -11,6 +11,7 @@ ERR_NAMES = {-1: "RTTNW_ERR_INVALID", -2: "RTTNW_ERR_STATE", -3: "RTTNW_ERR_UNSU
 
 XY, XZ, YZ = 0, 1, 2
 F64, F32 = 0, 1
+BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
 QUIRK_YROTATE_BACKROT = 1
 QUIRKS_REFERENCE = QUIRK_YROTATE_BACKROT
 
@@ -32,6 +33,11 @@ class Params(C.Structure):
                 ("t_min", C.c_double), ("background", c_double3), ("seed", C.c_uint64),
                 ("precision", C.c_uint32), ("quirks", C.c_uint32), ("spp_chunk", C.c_uint32),
                 ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("collect_counters", C.c_uint32)]
+
+
+class BuildInfo(C.Structure):
+    _fields_ = [("builder", C.c_uint32), ("n_nodes", C.c_uint32), ("n_prims", C.c_uint32), ("stack_depth", C.c_uint32),
+                ("lower_ms", C.c_double), ("device_ms", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -95,6 +101,9 @@ PRODUCT_FUNCS = [
     ("abi_version", C.c_int, []),
     ("device_count", C.c_int, []),
     ("scene_info", C.c_int, [scene_p, C.POINTER(Stats)]),
+    ("scene_set_bvh_builder", C.c_int, [scene_p, C.c_uint32]),
+    ("scene_build_info", C.c_int, [scene_p, C.POINTER(BuildInfo)]),
+    ("debug_scene_nodes", C.c_int, [scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
     ("builder", C.c_void_p, []),
     ("debug_probe_path", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint32,
                                    C.c_uint32, C.c_void_p, C.c_uint32]),

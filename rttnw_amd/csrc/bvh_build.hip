@@ -1,0 +1,254 @@
+// bvh_build.hip — linear BVH on the device: Morton keys -> radix sort -> Karras hierarchy -> bottom-up fit.
+//
+//   1. morton_kernel   63-bit Morton key of every leaf's centroid (21 bits per axis over the centroid bounds)
+//   2. rocprim::radix_sort_pairs (key, leaf index)
+//   3. hierarchy_kernel  one thread per inner node i in [0, n-2]: the range of sorted leaves it covers and its
+//                      split, from common-prefix lengths (Karras, "Maximizing Parallelism in the Construction of
+//                      BVHs, Octrees, and k-d Trees", HPG 2012); equal keys fall back to the index bits, so the
+//                      hierarchy is well defined with duplicate centroids
+//   4. fit_kernel      one thread per leaf walks towards the root; the second thread to arrive at a node (atomic
+//                      counter) fills in BOTH children's boxes + child slots of the 64-byte node record
+//                      (rt_types.hpp BvhNode) and the node's own box / height for its parent
+//   5. preorder_kernel + relayout_kernel  nodes re-numbered depth-first (root = 0, a node next to its first child)
+// HBM-bound integer/byte work: coalesced SoA arrays, no LDS needed.  The hierarchy has exactly n-1 inner nodes;
+// the root is node 0 before and after the re-numbering.
+#include "bvh_build.hpp"
+
+#include <hip/hip_runtime.h>
+#include <string.h> // rocprim/iterator/texture_cache_iterator.hpp calls memset unqualified
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+namespace rt {
+namespace {
+
+#define LBVH_TRY(expr)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) { err = std::string("lbvh_build: ") + hipGetErrorString(e_); rc = -4; goto done; } \
+    } while (0)
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) { // bit i of v -> bit 3i
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void morton_kernel(const BuildPrim* __restrict__ prims, uint32_t n, float cx, float cy, float cz, float sx, float sy,
+                              float sz, uint64_t* __restrict__ keys, uint32_t* __restrict__ order) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BuildPrim p = prims[i];
+    const float qx = (0.5f * (p.lo[0] + p.hi[0]) - cx) * sx, qy = (0.5f * (p.lo[1] + p.hi[1]) - cy) * sy,
+                qz = (0.5f * (p.lo[2] + p.hi[2]) - cz) * sz;
+    const float top = 2097151.f; // 2^21 - 1
+    const uint32_t ux = uint32_t(fminf(fmaxf(qx, 0.f), top)), uy = uint32_t(fminf(fmaxf(qy, 0.f), top)),
+                   uz = uint32_t(fminf(fmaxf(qz, 0.f), top));
+    keys[i] = (spread21(ux) << 2) | (spread21(uy) << 1) | spread21(uz);
+    order[i] = i;
+}
+
+// Length of the common prefix of sorted leaves i and j (-1 outside the array); equal keys continue with the index.
+__device__ __forceinline__ int common_prefix(const uint64_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz(int(uint32_t(i) ^ uint32_t(j)));
+}
+
+// child slot of the hierarchy before the fit: >= 0 inner node, < 0: ~(sorted leaf position)
+__global__ void hierarchy_kernel(const uint64_t* __restrict__ keys, int n, int2* __restrict__ children, int* __restrict__ node_parent,
+                                 int* __restrict__ leaf_parent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = common_prefix(keys, n, i, i - d);
+    int lmax = 2;
+    while (common_prefix(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (common_prefix(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = common_prefix(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (common_prefix(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    int2 c;
+    if (lo == gamma) { c.x = ~gamma; leaf_parent[gamma] = i; } else { c.x = gamma; node_parent[gamma] = i; }
+    if (hi == gamma + 1) { c.y = ~(gamma + 1); leaf_parent[gamma + 1] = i; } else { c.y = gamma + 1; node_parent[gamma + 1] = i; }
+    children[i] = c;
+    if (i == 0) node_parent[0] = -1;
+}
+
+struct NodeBox { float lo[3]; float hi[3]; };
+
+// agent-scope loads: the boxes below were written by another workgroup, possibly on another XCD (its own L2)
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void fit_kernel(const BuildPrim* __restrict__ prims, const uint32_t* __restrict__ order, int n, const int2* __restrict__ children,
+                           const int* __restrict__ node_parent, const int* __restrict__ leaf_parent, int* __restrict__ arrivals,
+                           NodeBox* __restrict__ node_box, int* __restrict__ node_levels, BvhNode* __restrict__ out, int base) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int p = leaf_parent[k];
+    while (p >= 0) {
+        __threadfence(); // what this thread wrote below (or nothing, first time) is visible before it counts itself in
+        if (atomicAdd(&arrivals[p], 1) == 0) return; // the sibling subtree is not finished: its last thread will go on
+        __threadfence();
+        const int2 c = children[p];
+        BvhNode nd;
+        float lo[3], hi[3];
+        int levels = 0;
+        for (int side = 0; side < 2; ++side) {
+            const int ch = side == 0 ? c.x : c.y;
+            float* blo = side == 0 ? nd.lo0 : nd.lo1;
+            float* bhi = side == 0 ? nd.hi0 : nd.hi1;
+            int code;
+            if (ch < 0) {
+                const BuildPrim q = prims[order[~ch]];
+                for (int a = 0; a < 3; ++a) { blo[a] = q.lo[a]; bhi[a] = q.hi[a]; }
+                code = q.leaf;
+            } else {
+                for (int a = 0; a < 3; ++a) { blo[a] = ld_agent(&node_box[ch].lo[a]); bhi[a] = ld_agent(&node_box[ch].hi[a]); }
+                code = base + ch;
+                levels = max(levels, ld_agent(&node_levels[ch]));
+            }
+            if (side == 0) nd.child0 = code; else nd.child1 = code;
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = side == 0 ? blo[a] : fminf(lo[a], blo[a]);
+                hi[a] = side == 0 ? bhi[a] : fmaxf(hi[a], bhi[a]);
+            }
+        }
+        nd.pad0 = nd.pad1 = 0;
+        out[p] = nd;
+        for (int a = 0; a < 3; ++a) { node_box[p].lo[a] = lo[a]; node_box[p].hi[a] = hi[a]; }
+        node_levels[p] = levels + 1;
+        p = node_parent[p];
+    }
+}
+
+// Depth-first (pre-order) position of every inner node: the first leaf of its range plus the number of ancestors that
+// hold it in their LEFT subtree.  (Pre-order puts a node after its ancestors and after every node lying entirely to
+// its left; inner nodes and the gaps between adjacent sorted leaves correspond one to one, which gives the count.)
+// The hierarchy's own numbering scatters the top of the tree over the whole array; pre-order keeps a node next to
+// its first child and the top levels together, as the host builder does.
+__global__ void preorder_kernel(const int2* __restrict__ children, const int* __restrict__ node_parent, int n_inner, int* __restrict__ pos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    int first = i; // leftmost leaf of node i's range: follow left children down
+    for (int c = children[i].x; c >= 0; c = children[c].x) first = c;
+    first = ~children[first].x;
+    int lefts = 0;
+    for (int c = i, p = node_parent[i]; p >= 0; c = p, p = node_parent[p]) lefts += children[p].x == c;
+    pos[i] = first + lefts;
+}
+__global__ void relayout_kernel(const BvhNode* __restrict__ in, const int* __restrict__ pos, int n_inner, int base, BvhNode* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    BvhNode nd = in[i];
+    if (nd.child0 >= 0) nd.child0 = base + pos[nd.child0 - base];
+    if (nd.child1 >= 0) nd.child1 = base + pos[nd.child1 - base];
+    out[pos[i]] = nd;
+}
+
+} // namespace
+
+int lbvh_build_device(const std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes, int32_t& root, uint32_t& levels,
+                      double* kernel_ms, std::string& err) {
+    const size_t n = prims.size();
+    if (n < 2 || n >= (size_t(1) << 26)) { err = "lbvh_build: needs 2 .. 2^26-1 leaves"; return -1; }
+    int rc = 0;
+    // centroid bounds on the host (the leaves come from the host anyway)
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const BuildPrim& p : prims)
+        for (int a = 0; a < 3; ++a) {
+            const float c = 0.5f * (p.lo[a] + p.hi[a]);
+            cmin[a] = std::min(cmin[a], c);
+            cmax[a] = std::max(cmax[a], c);
+        }
+    float scale[3];
+    for (int a = 0; a < 3; ++a) {
+        const float ext = cmax[a] - cmin[a];
+        scale[a] = (ext > 0.f && std::isfinite(ext)) ? 2097151.f / ext : 0.f;
+    }
+
+    BuildPrim* d_prims = nullptr;
+    uint64_t *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_order = nullptr, *d_order2 = nullptr;
+    int2* d_children = nullptr;
+    int *d_node_parent = nullptr, *d_leaf_parent = nullptr, *d_arrivals = nullptr, *d_levels = nullptr;
+    NodeBox* d_box = nullptr;
+    BvhNode *d_out = nullptr, *d_out2 = nullptr;
+    int* d_pos = nullptr;
+    void* d_temp = nullptr;
+    size_t temp_bytes = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const int base = int(nodes.size());
+    const uint32_t nb = uint32_t((n + 255) / 256);
+    int h_levels = 0;
+    {
+        LBVH_TRY(hipMalloc((void**)&d_prims, n * sizeof(BuildPrim)));
+        LBVH_TRY(hipMalloc((void**)&d_keys, n * 8));
+        LBVH_TRY(hipMalloc((void**)&d_keys2, n * 8));
+        LBVH_TRY(hipMalloc((void**)&d_order, n * 4));
+        LBVH_TRY(hipMalloc((void**)&d_order2, n * 4));
+        LBVH_TRY(hipMalloc((void**)&d_children, (n - 1) * sizeof(int2)));
+        LBVH_TRY(hipMalloc((void**)&d_node_parent, (n - 1) * 4));
+        LBVH_TRY(hipMalloc((void**)&d_leaf_parent, n * 4));
+        LBVH_TRY(hipMalloc((void**)&d_arrivals, (n - 1) * 4));
+        LBVH_TRY(hipMalloc((void**)&d_levels, (n - 1) * 4));
+        LBVH_TRY(hipMalloc((void**)&d_box, (n - 1) * sizeof(NodeBox)));
+        LBVH_TRY(hipMalloc((void**)&d_out, (n - 1) * sizeof(BvhNode)));
+        LBVH_TRY(hipMalloc((void**)&d_out2, (n - 1) * sizeof(BvhNode)));
+        LBVH_TRY(hipMalloc((void**)&d_pos, (n - 1) * 4));
+        LBVH_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 63, hipStream_t(0)));
+        LBVH_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
+        LBVH_TRY(hipEventCreate(&e0));
+        LBVH_TRY(hipEventCreate(&e1));
+        LBVH_TRY(hipMemcpy(d_prims, prims.data(), n * sizeof(BuildPrim), hipMemcpyHostToDevice));
+
+        LBVH_TRY(hipEventRecord(e0, 0));
+        LBVH_TRY(hipMemsetAsync(d_arrivals, 0, (n - 1) * 4, 0));
+        hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(256), 0, 0, d_prims, uint32_t(n), cmin[0], cmin[1], cmin[2], scale[0], scale[1],
+                           scale[2], d_keys, d_order);
+        LBVH_TRY(rocprim::radix_sort_pairs(d_temp, temp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 63, hipStream_t(0)));
+        hipLaunchKernelGGL(hierarchy_kernel, dim3(nb), dim3(256), 0, 0, d_keys2, int(n), d_children, d_node_parent, d_leaf_parent);
+        hipLaunchKernelGGL(fit_kernel, dim3(nb), dim3(256), 0, 0, d_prims, d_order2, int(n), d_children, d_node_parent, d_leaf_parent,
+                           d_arrivals, d_box, d_levels, d_out, base);
+        hipLaunchKernelGGL(preorder_kernel, dim3(nb), dim3(256), 0, 0, d_children, d_node_parent, int(n - 1), d_pos);
+        hipLaunchKernelGGL(relayout_kernel, dim3(nb), dim3(256), 0, 0, d_out, d_pos, int(n - 1), base, d_out2);
+        LBVH_TRY(hipEventRecord(e1, 0));
+        LBVH_TRY(hipGetLastError());
+        LBVH_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        LBVH_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (kernel_ms) *kernel_ms += ms;
+
+        nodes.resize(size_t(base) + n - 1);
+        LBVH_TRY(hipMemcpy(nodes.data() + base, d_out2, (n - 1) * sizeof(BvhNode), hipMemcpyDeviceToHost));
+        LBVH_TRY(hipMemcpy(&h_levels, d_levels, 4, hipMemcpyDeviceToHost));
+        root = base;
+        levels = uint32_t(h_levels);
+    }
+done:
+    if (rc) nodes.resize(size_t(base));
+    for (void* p : {(void*)d_prims, (void*)d_keys, (void*)d_keys2, (void*)d_order, (void*)d_order2, (void*)d_children, (void*)d_node_parent,
+                    (void*)d_leaf_parent, (void*)d_arrivals, (void*)d_levels, (void*)d_box, (void*)d_out, (void*)d_out2, (void*)d_pos, d_temp})
+        if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return rc;
+}
+
+} // namespace rt

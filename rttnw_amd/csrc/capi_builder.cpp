@@ -4,6 +4,7 @@
 #include "../../include/rttnw_hip.h"
 #include "scene_handle.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -194,12 +195,46 @@ int rttnw_scene_commit(rttnw_scene* s) {
     if (!s) return fail(RTTNW_ERR_INVALID, "scene is NULL");
     if (s->committed) return RTTNW_OK; // idempotent
     std::string err;
-    int rc = rt::lower_scene(s->graph, s->flat, err);
+    rt::BvhBuilder device_builder;
+    const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
+    if (on_device)
+        if (int brc = rt::device_bvh_builder(s, device_builder, err)) return fail(brc, err.c_str());
+    const auto t0 = std::chrono::steady_clock::now();
+    s->build_kernel_ms = 0;
+    int rc = rt::lower_scene(s->graph, s->flat, err, on_device ? &device_builder : nullptr);
+    s->lower_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc) return fail(rc, err.c_str());
     rc = rt::device_commit(s, err);
     if (rc) return fail(rc, err.c_str());
     s->committed = true;
     return RTTNW_OK;
+}
+
+int rttnw_scene_set_bvh_builder(rttnw_scene* s, uint32_t builder) {
+    if (int rc = check_open(s)) return rc;
+    if (builder != RTTNW_BVH_HOST_SAH && builder != RTTNW_BVH_DEVICE_LBVH) return fail(RTTNW_ERR_INVALID, "unknown BVH builder");
+    s->bvh_builder = builder;
+    return RTTNW_OK;
+}
+
+int rttnw_scene_build_info(const rttnw_scene* s, rttnw_build_info* out) {
+    if (!s || !out) return fail(RTTNW_ERR_INVALID, "scene_build_info: NULL argument");
+    if (!s->committed) return fail(RTTNW_ERR_STATE, "scene_build_info: scene is not committed");
+    out->builder = s->bvh_builder;
+    out->n_nodes = uint32_t(s->flat.nodes.size());
+    out->n_prims = s->flat.n_prims_in_bvh;
+    out->stack_depth = s->flat.stack_depth;
+    out->lower_ms = s->lower_ms;
+    out->device_ms = s->build_kernel_ms;
+    return RTTNW_OK;
+}
+
+int rttnw_debug_scene_nodes(const rttnw_scene* s, void* out_nodes, uint32_t max_nodes, int32_t* top_root) {
+    if (!s || !s->committed) return fail(RTTNW_ERR_STATE, "debug_scene_nodes: scene is not committed");
+    const uint32_t n = uint32_t(std::min<size_t>(s->flat.nodes.size(), max_nodes));
+    if (out_nodes && n) std::memcpy(out_nodes, s->flat.nodes.data(), size_t(n) * sizeof(rt::BvhNode));
+    if (top_root) *top_root = s->flat.top_root;
+    return int(s->flat.nodes.size());
 }
 
 const rttnw_builder_api* rttnw_builder(void) {

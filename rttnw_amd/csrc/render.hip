@@ -786,6 +786,18 @@ void device_release(DeviceState* d) {
     delete d;
 }
 
+int device_bvh_builder(::rttnw_scene* s, BvhBuilder& out, std::string& err) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        err = "no HIP device available (the device BVH builder has no CPU fallback)";
+        return RTTNW_ERR_HIP;
+    }
+    out = [s](const std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes, int32_t& root, uint32_t& levels, std::string& e) {
+        return lbvh_build_device(prims, nodes, root, levels, &s->build_kernel_ms, e);
+    };
+    return 0;
+}
+
 int device_commit(::rttnw_scene* s, std::string& err) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {

@@ -10,6 +10,9 @@ struct DeviceState; // defined in render.hip
 // Called by rttnw_scene_commit after lowering; uploads to the current HIP device.
 int device_commit(struct ::rttnw_scene* s, std::string& err);
 void device_release(DeviceState* d);
+// The device BVH builder bound to scene `s` (accumulates its kernel time in s->build_kernel_ms); fails without a
+// usable HIP device.  Defined in render.hip (and as a failing stub in the host-only test build).
+int device_bvh_builder(struct ::rttnw_scene* s, BvhBuilder& out, std::string& err);
 void set_last_error(const std::string& msg);
 } // namespace rt
 
@@ -18,5 +21,8 @@ struct rttnw_scene {
     rt::FlatScene flat;
     bool committed = false;
     uint32_t n_media = 0;
+    uint32_t bvh_builder = 0;      // RTTNW_BVH_*
+    double lower_ms = 0;           // host wall time of rttnw_scene_commit's lowering (BVH builds included)
+    double build_kernel_ms = 0;    // device time of the BVH build kernels (device builder only)
     rt::DeviceState* device = nullptr;
 };

@@ -111,6 +111,7 @@ struct Lowering {
     std::string& err;
     std::vector<int32_t> tex_index, mat_index; // graph id -> flat index
     int rc = 0;
+    const BvhBuilder* builder = nullptr;
 
     int fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return code; }
 
@@ -300,7 +301,8 @@ struct Lowering {
         return me;
     }
 
-    // Build a BVH whose root is always a node record.  Returns the root index.
+    // Build a BVH whose root is always a node record.  Returns the root index; `depth_out` = levels of inner nodes on
+    // the longest root-to-leaf path (what bounds the traversal stack: one pending sibling per inner level).
     int32_t build_root(std::vector<Item>& items, uint32_t& depth_out, Box3& box_out) {
         uint32_t md = 0;
         if (items.empty()) {
@@ -312,9 +314,28 @@ struct Lowering {
             box_out = Box3();
             return int32_t(fs.nodes.size() - 1);
         }
+        if (builder && items.size() >= 2) {
+            // external builder (device LBVH): every item is a one-record leaf; records are emitted in item order
+            std::vector<BuildPrim> prims(items.size());
+            box_out = Box3();
+            for (size_t i = 0; i < items.size(); ++i) {
+                const uint32_t idx = items[i].kind == PRIM_INSTANCE ? uint32_t(items[i].obj) : emit(items[i]);
+                set_box(prims[i].lo, prims[i].hi, items[i].box);
+                prims[i].leaf = make_leaf(items[i].kind, 1, idx);
+                prims[i].pad = 0;
+                box_out.grow(items[i].box);
+            }
+            fs.n_prims_in_bvh += uint32_t(items.size());
+            int32_t root = 0;
+            uint32_t levels = 0;
+            std::string berr;
+            if (int brc = (*builder)(prims, fs.nodes, root, levels, berr)) { fail(brc, berr); depth_out = 1; return 0; }
+            depth_out = levels;
+            return root;
+        }
         // reserve the root slot first so that it precedes its subtree
         int32_t code = build(items, 0, items.size(), 1, md, box_out);
-        depth_out = md + 1;
+        depth_out = std::max(1u, md - 1); // build() counts the leaf level too; a lone leaf gets the wrapper node below
         if (code >= 0) return code;
         BvhNode nd{};
         set_box(nd.lo0, nd.hi0, box_out);
@@ -500,19 +521,18 @@ struct Lowering {
         uint32_t top_depth = 0;
         Box3 wb;
         fs.top_root = build_root(top, top_depth, wb);
-        // Entries a lane's stack can hold at once: one pending far child per level of INNER nodes of the top tree
-        // (build depth counts the leaf level too, and build_root adds one), one sentinel while inside an instance,
-        // and the same for the instance's tree.  +1 spare.
-        fs.stack_depth = top_depth + inst_depth + 1;
+        // Entries a lane's stack can hold at once: one pending sibling per level of inner nodes of the top tree, and
+        // while inside an instance one sentinel plus the same for the instance's tree.  +1 spare.
+        fs.stack_depth = top_depth + (fs.insts.empty() ? 0u : 1u + inst_depth) + 1u;
         return 0;
     }
 };
 
 } // namespace
 
-int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err) {
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder) {
     out = FlatScene();
-    Lowering lw{g, out, err, {}, {}, 0};
+    Lowering lw{g, out, err, {}, {}, 0, builder};
     return lw.run();
 }
 

@@ -2,6 +2,7 @@
 // through the C ABI (the `Box/Arc<dyn Hittable>` graph of the reference, hittable.rs) and lowers
 // it into the flat, index-linked arrays of rt_types.hpp.  Pure C++; no HIP in here.
 #pragma once
+#include "bvh_build.hpp"
 #include "rt_types.hpp"
 
 #include <cstdint>
@@ -57,8 +58,9 @@ struct FlatScene {
     uint32_t n_prims_in_bvh = 0;
 };
 
-// Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.
-int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err);
+// Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.  `builder` (optional)
+// replaces the host binned-SAH build for every tree of two or more leaves (bvh_build.hpp).
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder = nullptr);
 
 // Camera::new — camera.rs:32-61 (computed once on the host, in f64)
 void make_camera(const double lookfrom[3], const double lookat[3], const double view_up[3], double vfov_deg,

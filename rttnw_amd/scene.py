@@ -118,6 +118,15 @@ class Scene:
     def set_world(self, lst):
         check(self.b.scene_set_world(self.handle, lst), self.b, "scene_set_world")
 
+    def set_bvh_builder(self, which):
+        """abi.BVH_HOST_SAH (default) or abi.BVH_DEVICE_LBVH; before commit / build_named."""
+        check(self.b.scene_set_bvh_builder(self.handle, int(which)), self.b, "scene_set_bvh_builder")
+
+    def build_info(self):
+        bi = abi.BuildInfo()
+        check(self.b.scene_build_info(self.handle, C.byref(bi)), self.b, "scene_build_info")
+        return bi
+
     def commit(self):
         check(self.b.scene_commit(self.handle), self.b, "scene_commit")
 

@@ -14,14 +14,24 @@
 namespace rt {
 int device_commit(::rttnw_scene*, std::string&) { return 0; } // no device in the host build
 void device_release(DeviceState*) {}
+int device_bvh_builder(::rttnw_scene*, BvhBuilder&, std::string& err) {
+    err = "the host test build has no device BVH builder";
+    return RTTNW_ERR_HIP;
+}
 } // namespace rt
 
 namespace {
 using namespace rt;
 
+std::atomic<int> g_max_stack{0}; // deepest traversal-stack index written since the last hostsim_max_stack() call
+
 struct HostStack {
     int32_t data[256];
-    void set(int i, int32_t v) { data[i] = v; }
+    void set(int i, int32_t v) {
+        data[i] = v;
+        int seen = g_max_stack.load(std::memory_order_relaxed);
+        while (i + 1 > seen && !g_max_stack.compare_exchange_weak(seen, i + 1, std::memory_order_relaxed)) {}
+    }
     int32_t get(int i) const { return data[i]; }
     template <typename R> BvhNode node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
 };
@@ -181,6 +191,8 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
                                      : render_t<double>(s, cam, p, out_linear, stats, n_threads);
 }
+// Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).
+int hostsim_max_stack() { return g_max_stack.exchange(0); }
 int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, rects, boxes, insts, media, stack_depth */) {
     if (!s || !s->committed) return RTTNW_ERR_INVALID;
     out[0] = uint32_t(s->flat.nodes.size()); out[1] = uint32_t(s->flat.spheres.size()); out[2] = uint32_t(s->flat.moving.size());

@@ -20,7 +20,12 @@ def test_core_f64_equals_golden(hostsim, scenes_lib, earth, case):
     key, name, w, h, spp, chunk, param = case
     sc, setup = util.build(hostsim, scenes_lib, name, earth, param)
     cam, p = util.params_for(setup, w, h, spp, spp_chunk=chunk, precision=abi.F64)
+    hostsim.lib.hostsim_max_stack()
     lin, _ = util.hostsim_render(hostsim, sc, cam, p)
+    # the LDS traversal stacks of the device are sized by the lowering's bound: it must cover what the walk really used
+    dims = (C.c_uint32 * 8)()
+    hostsim.lib.hostsim_scene_dims(sc.handle, dims)
+    assert hostsim.lib.hostsim_max_stack() <= dims[7], (key, dims[7])
     g = load()[key + "_linear"]
     d = np.abs(lin - g)
     # recursion (oracle) vs throughput loop (core) differ by rounding only

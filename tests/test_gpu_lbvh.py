@@ -1,0 +1,118 @@
+"""Device-side BVH build: rttnw_scene_set_bvh_builder(RTTNW_BVH_DEVICE_LBVH).
+
+The tree only decides WHICH records a ray tests, never what a test returns, and exact ties are resolved by list
+order, so a render through the device-built linear BVH must equal the render through the host SAH tree bit for
+bit — in f64 and in f32.  Plus structural checks of the node records the kernels wrote.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+from rttnw_amd import abi, render
+from rttnw_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+NODE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("child", "<i4", 2), ("pad", "<i4", 2)])
+assert NODE.itemsize == 64
+CHILD_EMPTY = -2**31
+
+# (scene, param, width, height, spp): every primitive kind, instances, media, an un-BVH'd list, a deep tree
+SCENES = [("cornell_box", 0, 64, 64, 8), ("smoke_cornell_box", 0, 48, 48, 4), ("final_scene", 0, 64, 64, 4),
+          ("random_scene", 0, 64, 40, 4), ("simple_light", 0, 48, 32, 4), ("two_perlin_spheres", 0, 32, 32, 2),
+          ("spheres_1m", 20000, 64, 64, 4)]
+
+
+def nodes_of(gpu, sc):
+    n = gpu.debug_scene_nodes(sc.handle, None, 0, None)
+    buf = np.zeros(n, dtype=NODE)
+    root = C.c_int32()
+    assert gpu.debug_scene_nodes(sc.handle, buf.ctypes.data, n, C.byref(root)) == n
+    return buf, root.value
+
+
+@pytest.mark.parametrize("case", SCENES, ids=[c[0] for c in SCENES])
+@pytest.mark.parametrize("precision", [abi.F64, abi.F32], ids=["f64", "f32"])
+def test_lbvh_render_equals_sah_render(gpu, scenes_lib, earth, case, precision):
+    name, param, w, h, spp = case
+    s_sah, setup = util.build(gpu, scenes_lib, name, earth, param)
+    s_lbvh, _ = util.build(gpu, scenes_lib, name, earth, param, bvh=abi.BVH_DEVICE_LBVH)
+    bi = s_lbvh.build_info()
+    assert bi.builder == abi.BVH_DEVICE_LBVH and bi.n_prims == s_sah.build_info().n_prims
+    cam, p = util.params_for(setup, w, h, spp, precision=precision, seed=5, collect_counters=1)
+    lin_a, rgba_a, st_a = render.render_host(s_sah, cam, p)
+    lin_b, rgba_b, st_b = render.render_host(s_lbvh, cam, p)
+    assert np.array_equal(lin_a, lin_b), (name, np.abs(lin_a - lin_b).max())
+    assert np.array_equal(rgba_a, rgba_b)
+    assert st_a.rays == st_b.rays  # the same paths; node / primitive counts differ with the tree
+
+
+def test_lbvh_structure(gpu, scenes_lib):
+    n_spheres = 5000
+    sc, _ = util.build(gpu, scenes_lib, "spheres_1m", None, n_spheres, bvh=abi.BVH_DEVICE_LBVH)
+    bi = sc.build_info()
+    assert bi.device_ms > 0 and bi.n_prims == n_spheres + 1  # + the area light
+    nodes, root = nodes_of(gpu, sc)
+    assert len(nodes) == bi.n_prims - 1 and root == 0  # a binary tree over n leaves; the hierarchy's node 0 is its root
+    seen_leaf, seen_node = set(), set()
+    depth_max = 0
+    stack = [(root, 1, np.full(3, -np.inf, np.float32), np.full(3, np.inf, np.float32))]
+    while stack:
+        i, depth, plo, phi = stack.pop()
+        assert i not in seen_node
+        seen_node.add(i)
+        depth_max = max(depth_max, depth)
+        nd = nodes[i]
+        for lo, hi, ch in ((nd["lo0"], nd["hi0"], nd["child"][0]), (nd["lo1"], nd["hi1"], nd["child"][1])):
+            assert (lo <= hi).all() and (lo >= plo).all() and (hi <= phi).all()  # child boxes nest in the parent's
+            if ch >= 0:
+                stack.append((int(ch), depth + 1, lo, hi))
+            else:
+                assert ch != CHILD_EMPTY
+                bits = ~int(ch) & 0xFFFFFFFF
+                assert (bits >> 26) & 3 == 0  # one record per leaf
+                key = (bits >> 28, bits & 0x3FFFFFF)
+                assert key not in seen_leaf
+                seen_leaf.add(key)
+    assert len(seen_node) == len(nodes) and len(seen_leaf) == bi.n_prims
+    assert sum(1 for k, _ in seen_leaf if k == 0) == n_spheres  # PRIM_SPHERE = 0
+    assert depth_max + 1 == bi.stack_depth  # one pending sibling per inner level, + 1 spare (no instances here)
+
+
+def test_lbvh_small_and_empty_worlds(gpu):
+    # 0 and 1 objects never reach the device builder; 2 objects is its smallest tree
+    for n in (0, 1, 2, 3):
+        sc = S.Scene(gpu, 1)
+        sc.set_bvh_builder(abi.BVH_DEVICE_LBVH)
+        red = sc.lambertian(sc.solid(0.8, 0.2, 0.2))
+        world = sc.list()
+        for k in range(n):
+            sc.push(world, sc.sphere((2.5 * k, 0.0, -5.0), 1.0, red))
+        sc.set_world(world)
+        sc.commit()
+        ref = S.Scene(gpu, 1)
+        red = ref.lambertian(ref.solid(0.8, 0.2, 0.2))
+        world = ref.list()
+        for k in range(n):
+            ref.push(world, ref.sphere((2.5 * k, 0.0, -5.0), 1.0, red))
+        ref.set_world(world)
+        ref.commit()
+        cam = abi.CameraDesc()
+        cam.lookfrom[:] = (2.0, 0.5, 3.0); cam.lookat[:] = (2.0, 0.0, -5.0); cam.view_up[:] = (0.0, 1.0, 0.0)
+        cam.vertical_fov = 50.0; cam.aspect_ratio = 1.0; cam.aperture = 0.0; cam.focus_distance = 1.0
+        cam.open_time = 0.0; cam.close_time = 1.0
+        p = S.make_params(32, 32, 4, background=(0.7, 0.8, 1.0), precision=abi.F64)
+        a, _, _ = render.render_host(sc, cam, p)
+        b, _, _ = render.render_host(ref, cam, p)
+        assert np.array_equal(a, b), n
+
+
+def test_builder_choice_is_frozen_by_commit(gpu):
+    sc = S.Scene(gpu, 1)
+    sc.set_world(sc.list())
+    sc.commit()
+    assert gpu.scene_set_bvh_builder(sc.handle, abi.BVH_DEVICE_LBVH) == -2  # RTTNW_ERR_STATE
+    sc2 = S.Scene(gpu, 1)
+    assert gpu.scene_set_bvh_builder(sc2.handle, 7) == -1  # RTTNW_ERR_INVALID

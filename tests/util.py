@@ -7,8 +7,10 @@ from rttnw_amd import abi
 from rttnw_amd import scene as S
 
 
-def build(binding, scenes_lib, name, earth=None, param=0, seed=0x5EED0001):
+def build(binding, scenes_lib, name, earth=None, param=0, seed=0x5EED0001, bvh=None):
     sc = S.Scene(binding, seed, scenes_binding=scenes_lib)
+    if bvh is not None:
+        sc.set_bvh_builder(bvh)
     setup = sc.build_named(name, earth_rgba=earth, param=param)
     return sc, setup
 

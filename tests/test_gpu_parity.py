@@ -199,3 +199,46 @@ def test_full_size_invariants(gpu, scenes_lib, earth):
     half_b = lin * 2 - lin4                                                      # mean of samples [4,8)
     assert half_b.min() > -1e-3
     assert abs(half_b.mean() - lin4.mean()) / lin4.mean() < 0.05
+
+
+@pytest.mark.parametrize("precision", [abi.F64, abi.F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("scene", [("cornell_box", 0), ("final_scene", 0), ("smoke_cornell_box", 0), ("spheres_1m", 20000)],
+                         ids=lambda s: s[0])
+def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatch):
+    """The three forms of the trace loop — lane-owns-path with the nodes in LDS, the same with the nodes in global
+    memory, and the decoupled (queued) kernel that large scenes select — run the same per-path steps in different
+    schedules: their f64 images must be bit-identical (the library picks one by scene size; RTTNW_KERNEL forces it)."""
+    name, param = scene
+    sc, setup = util.build(gpu, scenes_lib, name, earth, param)
+    cam, p = util.params_for(setup, 72, 56, 6, spp_chunk=2, precision=precision, seed=11, collect_counters=1)
+    out = {}
+    for form in ("plain", "plainglobal", "wave"):
+        monkeypatch.setenv("RTTNW_KERNEL", form)
+        lin, rgba, st = gpu_render(gpu, sc, cam, p)
+        assert st.reserved == (1 if form == "wave" else 0)
+        out[form] = (lin, rgba, st.rays, st.nodes_visited, st.prims_tested)
+    for form in ("plainglobal", "wave"):
+        if precision == abi.F64 or form == "plainglobal":
+            assert np.array_equal(out[form][0], out["plain"][0]), form
+            assert np.array_equal(out[form][1], out["plain"][1]), form
+            assert out[form][2:] == out["plain"][2:], form  # the same world.hit() calls, node visits and record tests
+        else:
+            # f32 is compiled with -ffp-contract=fast: the two kernels may fuse a multiply-add differently, and a path
+            # whose hit sits within an ulp of a decision goes another way (measured: 1 pixel of 4032 on final_scene)
+            d = np.abs(out[form][0] - out["plain"][0]).max(axis=2)
+            assert (d > 0).mean() <= 2e-3 and out[form][2] == pytest.approx(out["plain"][2], rel=1e-3), form
+
+
+def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):
+    """>= 65 536 nodes selects the decoupled kernel by itself; it must agree with the forced lane-owns-path form."""
+    sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=150000)
+    cam, p = util.params_for(setup, 64, 64, 4, precision=abi.F32, seed=3)
+    lin, rgba, st = gpu_render(gpu, sc, cam, p)
+    assert st.reserved == 1 and st.n_nodes >= 65536
+    import os
+    os.environ["RTTNW_KERNEL"] = "plain"
+    try:
+        lin2, rgba2, st2 = gpu_render(gpu, sc, cam, p)
+    finally:
+        del os.environ["RTTNW_KERNEL"]
+    assert st2.reserved == 0 and (np.abs(lin - lin2).max(axis=2) > 0).mean() <= 2e-3

@@ -155,7 +155,8 @@ typedef struct rttnw_params {
     uint64_t seed;       /* render seed of the keyed sample RNG (DESIGN.md "RNG") */
     uint32_t precision;  /* enum rttnw_precision */
     uint32_t quirks;     /* RTTNW_QUIRK_* bits; RTTNW_QUIRKS_REFERENCE reproduces the reference */
-    uint32_t spp_chunk;  /* samples folded sequentially per work item; 0 = library default, ceil(spp/256).  The
+    uint32_t spp_chunk;  /* samples folded sequentially per work item; 0 = library default (4-sample chunks, the last
+                            ~1/32 of the samples as single-sample chunks so that a launch ends on short items).  The
                             per-pixel sum is chunk sums added in chunk order (deterministic). */
     uint32_t tile_rank;  /* this GPU's rank in the tile partition (0 for a single GPU) */
     uint32_t tile_world; /* number of GPUs sharing the framebuffer (>= 1) */

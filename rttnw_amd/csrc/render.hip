@@ -252,8 +252,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                         tile_unpermute(rj.tile_rank + (rem >> 6) * rj.tile_world, rj.div_tiles_x, tx, ty);
                         const uint32_t px = tx * 8u + (rem & 7u), row = ty * 8u + ((rem & 63u) >> 3);
                         pxrow = px | (row << 16);
-                        smp = chunk * rj.spp_chunk;
-                        smp_end = smp + rj.spp_chunk < rj.spp ? smp + rj.spp_chunk : rj.spp;
+                        chunk_samples(rj, chunk, smp, smp_end);
                         if (px >= rj.width || row >= rj.height) smp = smp_end; // outside the image: an empty job
                         acc = V3<R>();
                     }
@@ -429,8 +428,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                     tile_unpermute(rc.tile_rank + local_tile * rc.tile_world, rc.div_tiles_x, tx, ty);
                     px = tx * 8u + (l & 7u);
                     row = ty * 8u + (l >> 3);
-                    s = chunk * rc.spp_chunk;
-                    s_end = min(rc.spp, s + rc.spp_chunk);
+                    chunk_samples(rc, chunk, s, s_end);
                     if (px >= rc.width || row >= rc.height) s = s_end; // outside the image: an empty job
                     acc = V3<R>();
                     has_job = true;
@@ -867,13 +865,12 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     fill_layout(p->width, p->height, p->tile_world, L);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 255u) / 256u; // default: <= 256 chunks per pixel (the end-of-launch tail is one job long)
-    rc.n_chunks = (p->spp + rc.spp_chunk - 1) / rc.spp_chunk;
     rc.tiles_x = L.tiles_x; rc.tiles_y = L.tiles_y; rc.n_tiles = L.n_tiles;
     rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     rc.profile = p->collect_counters;
+    plan_chunks(rc, p->spp, p->spp_chunk, uint64_t(rc.my_tiles) * 64, 3 * sizeof(R));
     const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
     if (n_jobs >= (size_t(1) << 32)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
     rc.div_jobs_per_chunk = make_fastdiv(std::max<uint32_t>(1u, rc.my_tiles * 64u));

@@ -105,8 +105,7 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
     CameraRec<R> camr = narrow_camera<R>(cam64);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    rc.spp_chunk = p->spp_chunk ? p->spp_chunk : (p->spp + 255) / 256;
-    rc.n_chunks = (p->spp + rc.spp_chunk - 1) / rc.spp_chunk;
+    plan_chunks(rc, p->spp, p->spp_chunk, uint64_t(p->width) * p->height, 3 * sizeof(R));
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));
     const R t_min = R(p->t_min);
@@ -123,7 +122,8 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
                 V3<R> total;
                 for (uint32_t c = 0; c < rc.n_chunks; ++c) { // one job = (pixel, chunk), folded sequentially
                     V3<R> acc;
-                    uint32_t s0 = c * rc.spp_chunk, s1 = std::min(rc.spp, s0 + rc.spp_chunk);
+                    uint32_t s0, s1;
+                    chunk_samples(rc, c, s0, s1);
                     for (uint32_t si = s0; si < s1; ++si) {
                         PathState<R> ps;
                         path_begin(ps, camr, rc, px, row, si);

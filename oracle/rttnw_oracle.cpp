@@ -1017,7 +1017,7 @@ int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
                     uint32_t c1 = std::min(spp, c0 + chunk);
                     for (uint32_t sidx = c0; sidx < c1; ++sidx) { // main.rs:211-217
                         PathCtx ctx;
-                        ctx.key = sample_key(p->seed, pixel, sidx);
+                        ctx.key = sample_key(p->seed, pixel, uint64_t(sidx) + p->sample_begin);
                         ctx.quirks = p->quirks;
                         ctx.cnt = cnt;
                         double u = (double(i) + keyed_uniform(ctx.key, ctr_of(0, SLOT_JITTER_U))) / double(W);

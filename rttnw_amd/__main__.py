@@ -2,7 +2,7 @@
 
 One positional argument, the scene number 1..9 with the reference's per-scene defaults (size, spp, camera:
 main.rs:66-183); writes `image.png` into the current directory (main.rs:231) and prints the wall time.
-Optional extras (not in the reference): --spp, --width, --precision f32|f64, --out, --seed.
+Optional extras (not in the reference): --spp, --width, --precision f32|f64, --out, --seed, --passes.
 """
 import argparse
 import sys
@@ -31,6 +31,8 @@ def main(argv=None):
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="image.png")
+    ap.add_argument("--passes", type=int, default=1, help="render in this many passes over disjoint sample ranges, "
+                    "rewriting the image after each (progressive)")
     try:
         args = ap.parse_args(argv)
     except SystemExit:
@@ -57,6 +59,13 @@ def main(argv=None):
     cam.aspect_ratio = setup.width / setup.height
     p = make_params(w, h, args.spp or setup.spp, background=tuple(setup.background), seed=args.seed,
                     precision=abi.F32 if args.precision == "f32" else abi.F64)
+    if args.passes > 1:
+        def show(k, linear):
+            Image.fromarray(render.quantise_rgba8(linear), "RGBA").save(args.out)
+            print("pass %d/%d written" % (k + 1, args.passes))
+        _, rgba, _ = render.render_host_passes(sc, cam, p, args.passes, on_pass=show)
+        print("%.3fs" % (time.time() - t0))
+        return 0
     _, rgba, st = render.render_host(sc, cam, p)
     Image.fromarray(np.ascontiguousarray(rgba), "RGBA").save(args.out)
     print("%.3fs (trace kernel %.1f ms, %.1f Msamples/s)" % (time.time() - t0, st.kernel_ms,

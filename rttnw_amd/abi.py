@@ -32,7 +32,8 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("max_depth", C.c_uint32),
                 ("t_min", C.c_double), ("background", c_double3), ("seed", C.c_uint64),
                 ("precision", C.c_uint32), ("quirks", C.c_uint32), ("spp_chunk", C.c_uint32),
-                ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("collect_counters", C.c_uint32)]
+                ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("collect_counters", C.c_uint32),
+                ("sample_begin", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class BuildInfo(C.Structure):

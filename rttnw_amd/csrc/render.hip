@@ -870,6 +870,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     rc.profile = p->collect_counters;
+    rc.sample_begin = p->sample_begin;
     plan_chunks(rc, p->spp, p->spp_chunk, uint64_t(rc.my_tiles) * 64, 3 * sizeof(R));
     const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
     if (n_jobs >= (size_t(1) << 32)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }

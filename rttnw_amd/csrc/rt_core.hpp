@@ -838,7 +838,7 @@ template <typename R> struct PathState {
 template <typename R>
 RT_HD void path_begin(PathState<R>& ps, const CameraRec<R>& cam, const RenderConsts& rc, uint32_t px, uint32_t row, uint32_t s) {
     const uint64_t pixel = uint64_t(row) * rc.width + px;
-    ps.key = sample_key(rc.seed, pixel, s);
+    ps.key = sample_key(rc.seed, pixel, uint64_t(s) + rc.sample_begin);
     const uint32_t j = rc.height - 1 - row;
     R u = (R(px) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_U))) / R(rc.width);
     R v = (R(j) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_V))) / R(rc.height);

@@ -154,6 +154,7 @@ struct RenderConsts {
     uint32_t tiles_x, tiles_y, n_tiles;
     uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
     uint32_t quirks;
+    uint32_t sample_begin; // index of the render's first sample (rttnw_params::sample_begin)
     uint32_t stack_depth;
     FastDiv div_jobs_per_chunk, div_tiles_x; // job index -> (chunk, tile, pixel) without integer division
     uint32_t profile;   // counting variant: 2 = also bucket the leaf clock by record kinds (atomics: perturbs the other clocks)

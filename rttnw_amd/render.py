@@ -24,6 +24,38 @@ def render_host(scene, cam, params, want_stats=True):
     return lin, rgba, st
 
 
+def render_host_passes(scene, cam, params, passes, on_pass=None):
+    """The same image as `render_host`, in `passes` passes over disjoint sample ranges (`rttnw_params.sample_begin`):
+    after every pass the running mean is a complete, displayable estimate — progressive display and a natural
+    checkpoint (persist the running sum and the next sample index) for long renders.  `on_pass(k, linear)` is called
+    with the running mean after pass k.  Returns (linear HxWx3 f64, rgba8 HxWx4 u8, samples per pixel done)."""
+    import copy
+    total, done = None, 0
+    base, spp = params.sample_begin, params.spp
+    for k in range(passes):
+        n = spp // passes + (1 if k < spp % passes else 0)
+        if n == 0:
+            continue
+        p = copy.copy(params)
+        p.spp, p.sample_begin = n, base + done
+        lin, _, _ = render_host(scene, cam, p, want_stats=False)
+        total = lin * n if total is None else total + lin * n
+        done += n
+        if on_pass is not None:
+            on_pass(k, total / done)
+    mean = total / max(done, 1)
+    return mean, quantise_rgba8(mean), done
+
+
+def quantise_rgba8(linear):
+    """main.rs:219-225 on a linear image: sqrt, clamp to 0.999, * 256, `as u8`; alpha 255."""
+    x = np.sqrt(np.maximum(linear, 0.0))
+    x = np.minimum(x, 0.999) * 256.0
+    rgba = np.full(linear.shape[:2] + (4,), 255, dtype=np.uint8)
+    rgba[..., :3] = np.nan_to_num(x, nan=0.0).astype(np.uint8)
+    return rgba
+
+
 def _torch_dtype(precision):
     import torch
     return torch.float32 if precision == abi.F32 else torch.float64

@@ -159,9 +159,9 @@ def camera_desc(lookfrom, lookat, vfov, aspect, aperture=0.0, view_up=(0.0, 1.0,
 
 def make_params(width, height, spp, *, background=(0.0, 0.0, 0.0), seed=1, precision=abi.F64,
                 quirks=abi.QUIRKS_REFERENCE, max_depth=50, t_min=1e-3, spp_chunk=0, tile_rank=0,
-                tile_world=1, collect_counters=0):
+                tile_world=1, collect_counters=0, sample_begin=0):
     return Params(width, height, spp, max_depth, t_min, vec3(background), seed, precision, quirks,
-                  spp_chunk, tile_rank, tile_world, collect_counters)
+                  spp_chunk, tile_rank, tile_world, collect_counters, sample_begin, 0)
 
 
 def load_earth():

@@ -107,6 +107,7 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
     plan_chunks(rc, p->spp, p->spp_chunk, uint64_t(p->width) * p->height, 3 * sizeof(R));
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    rc.sample_begin = p->sample_begin;
     V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));
     const R t_min = R(p->t_min);
     if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());

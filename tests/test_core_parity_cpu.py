@@ -103,3 +103,20 @@ def test_unsupported_graphs_are_rejected(hostsim):
     sc3 = S.Scene(hostsim)
     with pytest.raises(abi.RttnwError):
         sc3.commit()                                                             # world not set
+
+
+def test_sample_ranges_compose(hostsim, oracle, scenes_lib):
+    """rttnw_params.sample_begin: passes over disjoint sample ranges are the single render of their union (the same
+    keyed draws), and the oracle follows the same convention."""
+    sc, setup = util.build(hostsim, scenes_lib, "cornell_box")
+    so, _ = util.build(oracle, scenes_lib, "cornell_box")
+    cam, p_all = util.params_for(setup, 24, 24, 12, spp_chunk=4)
+    whole = util.hostsim_render(hostsim, sc, cam, p_all)[0]
+    parts = []
+    for begin, n in ((0, 4), (4, 8)):
+        _, p = util.params_for(setup, 24, 24, n, spp_chunk=4, sample_begin=begin)
+        parts.append((n, util.hostsim_render(hostsim, sc, cam, p)[0]))
+        assert np.abs(parts[-1][1] - rto.render(so, cam, p)[0]).max() <= 1e-12
+    mean = sum(n * im for n, im in parts) / 12
+    assert np.abs(mean - whole).max() <= 1e-12 * max(1.0, whole.max())
+    assert np.abs(parts[0][1] - parts[1][1]).max() > 1e-3  # different samples, different estimates

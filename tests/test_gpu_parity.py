@@ -242,3 +242,20 @@ def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):
     finally:
         del os.environ["RTTNW_KERNEL"]
     assert st2.reserved == 0 and (np.abs(lin - lin2).max(axis=2) > 0).mean() <= 2e-3
+
+
+def test_progressive_passes_compose(gpu, scenes_lib, earth):
+    """rttnw_params.sample_begin on the device: K passes over disjoint sample ranges average to the single render."""
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
+    cam, p = util.params_for(setup, 64, 48, 12, precision=abi.F64, spp_chunk=4, seed=3)
+    whole, rgba_whole, _ = gpu_render(gpu, sc, cam, p)
+    seen = []
+    mean, rgba, done = render.render_host_passes(sc, cam, p, 3, on_pass=lambda k, lin: seen.append(lin.copy()))
+    assert done == 12 and len(seen) == 3
+    assert np.abs(mean - whole).max() <= 1e-12 * max(1.0, whole.max())
+    assert (rgba == rgba_whole).all(axis=2).mean() >= 0.999
+    assert np.abs(seen[0] - whole).max() > 1e-3  # the first pass alone is a noisier estimate of the same image
+    # a pass that starts where another stopped continues the same sample sequence (checkpoint / resume)
+    _, p_tail = util.params_for(setup, 64, 48, 8, precision=abi.F64, spp_chunk=4, seed=3, sample_begin=4)
+    tail, _, _ = gpu_render(gpu, sc, cam, p_tail)
+    assert np.abs((seen[0] * 4 + tail * 8) / 12 - whole).max() <= 1e-12 * max(1.0, whole.max())

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
 
     const uint32_t wave_global = blockIdx.x * (TRACE_BLOCK / 64) + wave_in_block;
     const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;
-    const unsigned long long n_jobs = (unsigned long long)rc.my_tiles * 64ull * rc.n_chunks;
+    const unsigned long long n_jobs = rc.n_jobs;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const V3<R> background(bg_r, bg_g, bg_b);
 
@@ -246,14 +246,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                     if (job >= n_jobs) {
                         slot_done = true; // no jobs left: this slot retires
                     } else {
-                        uint32_t chunk, rem, tx, ty;
                         const RenderConsts rj = kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)); // cold: keep it out of the SGPRs
-                        job_split(job, rj.div_jobs_per_chunk, chunk, rem);
-                        tile_unpermute(rj.tile_rank + (rem >> 6) * rj.tile_world, rj.div_tiles_x, tx, ty);
-                        const uint32_t px = tx * 8u + (rem & 7u), row = ty * 8u + ((rem & 63u) >> 3);
-                        pxrow = px | (row << 16);
-                        chunk_samples(rj, chunk, smp, smp_end);
-                        if (px >= rj.width || row >= rj.height) smp = smp_end; // outside the image: an empty job
+                        const JobInfo ji = job_decode(rj, uint32_t(job));
+                        pxrow = ji.px | (ji.row << 16);
+                        smp = ji.s; smp_end = ji.s_end;
+                        job = ji.real ? (unsigned long long)ji.sum_index : ~0ull; // from here on: where the job's sum goes (none for padding)
                         acc = V3<R>();
                     }
                 }
@@ -389,8 +386,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
     typename CounterSel<COUNT>::type cnt;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
-    const unsigned long long n_jobs = jobs_per_chunk * rc.n_chunks;
+    const unsigned long long n_jobs = rc.n_jobs;
     const V3<R> background(bg_r, bg_g, bg_b);
 
     bool has_job = false, alive = false, done = false;
@@ -422,16 +418,11 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                 if (job >= n_jobs) {
                     done = true;
                 } else {
-                    uint32_t chunk, rem, tx, ty;
-                    job_split(job, rc.div_jobs_per_chunk, chunk, rem);
-                    const uint32_t local_tile = rem >> 6, l = rem & 63u;
-                    tile_unpermute(rc.tile_rank + local_tile * rc.tile_world, rc.div_tiles_x, tx, ty);
-                    px = tx * 8u + (l & 7u);
-                    row = ty * 8u + (l >> 3);
-                    chunk_samples(rc, chunk, s, s_end);
-                    if (px >= rc.width || row >= rc.height) s = s_end; // outside the image: an empty job
+                    const JobInfo ji = job_decode(rc, uint32_t(job));
+                    px = ji.px; row = ji.row; s = ji.s; s_end = ji.s_end;
+                    job = ji.sum_index; // from here on: where the job's sum goes
                     acc = V3<R>();
-                    has_job = true;
+                    has_job = ji.real; // padding jobs have no sum to write
                 }
             }
         }
@@ -872,11 +863,10 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.profile = p->collect_counters;
     rc.sample_begin = p->sample_begin;
     plan_chunks(rc, p->spp, p->spp_chunk, uint64_t(rc.my_tiles) * 64, 3 * sizeof(R));
-    const size_t n_jobs = size_t(rc.my_tiles) * 64 * rc.n_chunks;
-    if (n_jobs >= (size_t(1) << 32)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
-    rc.div_jobs_per_chunk = make_fastdiv(std::max<uint32_t>(1u, rc.my_tiles * 64u));
+    if (!plan_jobs(rc)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
+    const size_t n_jobs = rc.n_jobs;
     rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
-    if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(n_jobs, 1) * 3 * sizeof(R))) return g;
+    if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(size_t(rc.jobs_per_chunk) * rc.n_chunks, 1) * 3 * sizeof(R))) return g;
 
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,

@@ -156,7 +156,9 @@ struct RenderConsts {
     uint32_t quirks;
     uint32_t sample_begin; // index of the render's first sample (rttnw_params::sample_begin)
     uint32_t stack_depth;
-    FastDiv div_jobs_per_chunk, div_tiles_x; // job index -> (chunk, tile, pixel) without integer division
+    FastDiv div_jobs_per_group, div_tiles_x; // job index -> (chunk, tile, pixel) without integer division (job_decode)
+    uint32_t jobs_per_chunk;                 // my_tiles * 64: the sums of chunk c start at c * jobs_per_chunk
+    uint32_t n_jobs;                         // job indices handed out (chunk groups are padded: some jobs are empty)
     uint32_t profile;   // counting variant: 2 = also bucket the leaf clock by record kinds (atomics: perturbs the other clocks)
     uint32_t lds_nodes; // lane-owns-path kernel: number of BVH nodes resident in LDS (0 = nodes read from global memory)
     uint64_t seed;

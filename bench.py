@@ -67,9 +67,23 @@ def main():
     if world != args.gpus:
         log("bench: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RTTNW_BENCH_FORCE_DIST=1: take the torch.distributed code path with a single rank too (checks the launch plumbing
+    # on a 1-GPU box; the numbers are the same)
+    use_dist = world > 1 or os.environ.get("RTTNW_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        # RCCL prints its version banner on stdout when NCCL_DEBUG=VERSION is set (it is, on the GPU boxes): keep stdout
+        # for the ONE JSON line by pointing fd 1 at stderr while the communicator comes up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     gpu = library.product()
     if gpu.device_count() < 1:
@@ -108,7 +122,7 @@ def main():
     for _ in range(args.warmup):
         r.step()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -118,12 +132,12 @@ def main():
         ev[k][1].record()
         r.collect()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms_per_step, kernel_ms = float(t[0]), float(t[1])
@@ -204,7 +218,7 @@ def main():
             "f64_kernels": f64,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -80,8 +80,10 @@ class DeviceRenderer:
         dev = torch.device("cuda", torch.cuda.current_device())
         self.packed = torch.zeros((self.lay["pixels_per_rank"], 4), dtype=dt, device=dev)
         root = self.rank == 0
+        # force_gather: run the collective with a single rank too (launch-plumbing check on a 1-GPU box)
+        self.force_gather = bool(group is None and self.world == 1 and __import__("os").environ.get("RTTNW_BENCH_FORCE_DIST") == "1")
         self.gathered = (torch.zeros((self.world, self.lay["pixels_per_rank"], 4), dtype=dt, device=dev)
-                         if (root and self.world > 1) else None)
+                         if (root and (self.world > 1 or self.force_gather)) else None)
         self.linear = torch.zeros((params.height, params.width, 3), dtype=dt, device=dev) if root else None
         self.rgba8 = torch.zeros((params.height, params.width, 4), dtype=torch.uint8, device=dev) if root else None
 
@@ -95,7 +97,7 @@ class DeviceRenderer:
     def collect(self):
         """Gather every rank's packed tiles on rank 0 (RCCL over xGMI) and scatter them into the framebuffer."""
         src = self.packed
-        if self.world > 1:
+        if self.world > 1 or self.force_gather:
             import torch.distributed as dist
             glist = list(self.gathered.unbind(0)) if self.rank == 0 else None
             dist.gather(self.packed, glist, dst=0, group=self.group)   # RCCL: grouped send/recv into rank 0

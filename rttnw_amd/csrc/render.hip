@@ -691,7 +691,7 @@ template <typename R> struct DeviceScene {
         std::vector<InstanceRec<R>> in;
         for (auto& i : f.insts) {
             InstanceRec<R> o{};
-            o.n_ops = i.n_ops; o.root = i.root;
+            o.n_ops = i.n_ops; o.root = i.root; o.single_leaf = i.single_leaf;
             for (int k = 0; k < MAX_INSTANCE_OPS; ++k) {
                 o.ops[k].type = i.ops[k].type;
                 for (int c = 0; c < 3; ++c) o.ops[k].v[c] = R(i.ops[k].v[c]);

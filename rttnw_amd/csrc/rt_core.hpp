@@ -460,6 +460,18 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     if (kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
         cnt.prim();
         const InstanceRec<R> in = sc.insts[first];
+        if (in.single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk
+            const Ray<R> outer = tr.ray;
+            const int32_t outer_inst = tr.cur_inst;
+            tr.ray = to_object(in, wray);
+            tr.cur_inst = int32_t(first);
+            cnt.prim();
+            trav_test_record(tr, sc, leaf_kind(in.single_leaf), leaf_first(in.single_leaf), t_min);
+            tr.ray = outer;
+            tr.cur_inst = outer_inst;
+            trav_pop(tr, wray, stack);
+            return;
+        }
         stack.set(tr.sp++, STACK_SENTINEL);
         tr.ray = to_object(in, wray);
         tr.sr = slab_ray(tr.ray.o, tr.ray.d);

@@ -70,7 +70,9 @@ constexpr int MAX_INSTANCE_OPS = 3;
 // = Translate(YRotate(x)) lowers to ops = { translate v, rotate a }.
 template <typename R> struct alignas(16) InstanceRec {
     int32_t n_ops;
-    int32_t root; // sub-BVH root node
+    int32_t root;        // sub-BVH root node
+    int32_t single_leaf; // the wrapped group is ONE record: its leaf bits (< 0), tested in place without walking `root`; else 0
+    int32_t pad0;
     struct Op { int32_t type; int32_t pad; R v[3]; } ops[MAX_INSTANCE_OPS]; // translate: offset; rotate: {sin, cos, -}
 };
 

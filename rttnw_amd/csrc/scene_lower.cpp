@@ -410,6 +410,12 @@ struct Lowering {
             Box3 ob;
             in.root = build_root(sub, depth, ob);
             inst_depth = std::max(inst_depth, depth);
+            // a wrapped single object (the Cornell blocks: `cube.rotate_y(a).translate(v)`): build_root made a node whose
+            // only child is that record's leaf; the walk tests the record in place instead of entering a one-node tree
+            in.single_leaf = 0;
+            if (sub.size() == 1 && sub[0].kind != PRIM_INSTANCE && fs.nodes[in.root].child0 < 0 && fs.nodes[in.root].child1 == CHILD_EMPTY &&
+                leaf_count(fs.nodes[in.root].child0) == 1)
+                in.single_leaf = fs.nodes[in.root].child0;
             Box3 wb;
             if (!sub.empty()) {
                 for (int c = 0; c < 8; ++c) {

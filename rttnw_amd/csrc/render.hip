@@ -462,12 +462,13 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                 Trav<R> tr;
                 trav_begin(tr, sc, ps.ray);
                 while (tr.node != TRAV_DONE) {
-                    // the loop body of closest_solid() (node step, then leaf step for the lanes at a leaf by then), tallied
+                    // the loop body of closest_solid() (two node steps, then a leaf step for the lanes at a leaf by then), tallied
                     const unsigned long long act = __ballot(true);
                     const bool is_node = tr.node >= 0;
                     const unsigned long long nm = __ballot(is_node);
                     const long long q0 = clock64();
                     if (is_node) { prof[5] += 1; trav_node_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    if (tr.node >= 0) { prof[5] += 1; trav_node_step(tr, sc, ps.ray, t_min, stack, cnt); }
                     const long long q1 = clock64();
                     const bool is_leaf = tr.node < 0 && tr.node != TRAV_DONE;
                     const unsigned long long lm = __ballot(is_leaf);

@@ -497,8 +497,12 @@ RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R&
     Trav<R> tr;
     trav_begin(tr, sc, wray);
     while (tr.node != TRAV_DONE) {
-        // node step, then leaf step: a lane whose node step arrives at a leaf tests it in the same trip round the loop,
-        // together with the lanes that were already waiting at theirs
+        // one trip: two node steps, then a leaf step for the lanes at a leaf by then.  A lane whose node step arrives at
+        // a leaf tests it in the same trip, together with the lanes that were already waiting at theirs; the second node
+        // step halves the trips of node-heavy walks and with them the executions of the (wide, poorly filled) leaf
+        // code.  Measured, node steps per trip 1 / 2 / 3 / 4: final_scene 1288 / 1368 / 1357 / 1356 Msamples/s,
+        // cornell_box 1707 / 1718 / 1665 / 1691.
+        if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
         if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
         if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
     }

@@ -539,6 +539,13 @@ template <typename R> RT_HD void sphere_uv(V3<R> p, R& u, R& v) { // hittable.rs
     v = theta / pi;
 }
 
+// The reference computes (u, v) for every hit (Sphere::uv's acos + atan2, the rectangles' two divisions; Q11), but only
+// an image texture — possibly under a checker — ever reads them: they are computed only then.  Same results.
+template <typename R> RT_HD bool uv_is_read(const SceneView<R>& sc, int32_t mat) {
+    const int32_t tex = sc.mats[mat].tex;
+    return tex >= 0 && (sc.texs[tex].type == TEX_IMAGE || sc.texs[tex].type == TEX_CHECKER);
+}
+
 template <typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim), idx = ref_index(ref.prim);
@@ -553,11 +560,8 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         rec.p = ray.at(t);
         outward = (rec.p - c) / s.r;
         rec.mat = sc.sphere_mat[idx];
-        // Sphere::uv (acos + atan2) is evaluated by the reference for every hit (Q11) but only an image texture
-        // (possibly under a checker) ever reads it: compute it only then — same result, ~100 instructions saved.
-        const int32_t tex = sc.mats[rec.mat].tex;
         rec.u = R(0); rec.v = R(0);
-        if (tex >= 0 && (sc.texs[tex].type == TEX_IMAGE || sc.texs[tex].type == TEX_CHECKER)) sphere_uv(outward, rec.u, rec.v);
+        if (uv_is_read(sc, rec.mat)) sphere_uv(outward, rec.u, rec.v);
     } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
         const MovingSphereRec<R> m = sc.moving[idx];
         rec.p = ray.at(t);
@@ -566,22 +570,28 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         rec.mat = m.mat;
     } else if (kind == PRIM_RECT) { // hittable.rs:515-519
         const RectRec<R> r = sc.rects[idx];
-        R a, b;
-        rect_ab(r.plane, ray, t, a, b);
-        rec.u = (a - r.a0) / (r.a1 - r.a0);
-        rec.v = (b - r.b0) / (r.b1 - r.b0);
+        rec.u = R(0); rec.v = R(0);
+        if (uv_is_read(sc, r.mat)) {
+            R a, b;
+            rect_ab(r.plane, ray, t, a, b);
+            rec.u = (a - r.a0) / (r.a1 - r.a0);
+            rec.v = (b - r.b0) / (r.b1 - r.b0);
+        }
         outward = V3<R>(r.plane == 2 ? R(1) : R(0), r.plane == 1 ? R(1) : R(0), r.plane == 0 ? R(1) : R(0));
         rec.p = ray.at(t);
         rec.mat = r.mat;
     } else { // PRIM_BOX: the winning face's rectangle record
         const BoxRec<R> bx = sc.boxes[idx];
         const int plane = ref.aux >> 1;
-        R a, b;
-        rect_ab(plane, ray, t, a, b);
-        R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
-        R b0 = plane == 0 ? bx.mn[1] : bx.mn[2], b1 = plane == 0 ? bx.mx[1] : bx.mx[2];
-        rec.u = (a - a0) / (a1 - a0);
-        rec.v = (b - b0) / (b1 - b0);
+        rec.u = R(0); rec.v = R(0);
+        if (uv_is_read(sc, bx.mat)) {
+            R a, b;
+            rect_ab(plane, ray, t, a, b);
+            R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
+            R b0 = plane == 0 ? bx.mn[1] : bx.mn[2], b1 = plane == 0 ? bx.mx[1] : bx.mx[2];
+            rec.u = (a - a0) / (a1 - a0);
+            rec.v = (b - b0) / (b1 - b0);
+        }
         outward = V3<R>(plane == 2 ? R(1) : R(0), plane == 1 ? R(1) : R(0), plane == 0 ? R(1) : R(0));
         rec.p = ray.at(t);
         rec.mat = bx.mat;
@@ -690,7 +700,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         R distance_inside = (t2 - t1) * ray_length;
         R hit_distance = md.neg_inv_density * rt_log(uniform01_log<R>(key, rng_ctr(bounce + 1, SLOT_MEDIUM + uint32_t(m))));
         if (hit_distance > distance_inside) continue;
-        closest = t1 + hit_distance / ray_length;
+        closest = t1 + rt_div(hit_distance, ray_length);
         medium = m;
         found = true;
     }
@@ -837,7 +847,7 @@ RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, 
     }
     // MAT_DIELECTRIC — material.rs:179-203
     att = V3<R>(R(1), R(1), R(1));
-    R ratio = rec.front_face ? R(1) / m.param : m.param;
+    R ratio = rec.front_face ? rt_rcp(m.param) : m.param;
     V3<R> ud = unit(ray.d);
     R cos_theta = rt_min(dot(-ud, rec.normal), R(1));
     R sin_theta = rt_sqrt(R(1) - cos_theta * cos_theta);

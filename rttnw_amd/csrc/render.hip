@@ -1,17 +1,19 @@
 // render.hip — the device half of include/rttnw_hip.h for gfx950 (MI355X).
 //
 // One kernel does the whole per-pixel sample loop of main.rs:202-229:
-//   * persistent workgroups (4 wave64 each) pull JOBS from one global counter.  A job is
-//     (pixel, chunk of `spp_chunk` samples); 64 consecutive jobs are the 64 pixels of one 8x8 tile,
-//     so a wave starts out on a coherent tile.  Idle lanes are counted with __ballot, the wave leader
-//     takes that many jobs with ONE atomic and the lanes pick theirs by popcount rank — lanes never
-//     wait for the longest path in the wave (path lengths run 1..50, the Cornell blocks trap rays).
+//   * persistent workgroups pull JOBS from one global counter.  A job is (pixel, chunk of samples) — rt_types.hpp
+//     plan_chunks, rt_core.hpp job_decode: 64 consecutive jobs are a 2x2 pixel block x 16 chunks, so the lanes of a
+//     wave start nearly the same ray.  Idle lanes are counted with __ballot and pick distinct jobs by popcount rank
+//     out of a batch of 256 job indices the wave reserved with ONE atomic — lanes never wait for the longest path in
+//     the wave (path lengths run 1..50, the Cornell blocks trap rays).
 //   * a lane folds its job's samples sequentially (main.rs:211) with one path per lane: regenerate a
 //     camera ray when the path dies, otherwise do one world.hit + scatter (rt_core.hpp).
 //   * BVH traversal keeps its stack in LDS, interleaved by lane (entry e of lane l at e*blockDim+l:
-//     conflict-free ds_read/ds_write_b32).
+//     conflict-free ds_read/ds_write_b32); small scenes keep the node records there too.
 //   * job sums go to a partial buffer; a resolve kernel adds a pixel's chunks in chunk order, so the
 //     image is bit-identical whatever the scheduling, the grid size or the number of GPUs.
+// Two forms of the loop: trace_kernel_plain (a lane owns a path) and trace_kernel (paths decoupled
+// from lanes through wave-private queues, for trees that live in HBM).
 // No CPU fallback: every entry point needs a HIP device.
 #include "../../include/rttnw_hip.h"
 #include "rt_core.hpp"
@@ -121,8 +123,8 @@ constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH |
 //   * SHADE: as soon as 64 hits are queued the whole wave processes them at full occupancy — media, hit record,
 //     emitted + scatter (rt_core.hpp path_shade) — and pushes the 64 continuation rays.  A path that ended adds its
 //     radiance to its job's sequential sum (main.rs:211-216) and starts the job's next sample; a slot whose job is
-//     finished writes the job's partial sum and takes the next job ((pixel, sample chunk); 64 consecutive jobs =
-//     one 8x8 tile) from the global counter with one wave-aggregated atomic.
+//     finished writes the job's partial sum and takes the next job ((pixel, sample chunk), see job_decode) from the
+//     wave's batch of job indices (one atomic on the global counter per 256 jobs).
 // Results do not depend on any of this scheduling: every draw is keyed by (pixel, sample, bounce), every job is a
 // sequential fold, and the resolve kernel adds a pixel's jobs in chunk order.
 // Re-read a by-value kernel argument from the kernarg segment at its (cold) point of use, so that it does not hold

@@ -171,7 +171,7 @@ struct RenderConsts {
 // decide how long the final lanes of a launch run alone.  Default schedule (user_chunk == 0): 4-sample chunks for
 // the first ~31/32 of the samples, then single-sample chunks — the launch ends on one-sample jobs whatever spp is
 // (with uniform ceil(spp/256) chunks an 8-GPU run at spp 8000 lost 11 % of a rank's throughput to its tail).
-// Short jobs also keep a wave's lanes on the same 8x8 tile: measured on final_scene, main chunks of 16 / 8 / 4 / 2
+// Short jobs also keep a wave's lanes on the same few pixels: measured on final_scene, main chunks of 16 / 8 / 4 / 2
 // samples give 1140 / 1206 / 1245 / 1250 Msamples/s (cornell_box 1589 / 1600 / 1595 / 1582).
 // The main chunk grows if the job count or the buffer of chunk sums (bytes_per_sum each) would get out of hand.
 inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk, uint64_t jobs_per_chunk, uint64_t bytes_per_sum) {

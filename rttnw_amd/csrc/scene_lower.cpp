@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -112,6 +113,7 @@ struct Lowering {
     std::vector<int32_t> tex_index, mat_index; // graph id -> flat index
     int rc = 0;
     const BvhBuilder* builder = nullptr;
+    size_t max_leaf = 4; // records per leaf of the host SAH build (lower_scene picks it)
 
     int fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return code; }
 
@@ -224,7 +226,7 @@ struct Lowering {
             return make_leaf(items[lo].kind, uint32_t(n), first);
         };
         if (n == 1) return make_leaf_here();
-        const bool can_leaf = same_kind && groupable(items[lo].kind) && n <= 4;
+        const bool can_leaf = same_kind && groupable(items[lo].kind) && n <= max_leaf;
 
         // best binned split
         constexpr int NB = 16;
@@ -536,10 +538,24 @@ struct Lowering {
 
 } // namespace
 
+// Leaf size of the host SAH build.  A record test costs 1.5-2.5 node steps in the kernels and its code runs for few
+// lanes at a time, so ONE record per leaf is best (cornell_box: 18 instead of 46 record tests per sample, +14 %) —
+// unless the extra nodes push the tree out of the LDS-resident form of the trace kernel (final_scene: 1406 nodes
+// instead of 891 no longer fit beside the stacks, -14 %).  So: the finest of 1 / 2 / 4 records per leaf whose tree
+// still fits; big scenes (which never fit) take 4 and save a third of the node memory.
+static bool fits_lds_form(const FlatScene& f) {
+    return f.nodes.size() * sizeof(BvhNode) + size_t(f.stack_depth) * 1024 * sizeof(int32_t) <= 160 * 1024;
+}
 int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder) {
-    out = FlatScene();
-    Lowering lw{g, out, err, {}, {}, 0, builder};
-    return lw.run();
+    const bool small = g.objs.size() <= 8192 && builder == nullptr;
+    for (size_t max_leaf : {size_t(1), size_t(2), size_t(4)}) {
+        if (!small && max_leaf != 4) continue;
+        out = FlatScene();
+        Lowering lw{g, out, err, {}, {}, 0, builder, max_leaf};
+        const int rc = lw.run();
+        if (rc != 0 || max_leaf == 4 || fits_lds_form(out)) return rc;
+    }
+    return 0;
 }
 
 } // namespace rt

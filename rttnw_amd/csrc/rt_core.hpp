@@ -202,10 +202,48 @@ RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key) {
 template <typename R> struct SlabRay { // what a ray contributes to every slab test of its walk
     V3<R> inv; // 1 / d
 };
+// f64: the boxes are f32 and only cull, so the f64 kernels test them in f32 too — CONSERVATIVELY, which the f32
+// kernels need not be: origin and 1/d are rounded to f32 once per walk, and every plane distance is widened by a
+// bound on what that rounding can have done to it.  With o32 = o(1+e), inv32 = inv(1+e'), |e|,|e'| <= 2^-24:
+//   t32 = fl(fl(b - o32) inv32) = t (1+E) - (o32 - o) inv (1+E),  |E| <= 3 * 2^-24 + ...  ~ 1.8e-7
+//   |t32 - t| <= 1.8e-7 |t| + 6.0e-8 |o inv|      (t = (b - o) inv exactly, b a float)
+// so near planes move down and far planes up by 2.4e-7 |t32| + slack, slack = 1.2e-7 |o32 inv32|, the range's ends
+// are rounded outward, and NaN / inf (axis-parallel rays) never cull.  A box the exact test would pass always
+// passes: images and hits are those of f64 slab tests, a node step costs about a third (f64 runs at half rate and
+// selects move register pairs).
+template <> struct SlabRay<double> {
+    float o[3], inv[3], slack[3];
+};
 template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     SlabRay<R> sr;
-    sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    if constexpr (sizeof(R) == 8) {
+        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            sr.o[a] = float(oo[a]);
+            sr.inv[a] = float(1.0 / dd[a]);
+            sr.slack[a] = rt_fabs(sr.o[a] * sr.inv[a]) * 1.2e-7f;
+        }
+    } else {
+        sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    }
     return sr;
+}
+RT_HD bool slab_hit(const float* lo, const float* hi, V3<double>, const SlabRay<double>& sr, double tmin, double tmax, double& t_enter) {
+    float lo_t = float(tmin), hi_t = float(tmax);
+    lo_t = __builtin_fmaf(-rt_fabs(lo_t), 2.4e-7f, lo_t); // outward: float() rounds to nearest
+    hi_t = __builtin_fmaf(rt_fabs(hi_t), 2.4e-7f, hi_t);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float t0 = (lo[a] - sr.o[a]) * sr.inv[a], t1 = (hi[a] - sr.o[a]) * sr.inv[a];
+        float n = sr.inv[a] < 0.f ? t1 : t0, f = sr.inv[a] < 0.f ? t0 : t1;
+        n = __builtin_fmaf(-rt_fabs(n), 2.4e-7f, n) - sr.slack[a];
+        f = __builtin_fmaf(rt_fabs(f), 2.4e-7f, f) + sr.slack[a];
+        lo_t = rt_max(n, lo_t); // maxNum / minNum: a NaN plane (0 * inf) drops out
+        hi_t = rt_min(f, hi_t);
+    }
+    t_enter = double(lo_t);
+    return !(hi_t < lo_t);
 }
 template <typename R>
 RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, const SlabRay<R>& sr, R tmin, R tmax, R& t_enter) {
@@ -220,8 +258,7 @@ RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, const SlabRay<R>&
     tmax = rt_min(fz, rt_min(fy, rt_min(fx, tmax)));
     t_enter = tmin;
     // f32: absorb the rounding of (bound - o) * inv and of the 1-2 ulp reciprocal (boxes are already padded)
-    if constexpr (sizeof(R) == 4) return !((tmax > R(0) ? tmax * R(1.0000005) : tmax) < tmin);
-    else return !(tmax < tmin);
+    return !((tmax > R(0) ? tmax * R(1.0000005) : tmax) < tmin);
 }
 
 // ---------------------------------------------------------------- primitive tests: t only

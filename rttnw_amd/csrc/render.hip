@@ -17,7 +17,6 @@
 // No CPU fallback: every entry point needs a HIP device.
 #include "../../include/rttnw_hip.h"
 #include "rt_core.hpp"
-#include "rt_sched.hpp"
 #include "scene_handle.hpp"
 
 #include <hip/hip_runtime.h>
@@ -117,9 +116,9 @@ constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH |
 // global memory; a lane only ever holds a RAY BEING TRAVERSED (origin, direction, closest hit, BVH cursor), so the
 // traversal loop is tight and nothing else is loop-carried.  Two wave-private LDS queues connect the two halves:
 //   * TRAVERSE iteration: lanes without a ray pop one from the ray queue (ranks by __ballot/popcount — the queues are
-//     private to the wave, no atomics), every lane advances its ray by one node / primitive step, lanes whose ray
-//     is finished push (slot, t, primitive) onto the hit queue and are free for the next ray immediately: no lane
-//     waits for the longest traversal in the wave.
+//     private to the wave, no atomics), every lane advances its ray by one walk trip (a few node steps and a leaf
+//     step), lanes whose ray is finished push (slot, t, primitive) onto the hit queue and are free for the next ray:
+//     no lane waits for the longest traversal in the wave.
 //   * SHADE: as soon as 64 hits are queued the whole wave processes them at full occupancy — media, hit record,
 //     emitted + scatter (rt_core.hpp path_shade) — and pushes the 64 continuation rays.  A path that ended adds its
 //     radiance to its job's sequential sum (main.rs:211-216) and starts the job's next sample; a slot whose job is
@@ -170,9 +169,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
     uint32_t ray_n = 0, hit_n = SLOTS_PER_WAVE; // wave-uniform queue fill levels
     unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
 
-    SchedPolicy pol = default_policy();
-    uint32_t served[ST_COUNT] = {0, 0, 0, 0}; // lane-steps per traversal stage so far (wave-uniform)
-    uint32_t iter = 0;
     uint32_t dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     bool has_ray = false;
@@ -305,31 +301,22 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
             }
             ray_n -= take;
         }
-        // A burst of traversal steps: one stage per step, chosen by vote (rt_sched.hpp) — the code of ONE step kind runs,
-        // for all lanes waiting on it; the others keep their cursor.  Only the traversal cursor is loop-carried here.
-        // The burst ends once enough lanes have finished their ray to make the hand-over below worth its cost.
+        // A burst of walk trips (the loop body of closest_solid(), with more node steps per trip: these trees are deep): it
+        // ends once enough lanes have finished their ray to make the hand-over below worth its cost.  (An earlier form
+        // voted, per step, for ONE kind of step — inner node / sphere / box / other — to run for all lanes waiting on it;
+        // the vote cost about as much as a node step, and plain trips beat it: spheres_1m 306 -> 330 Msamples/s,
+        // final_scene through this kernel 916 -> 1084.  Node steps per trip 2 / 3 / 4 / 6: 302 / 321 / 325 / 330.)
         {
             const uint32_t retire_batch = ray_n != 0u ? 16u : 64u;
             if constexpr (COUNT) dbg[8] += 1;
             for (;;) {
-                const uint32_t st = (has_ray && tr.node != TRAV_DONE) ? stage_of(tr.node) : uint32_t(ST_NONE);
-                uint32_t n[ST_COUNT];
+                const bool walking = has_ray && tr.node != TRAV_DONE;
+                if (__ballot(walking) == 0ull) break; // every ray of the wave is finished
+                if (walking) {
 #pragma unroll
-                for (uint32_t k = 0; k < ST_COUNT; ++k) n[k] = uint32_t(__popcll(__ballot(st == k)));
-                if (n[0] + n[1] + n[2] + n[3] == 0u) break; // every ray of the wave is finished
-                const uint32_t pick = sched_pick(n, pol);
-#pragma unroll
-                for (uint32_t k = 0; k < ST_COUNT; ++k)
-                    if (pick == k) { served[k] += n[k]; if constexpr (COUNT) { dbg[k] += 1; dbg[4 + k] += n[k]; } }
-                if ((++iter & 255u) == 0u) adapt_policy(pol, served);
-                if (pick == ST_NODE) { // up to three node steps per vote: a lane still at an inner node goes on at once
-                    if (st == ST_NODE) { // (the vote costs about as much as a node step; measured on spheres_1m, steps per vote 1 / 2 / 3 / 4 / 6: 271 / 298 / 305 / 305 / 301 Msamples/s)
-                        trav_node_step(tr, sc, wray, t_min, stack, cnt);
+                    for (int k = 0; k < 6; ++k)
                         if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
-                        if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
-                    }
-                } else if (st == pick) {
-                    trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
+                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
                 }
                 if (uint32_t(__popcll(__ballot(has_ray && tr.node == TRAV_DONE))) >= retire_batch) break;
             }
@@ -988,11 +975,8 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
                         double(hc.dbg[5]) / hc.dbg[7], double(hc.dbg[6]) / hc.dbg[8], double(hc.dbg[9]) * 64 / stats->samples,
                         double(hc.dbg[10]) / hc.dbg[9], 100.0 * hc.dbg[11] / hc.dbg[9], hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
             } else if (getenv("RTTNW_DEBUG_SCHED")) {
-                static const char* names[] = {"NODE", "SPHERE", "BOX", "MISC"};
                 const double w64 = double(stats->samples) / 64.0;
-                for (int k = 0; k < 4; ++k)
-                    fprintf(stderr, "[sched] %-6s execs/64smp %8.1f  lanes/exec %5.1f\n", names[k], hc.dbg[k] / w64, hc.dbg[k] ? double(hc.dbg[4 + k]) / hc.dbg[k] : 0.0);
-                fprintf(stderr, "[sched] bursts/64smp %.1f  shades/64smp %.2f (lanes %.1f)  refills/64smp %.1f (lanes %.1f)\n", hc.dbg[8] / w64, hc.dbg[9] / w64,
+                fprintf(stderr, "[decoupled] bursts/64smp %.1f  shades/64smp %.2f (lanes %.1f)  refills/64smp %.1f (lanes %.1f)\n", hc.dbg[8] / w64, hc.dbg[9] / w64,
                         hc.dbg[9] ? double(hc.dbg[10]) / hc.dbg[9] : 0.0, hc.dbg[11] / w64, hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
             }
         }

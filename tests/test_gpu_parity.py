@@ -259,3 +259,18 @@ def test_progressive_passes_compose(gpu, scenes_lib, earth):
     _, p_tail = util.params_for(setup, 64, 48, 8, precision=abi.F64, spp_chunk=4, seed=3, sample_begin=4)
     tail, _, _ = gpu_render(gpu, sc, cam, p_tail)
     assert np.abs((seen[0] * 4 + tail * 8) / 12 - whole).max() <= 1e-12 * max(1.0, whole.max())
+
+
+def test_chunk_schedule_boundaries_and_sample_offsets(gpu, oracle, scenes_lib):
+    """The tapered default schedule (4-sample chunks, single-sample chunks for the last 1/32, groups of 16 chunks padded)
+    around its boundaries, explicit chunkings, and a sample range that starts near 2^32."""
+    sg, setup = util.build(gpu, scenes_lib, "cornell_box")
+    so, _ = util.build(oracle, scenes_lib, "cornell_box")
+    for spp, chunk, begin in [(1, 0, 0), (5, 0, 0), (31, 0, 0), (32, 0, 0), (33, 0, 0), (67, 0, 0), (129, 0, 7), (40, 7, 0), (16, 16, 0),
+                              (3, 0, 2**32 - 2)]:
+        cam, p = util.params_for(setup, 19, 11, spp, spp_chunk=chunk, sample_begin=begin, seed=2)
+        lin, rgba, st = gpu_render(gpu, sg, cam, p)
+        lo, ro, _ = rto.render(so, cam, p)
+        assert st.samples == 19 * 11 * spp
+        assert np.abs(lin - lo).max() <= T1_ABS, (spp, chunk, begin)
+        assert np.array_equal(rgba, ro)

@@ -160,7 +160,7 @@ typedef struct rttnw_params {
                             per-pixel sum is chunk sums added in chunk order (deterministic). */
     uint32_t tile_rank;  /* this GPU's rank in the tile partition (0 for a single GPU) */
     uint32_t tile_world; /* number of GPUs sharing the framebuffer (>= 1) */
-    uint32_t collect_counters; /* 1: run the counting kernel variant and fill rttnw_stats (2: plus per-record-kind timing, debugging) */
+    uint32_t collect_counters; /* 1: run the counting kernel variant and fill rttnw_stats (2: plus per-record-kind timing, 3: plus walk-length histograms; debugging) */
     uint32_t sample_begin; /* index of the first sample: this render covers samples [sample_begin, sample_begin + spp) of
                               every pixel and returns THEIR mean.  Draws are keyed by (pixel, sample), so passes over
                               disjoint ranges are independent estimates whose weighted mean is the single render of the

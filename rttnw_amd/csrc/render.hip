@@ -450,11 +450,13 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
             R closest = R(0);
             HitRef best;
             best.prim = 0; best.inst = -1; best.aux = 0;
+            uint32_t my_trips = 0;
             if (alive) {
                 cnt.ray();
                 Trav<R> tr;
                 trav_begin(tr, sc, ps.ray);
                 while (tr.node != TRAV_DONE) {
+                    ++my_trips;
                     // the loop body of closest_solid() (two node steps, then a leaf step for the lanes at a leaf by then), tallied
                     const unsigned long long act = __ballot(true);
                     const bool is_node = tr.node >= 0;
@@ -480,13 +482,26 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
                         prof[8] += lm != 0ull;
                         prof[13] += (unsigned long long)(q1 - q0);
                         prof[14] += (unsigned long long)(q2 - q1b);
-                        if (kmask && rc.profile >= 2u) { // leaf time by the set of record kinds the iteration served: dbg[16+set], count dbg[80+set]
+                        if (kmask && rc.profile == 2u) { // leaf time by the set of record kinds the iteration served: dbg[16+set], count dbg[80+set]
                             atomicAdd(&counters->dbg[16 + kmask], (unsigned long long)(q2 - q1b));
                             atomicAdd(&counters->dbg[80 + kmask], 1ull);
                         }
                     }
                 }
                 found = tr.found; closest = tr.closest; best = tr.best;
+                if (rc.profile == 3u) {
+                    atomicAdd(&counters->dbg[16 + min(my_trips, 63u)], 1ull); // histogram of trips per walk
+                    // ... and trips by what the walk found: 0 miss, 1 + kind (sphere, moving, rect, box), 6 anything inside an instance
+                    const uint32_t cls = !tr.found ? 0u : (tr.best.inst >= 0 ? 6u : 1u + ref_kind(tr.best.prim));
+                    atomicAdd(&counters->dbg[144 + cls], (unsigned long long)my_trips);
+                    atomicAdd(&counters->dbg[152 + cls], 1ull);
+                }
+            }
+            if (rc.profile == 3u) { // ... and of the trips of the wave's longest walk, per round
+                uint32_t mx = my_trips;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx = max(mx, uint32_t(__shfl_xor(int(mx), off, 64)));
+                if (lane == 0) atomicAdd(&counters->dbg[80 + min(mx, 63u)], 1ull);
             }
             tk3 = clock64();
             long long tk3b = tk3;
@@ -971,6 +986,15 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
                                 m & 2 ? "moving " : "", m & 4 ? "rect " : "", m & 8 ? "box " : "", m & 16 ? "instance " : "", m & 32 ? "empty " : "",
                                 100.0 * hc.dbg[80 + m] / hc.dbg[8], 100.0 * hc.dbg[16 + m] / hc.dbg[14], double(hc.dbg[16 + m]) / hc.dbg[80 + m]);
                 fprintf(stderr, "[plain]   node iterations: %.0f clocks each\n", double(hc.dbg[13]) / hc.dbg[7]);
+                if (rc.profile == 3u) { // collect_counters = 3: distribution of walk lengths, in trips
+                    fprintf(stderr, "[plain] trips per walk (lanes):");
+                    for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", hc.dbg[16 + k]);
+                    fprintf(stderr, "\n[plain] walks / mean trips by result (miss, sphere, moving, rect, box, -, in instance):");
+                    for (int k = 0; k < 7; ++k) fprintf(stderr, " %llu / %.1f", hc.dbg[152 + k], hc.dbg[152 + k] ? double(hc.dbg[144 + k]) / hc.dbg[152 + k] : 0.0);
+                    fprintf(stderr, "\n[plain] trips of the longest walk per round (waves):");
+                    for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", hc.dbg[80 + k]);
+                    fprintf(stderr, "\n");
+                }
                 fprintf(stderr, "[plain] node lanes per node iteration %.1f, leaf lanes per leaf iteration %.1f; rounds/sample %.2f, lanes alive per round %.1f; begin in %.0f%% of rounds, %.1f lanes each\n",
                         double(hc.dbg[5]) / hc.dbg[7], double(hc.dbg[6]) / hc.dbg[8], double(hc.dbg[9]) * 64 / stats->samples,
                         double(hc.dbg[10]) / hc.dbg[9], 100.0 * hc.dbg[11] / hc.dbg[9], hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);

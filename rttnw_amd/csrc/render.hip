@@ -137,7 +137,10 @@ template <typename T> __device__ __forceinline__ T kernarg_reload(uint32_t offse
     __builtin_memcpy(&v, p + offset, sizeof(T));
     return v;
 }
-template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; }; // layout of the first three kernel arguments
+// Layout of the first three kernel arguments: the kernarg segment places by-value arguments in order at their natural
+// alignment, which is what this struct does with its members (the GPU parity tests would not survive a mismatch).
+template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; };
+static_assert(alignof(SceneView<float>) <= 8 && alignof(CameraRec<double>) <= 8 && alignof(RenderConsts) <= 8, "kernarg_reload assumes naturally aligned arguments");
 
 template <typename R, bool COUNT>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,

@@ -173,21 +173,40 @@ struct RenderConsts {
 // (with uniform ceil(spp/256) chunks an 8-GPU run at spp 8000 lost 11 % of a rank's throughput to its tail).
 // Short jobs also keep a wave's lanes on the same few pixels: measured on final_scene, main chunks of 16 / 8 / 4 / 2
 // samples give 1140 / 1206 / 1245 / 1250 Msamples/s (cornell_box 1589 / 1600 / 1595 / 1582).
-// The main chunk grows if the job count or the buffer of chunk sums (bytes_per_sum each) would get out of hand.
+// The main chunk grows (and for huge images the schedule falls back to uniform chunks) when the job count or the
+// buffer of chunk sums (bytes_per_sum each) would get out of hand.
 inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk, uint64_t jobs_per_chunk, uint64_t bytes_per_sum) {
     if (user_chunk) {
         rc.spp_chunk = user_chunk;
         rc.n_chunks = rc.n_main = (spp + user_chunk - 1) / user_chunk;
         return;
     }
+    // chunks per pixel the launch can afford: job indices are 32-bit (16 chunks of padding, job_decode), and the chunk
+    // sums of a rank should not take more than 8 GB
+    const uint64_t per = jobs_per_chunk ? jobs_per_chunk : 1;
+    uint64_t max_chunks = ((1ull << 32) - 1) / per;
+    max_chunks = max_chunks > 16 ? max_chunks - 16 : 1;
+    const uint64_t by_bytes = (8ull << 30) / (per * (bytes_per_sum ? bytes_per_sum : 1));
+    if (by_bytes < max_chunks) max_chunks = by_bytes ? by_bytes : 1;
     const uint32_t tail = spp < 32u ? spp : spp / 32u;
-    for (uint32_t m = 4;; m *= 2) {
-        rc.spp_chunk = m;
-        rc.n_main = (spp - tail) / m;
-        rc.n_chunks = rc.n_main + (spp - rc.n_main * m);
-        const uint64_t jobs = jobs_per_chunk * rc.n_chunks;
-        if ((jobs < (1ull << 32) && jobs * bytes_per_sum <= (8ull << 30)) || m >= (1u << 30)) break;
+    for (uint64_t m = 4; m <= spp; m *= 2) {
+        const uint32_t n_main = uint32_t((spp - tail) / m);
+        const uint64_t n_chunks = uint64_t(n_main) + (spp - n_main * m);
+        if (n_chunks <= max_chunks) {
+            rc.spp_chunk = uint32_t(m);
+            rc.n_main = n_main;
+            rc.n_chunks = uint32_t(n_chunks);
+            return;
+        }
     }
+    if (spp <= max_chunks) { // few samples: every chunk one sample
+        rc.spp_chunk = 1;
+        rc.n_chunks = rc.n_main = spp;
+        return;
+    }
+    // an image so large that not even the single-sample tail fits: uniform chunks, as few as the budget allows
+    rc.spp_chunk = uint32_t((spp + max_chunks - 1) / max_chunks);
+    rc.n_chunks = rc.n_main = (spp + rc.spp_chunk - 1) / rc.spp_chunk;
 }
 RT_HD void chunk_samples(const RenderConsts& rc, uint32_t chunk, uint32_t& s, uint32_t& s_end) {
     if (chunk < rc.n_main) {

@@ -192,6 +192,16 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
                                      : render_t<double>(s, cam, p, out_linear, stats, n_threads);
 }
+// The chunk schedule of a render (rt_types.hpp plan_chunks + rt_core.hpp plan_jobs) for the given sizes:
+// out = {spp_chunk, n_main, n_chunks, n_jobs}; returns 0, or -1 when the job count does not fit.
+int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t my_tiles, uint32_t bytes_per_sum, uint32_t* out) {
+    RenderConsts rc{};
+    rc.spp = spp; rc.my_tiles = my_tiles;
+    plan_chunks(rc, spp, user_chunk, uint64_t(my_tiles) * 64, bytes_per_sum);
+    const bool ok = plan_jobs(rc);
+    out[0] = rc.spp_chunk; out[1] = rc.n_main; out[2] = rc.n_chunks; out[3] = rc.n_jobs;
+    return ok ? 0 : -1;
+}
 // Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).
 int hostsim_max_stack() { return g_max_stack.exchange(0); }
 int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, rects, boxes, insts, media, stack_depth */) {

@@ -120,3 +120,22 @@ def test_sample_ranges_compose(hostsim, oracle, scenes_lib):
     mean = sum(n * im for n, im in parts) / 12
     assert np.abs(mean - whole).max() <= 1e-12 * max(1.0, whole.max())
     assert np.abs(parts[0][1] - parts[1][1]).max() > 1e-3  # different samples, different estimates
+
+
+def test_chunk_schedule_covers_every_sample_within_budget(hostsim):
+    """plan_chunks / plan_jobs for small, ordinary and very large renders: the chunks partition [0, spp) exactly, the
+    launch ends on single-sample chunks when it can, job indices stay below 2^32 and the chunk sums below 8 GB."""
+    out = (C.c_uint32 * 4)()
+    cases = [(1, 1), (5, 10), (31, 10), (32, 10), (33, 10), (1000, 10000), (5000, 10000), (8000, 1250), (10000, 5000),
+             (10000, 40000), (100000, 40000), (7, 40000), (1000000, 160000)]
+    for spp, tiles in cases:
+        for bytes_per_sum in (12, 24):
+            assert hostsim.lib.hostsim_plan(spp, 0, tiles, bytes_per_sum, out) == 0, (spp, tiles)
+            chunk, n_main, n_chunks, n_jobs = list(out)
+            covered = n_main * chunk if n_main < n_chunks else min(spp, n_main * chunk)
+            assert covered + (n_chunks - n_main) == spp or (n_main == n_chunks and (n_chunks - 1) * chunk < spp <= n_chunks * chunk), (spp, tiles, list(out))
+            assert n_chunks * tiles * 64 * bytes_per_sum <= 8 * 2**30 + tiles * 64 * bytes_per_sum
+            assert n_jobs >= n_chunks * tiles * 64 and n_jobs < 2**32
+            if spp * tiles * 64 * bytes_per_sum <= 2**30:  # ordinary sizes: the tapered schedule
+                assert chunk in (1, 4) and (n_chunks - n_main >= min(spp, max(1, spp // 32)) or chunk == 1)
+    assert hostsim.lib.hostsim_plan(40, 7, 100, 12, out) == 0 and list(out)[:3] == [7, 6, 6]   # explicit chunking is uniform

@@ -18,6 +18,12 @@ _dp = C.POINTER(C.c_double)
 _PROBES = [
     ("render", C.c_int, [abi.scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_void_p, C.c_void_p,
                          C.POINTER(Stats), C.c_int]),
+    ("render_window", C.c_int, [abi.scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32,
+                                C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_int]),
+    ("render_pixel_list", C.c_int, [abi.scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_uint32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_int]),
+    ("probe_path", C.c_int, [abi.scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32,
+                             _dp, C.c_uint32]),
     ("builder", C.c_void_p, []),
     ("probe_camera", C.c_int, [C.POINTER(CameraDesc), _dp]),
     ("probe_camera_ray", C.c_int, [C.POINTER(CameraDesc), C.c_double, C.c_double, C.c_uint64, C.c_uint64,
@@ -77,3 +83,45 @@ def render(scene, cam, params, n_threads=0, want_rgba8=True):
                   rgba.ctypes.data if rgba is not None else None, C.byref(st), int(n_threads))
     abi.check(rc, b, "rto_render")
     return lin, rgba, st
+
+
+def render_window(scene, cam, params, x0, y0, x1, y1, n_threads=0, want_var=False):
+    """rto_render_window: the pixels [x0, x1) x [y0, y1) of the params.width x params.height render (same keys as the
+    full image) -> (linear hxwx3, rgba8 hxwx4, per-channel variance of the sample radiances hxwx3 or None, Stats)."""
+    b = binding()
+    h, w = y1 - y0, x1 - x0
+    lin = np.zeros((h, w, 3), dtype=np.float64)
+    rgba = np.zeros((h, w, 4), dtype=np.uint8)
+    var = np.zeros((h, w, 3), dtype=np.float64) if want_var else None
+    st = Stats()
+    rc = b.render_window(scene.handle, C.byref(cam), C.byref(params), x0, y0, x1, y1, lin.ctypes.data, rgba.ctypes.data,
+                         var.ctypes.data if var is not None else None, C.byref(st), int(n_threads))
+    abi.check(rc, b, "rto_render_window")
+    return lin, rgba, var, st
+
+
+def render_pixel_list(scene, cam, params, xs, ys, n_threads=0, want_var=False):
+    """rto_render_pixel_list: the pixels (xs[k], ys[k]) of the full-size render -> (linear nx3, rgba8 nx4, variance nx3 or None)."""
+    b = binding()
+    xs = np.ascontiguousarray(xs, dtype=np.uint32)
+    ys = np.ascontiguousarray(ys, dtype=np.uint32)
+    n = len(xs)
+    lin = np.zeros((n, 3), dtype=np.float64)
+    rgba = np.zeros((n, 4), dtype=np.uint8)
+    var = np.zeros((n, 3), dtype=np.float64) if want_var else None
+    rc = b.render_pixel_list(scene.handle, C.byref(cam), C.byref(params), xs.ctypes.data, ys.ctypes.data, n, lin.ctypes.data,
+                             rgba.ctypes.data, var.ctypes.data if var is not None else None, None, int(n_threads))
+    abi.check(rc, b, "rto_render_pixel_list")
+    return lin, rgba, var
+
+
+PROBE_STRIDE = 12
+
+
+def probe_path(scene, cam, params, px, row, sample, max_out=64):
+    """rto_probe_path -> array [n_hits, 12]: t, p(3), normal(3), material id, u, v, front_face, scattered."""
+    b = binding()
+    out = np.zeros((max_out, PROBE_STRIDE), dtype=np.float64)
+    n = b.probe_path(scene.handle, C.byref(cam), C.byref(params), px, row, sample, out.ctypes.data_as(_dp), max_out)
+    abi.check(n, b, "rto_probe_path")
+    return out[:n]

@@ -326,6 +326,10 @@ struct Dielectric : Material { // material.rs:173-204
     bool scatter(const Ray& ray, const HitRecord& rec, const PathCtx& ctx, V3& att, Ray& out) const override {
         att = V3(1.0, 1.0, 1.0);
         double ratio = rec.front_face ? 1.0 / ri : ri;
+        // ORACLE-ONLY experiment switch (tests/test_oracle_png_pins.py): image.png shows its two dielectric spheres as
+        // upright see-through "bubbles" with a reflecting ring, not as the inverting glass balls material.rs:179-203
+        // renders; bit 0x100 evaluates the variant with the two ratios swapped to test that reading of image.png.
+        if (ctx.quirks & 0x100u) ratio = rec.front_face ? ri : 1.0 / ri;
         V3 ud = unit(ray.direction());
         double cos_theta = std::fmin(dot(-ud, rec.normal), 1.);
         double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
@@ -982,11 +986,21 @@ static uint32_t oracle_tile_owner(uint32_t tx, uint32_t ty, uint32_t tiles_x, ui
     return permuted % world;
 }
 
-int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
-               uint8_t* out_rgba8, rttnw_stats* stats, int n_threads) {
+// The per-pixel fold of main.rs:209-226 over an arbitrary set of pixels of the W x H image (same keys and jitter as in
+// the full render): the window [x0, x1) x [y0, y1) when `xs == nullptr` (outputs are (y1-y0) x (x1-x0) arrays), else the
+// n_list pixels (xs[k], ys[k]) (outputs are n_list records).  `out_var` (optional, 3 doubles per pixel): unbiased
+// per-channel variance of the pixel's SAMPLE radiances (what the f32-vs-f64 statistical tier needs for its
+// 6 sigma / sqrt(spp) bound).
+static int render_pixels(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t x0, uint32_t y0, uint32_t x1,
+                         uint32_t y1, const uint32_t* xs, const uint32_t* ys, uint32_t n_list, double* out_linear,
+                         uint8_t* out_rgba8, double* out_var, rttnw_stats* stats, int n_threads) {
     if (!s || !s->world || !cam || !p) return fail(RTTNW_ERR_INVALID, "render: bad arguments");
     if (!p->width || !p->height || !p->spp) return fail(RTTNW_ERR_INVALID, "render: empty image or spp");
-    const uint32_t W = p->width, H = p->height, spp = p->spp;
+    if (!xs && (x0 >= x1 || y0 >= y1 || x1 > p->width || y1 > p->height)) return fail(RTTNW_ERR_INVALID, "render: bad window");
+    if (xs)
+        for (uint32_t k = 0; k < n_list; ++k)
+            if (xs[k] >= p->width || ys[k] >= p->height) return fail(RTTNW_ERR_INVALID, "render: pixel outside the image");
+    const uint32_t W = p->width, H = p->height, spp = p->spp, WW = xs ? n_list : x1 - x0, WH = xs ? 1 : y1 - y0;
     const uint32_t chunk = p->spp_chunk ? p->spp_chunk : spp;
     const uint32_t world = p->tile_world ? p->tile_world : 1;
     const uint32_t tiles_x = (W + 7) / 8;
@@ -996,7 +1010,7 @@ int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
     if (n_threads <= 0) n_threads = 1;
     // work unit = 16 consecutive pixels of a row (finer than the reference's rayon row/column split needs, but it
     // keeps hundreds of host threads busy to the end)
-    const uint32_t SEG = 16, segs_per_row = (W + SEG - 1) / SEG;
+    const uint32_t SEG = 16, segs_per_row = (WW + SEG - 1) / SEG;
     std::atomic<uint32_t> next_unit{0};
     std::vector<Counters> counters(n_threads);
     const List& world_list = *s->world;
@@ -1004,14 +1018,15 @@ int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
         Counters* cnt = p->collect_counters ? &counters[tid] : nullptr;
         for (;;) {
             uint32_t unit = next_unit.fetch_add(1);
-            if (unit >= H * segs_per_row) break;
-            uint32_t r = unit / segs_per_row; // r = 0 is the TOP row == j = height-1 (main.rs:202-205)
-            uint32_t i0 = (unit % segs_per_row) * SEG, i1 = std::min(W, i0 + SEG);
-            uint32_t j = H - 1 - r;
-            for (uint32_t i = i0; i < i1; ++i) {
+            if (unit >= WH * segs_per_row) break;
+            const uint32_t wr = unit / segs_per_row, k0 = (unit % segs_per_row) * SEG, k1 = std::min(WW, k0 + SEG);
+            for (uint32_t k = k0; k < k1; ++k) {
+                const uint32_t i = xs ? xs[k] : x0 + k;
+                const uint32_t r = xs ? ys[k] : y0 + wr; // r = 0 is the TOP row == j = height-1 (main.rs:202-205)
+                const uint32_t j = H - 1 - r;
                 if (world > 1 && oracle_tile_owner(i / 8, r / 8, tiles_x, world) != p->tile_rank) continue;
                 uint64_t pixel = uint64_t(r) * W + i;
-                V3 total(0, 0, 0);
+                V3 total(0, 0, 0), sq(0, 0, 0);
                 for (uint32_t c0 = 0; c0 < spp; c0 += chunk) {
                     V3 acc(0, 0, 0);
                     uint32_t c1 = std::min(spp, c0 + chunk);
@@ -1023,17 +1038,26 @@ int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
                         double u = (double(i) + keyed_uniform(ctx.key, ctr_of(0, SLOT_JITTER_U))) / double(W);
                         double v = (double(j) + keyed_uniform(ctx.key, ctr_of(0, SLOT_JITTER_V))) / double(H);
                         Ray ray = camera.ray(u, v, ctx.key);
-                        acc = acc + color(ray, background, world_list, int(p->max_depth), ctx, p->t_min);
+                        const V3 c = color(ray, background, world_list, int(p->max_depth), ctx, p->t_min);
+                        acc = acc + c;
+                        if (out_var) sq = sq + c * c;
                     }
                     total = total + acc;
                 }
                 V3 mean = total / double(spp);
+                const uint64_t o = uint64_t(wr) * WW + k; // position in the output arrays
                 if (out_linear) {
-                    out_linear[pixel * 3 + 0] = mean.x; out_linear[pixel * 3 + 1] = mean.y; out_linear[pixel * 3 + 2] = mean.z;
+                    out_linear[o * 3 + 0] = mean.x; out_linear[o * 3 + 1] = mean.y; out_linear[o * 3 + 2] = mean.z;
                 }
                 if (out_rgba8) {
-                    out_rgba8[pixel * 4 + 0] = quantise(mean.x); out_rgba8[pixel * 4 + 1] = quantise(mean.y);
-                    out_rgba8[pixel * 4 + 2] = quantise(mean.z); out_rgba8[pixel * 4 + 3] = 255;
+                    out_rgba8[o * 4 + 0] = quantise(mean.x); out_rgba8[o * 4 + 1] = quantise(mean.y);
+                    out_rgba8[o * 4 + 2] = quantise(mean.z); out_rgba8[o * 4 + 3] = 255;
+                }
+                if (out_var) {
+                    const double n = double(spp), d = spp > 1 ? n - 1.0 : 1.0;
+                    out_var[o * 3 + 0] = (sq.x - n * mean.x * mean.x) / d;
+                    out_var[o * 3 + 1] = (sq.y - n * mean.y * mean.y) / d;
+                    out_var[o * 3 + 2] = (sq.z - n * mean.z * mean.z) / d;
                 }
             }
         }
@@ -1044,13 +1068,28 @@ int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
     for (auto& t : threads) t.join();
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        stats->samples = uint64_t(W) * H * spp;
+        stats->samples = uint64_t(WW) * WH * spp;
         for (auto& c : counters) {
             stats->rays += c.rays; stats->nodes_visited += c.nodes; stats->prims_tested += c.prims;
             stats->texel_fetches += c.texels;
         }
     }
     return RTTNW_OK;
+}
+
+int rto_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
+               uint8_t* out_rgba8, rttnw_stats* stats, int n_threads) {
+    if (!p) return fail(RTTNW_ERR_INVALID, "render: bad arguments");
+    return render_pixels(s, cam, p, 0, 0, p->width, p->height, nullptr, nullptr, 0, out_linear, out_rgba8, nullptr, stats, n_threads);
+}
+int rto_render_window(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t x0, uint32_t y0, uint32_t x1,
+                      uint32_t y1, double* out_linear, uint8_t* out_rgba8, double* out_var, rttnw_stats* stats, int n_threads) {
+    return render_pixels(s, cam, p, x0, y0, x1, y1, nullptr, nullptr, 0, out_linear, out_rgba8, out_var, stats, n_threads);
+}
+int rto_render_pixel_list(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, const uint32_t* xs, const uint32_t* ys,
+                          uint32_t n, double* out_linear, uint8_t* out_rgba8, double* out_var, rttnw_stats* stats, int n_threads) {
+    if (!xs || !ys || !n) return fail(RTTNW_ERR_INVALID, "render_pixel_list: empty list");
+    return render_pixels(s, cam, p, 0, 0, 0, 0, xs, ys, n, out_linear, out_rgba8, out_var, stats, n_threads);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1189,7 +1228,8 @@ int rto_probe_sample(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     return RTTNW_OK;
 }
 
-// Per-bounce trace of one sample: out[b*8 + (0..7)] = t, p(3), normal(3), material id; returns #hits.
+// Per-bounce trace of one sample (the CPU twin of rttnw_debug_probe_path): out[b*12 + ..] = [0] t, [1..3] p, [4..6] normal,
+// [7] material id (graph object id), [8] u, [9] v, [10] front_face, [11] scattered (1) / absorbed (0); returns #hits.
 int rto_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
                    uint32_t sample, double* out, uint32_t max_out) {
     if (!s || !s->world || !cam || !p || !out) return fail(RTTNW_ERR_INVALID, "probe_path: bad arguments");
@@ -1204,12 +1244,14 @@ int rto_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     for (uint32_t depth = p->max_depth; depth > 0 && n < max_out; --depth) {
         HitRecord rec;
         if (!s->world->hit(ray, p->t_min, std::numeric_limits<double>::max(), ctx, rec)) break;
-        double* o = out + size_t(n) * 8;
+        double* o = out + size_t(n) * 12;
         o[0] = rec.t; o[1] = rec.p.x; o[2] = rec.p.y; o[3] = rec.p.z; o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z;
         o[7] = double(rec.material->id);
+        o[8] = rec.u; o[9] = rec.v; o[10] = rec.front_face ? 1.0 : 0.0; o[11] = 0.0;
         ++n;
         V3 att; Ray sc;
         if (!rec.material->scatter(ray, rec, ctx, att, sc)) break;
+        o[11] = 1.0;
         ray = sc;
         ctx.bounce += 1;
     }

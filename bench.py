@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the per-pixel sample loop on final_scene 800x800 spp=1000 (BASELINE.json).
 
-A "step" is one pass of the hot path over one batch: one full render of the workload (trace kernel +
+A "step" is one pass of the hot path over one batch: one full render of the workload (trace kernel(s) +
 resolve + tile gather to rank 0 + un-tile/quantise), with the scene already resident in HBM.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; the 8x8-tile partition of the framebuffer is interleaved over the ranks, every
-rank traces its own tiles (no data-path collective), one RCCL gather brings the packed tiles to rank 0.
-Weak scaling: per-GPU work is fixed — spp grows with N (spp = 1000 N on the same 800x800 image), so the
-job is N x 640 Msamples.  value = samples of all ranks / max-over-ranks time.
+Arithmetic: the F64 kernels by default — the reference is f64 end to end (src/math/vec3.rs:12); the F32
+(throughput) kernels are timed beside them and reported under "f32_kernels".
+
+N = 1 (default): BASELINE.json's metric config, final_scene 800x800 spp=1000.
+N > 1: one process per GPU; the 8x8-tile partition of the framebuffer is interleaved over the ranks, every rank
+traces its own tiles (no data-path collective), one RCCL gather brings the packed tiles to rank 0.  The workload
+is BASELINE configs[3]'s frame, final_scene 1600x1600, at spp = 1250 x N: per-GPU work is fixed (weak scaling:
+3200 Msamples per GPU and step) and the N = 8 point IS configs[3] (1600x1600 spp=10000 tile-sharded across 8).
+value = samples of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant (trace) kernel against HBM with the counted
 algorithmic bytes of SURVEY.md §8(d); `cpu_baseline` times the CPU oracle (a port of the reference: the
 Rust reference cannot be built here) on the host cores for a bounded sample of the same workload.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,16 +34,48 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
-    # name: (scene, width, height, spp, param)
-    "final_scene": ("final_scene", 800, 800, 1000, 0),      # BASELINE.json metric / configs[2] headline
-    "cornell_box": ("cornell_box", 800, 800, 1000, 0),      # configs[1]
-    "spheres_1m": ("spheres_1m", 1024, 1024, 256, 0),       # configs[4]
+    # name: (scene, width, height, spp per GPU, param)
+    "final_scene": ("final_scene", 800, 800, 1000, 0),          # BASELINE.json metric / configs[2] headline
+    "cornell_box": ("cornell_box", 800, 800, 1000, 0),          # configs[1]
+    "spheres_1m": ("spheres_1m", 1024, 1024, 256, 0),           # configs[4]
+    "final_scene_1600": ("final_scene", 1600, 1600, 1250, 0),   # configs[3] when run on 8 GPUs (spp = 1250 x N)
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PROFILE_ROUND = "r02"
+KERNEL_SOURCES = ["rttnw_amd/csrc/render.hip", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp", "rttnw_amd/csrc/Makefile"]
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def kernel_source_sha():
+    """Identifies the kernel sources a PMC summary was collected with (profiles/collect_pmc.sh records it)."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(scene_name, precision_name):
+    """HBM traffic of one launch of the dominant kernel.  PMC counters can only be collected under rocprofv3, so the
+    figure comes from the committed summary of `profiles/collect_pmc.sh` for this workload and kernel (FETCH_SIZE x 2
+    per the gfx950 correction + WRITE_SIZE, both in KB) — and only while that summary was collected with the kernel
+    sources of THIS tree (its `kernel_source_sha` line); otherwise null."""
+    pmc = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_%s_%s.txt" % (scene_name, precision_name))
+    if not os.path.exists(pmc):
+        return None, None
+    vals, sha = {}, None
+    for line in open(pmc):
+        f = line.split()
+        if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[f[0]] = float(f[1])
+        if len(f) >= 2 and f[0] == "kernel_source_sha":
+            sha = f[1]
+    if len(vals) != 2 or sha != kernel_source_sha():
+        return None, None
+    return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), "profiles/%s/%s" % (PROFILE_ROUND, os.path.basename(pmc))
 
 
 def main():
@@ -45,13 +83,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="final_scene", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: final_scene (800x800 spp=1000) on one GPU, final_scene_1600 (spp = 1250 x N) on N > 1")
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64"])
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU)")
     ap.add_argument("--size", type=int, default=0, help="override width = height")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--counter-spp", type=int, default=8)
-    ap.add_argument("--no-f64", action="store_true", help="skip the one-step F64 cross-check line")
+    ap.add_argument("--no-other", action="store_true", help="skip the timing of the other precision's kernels")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder at commit: host binned SAH (default) or device LBVH")
     args = ap.parse_args()
 
@@ -89,7 +128,8 @@ def main():
     if gpu.device_count() < 1:
         raise RuntimeError("bench: no HIP device (no CPU fallback in the product path)")
     scenes = library.scenes()
-    scene_name, W, H, spp1, param = WORKLOADS[args.workload]
+    workload = args.workload or ("final_scene" if world == 1 else "final_scene_1600")
+    scene_name, W, H, spp1, param = WORKLOADS[workload]
     if args.size:
         W = H = args.size
     if args.spp:
@@ -102,64 +142,81 @@ def main():
     sc, setup = util.build(gpu, scenes, scene_name, earth, param, bvh=abi.BVH_DEVICE_LBVH if args.bvh == "lbvh" else None)
     build_s = time.time() - t0
     binfo = sc.build_info()
-    cam, p = util.params_for(setup, W, H, spp, precision=precision, tile_rank=rank, tile_world=world, seed=1)
     info = abi.Stats()
     gpu.scene_info(sc.handle, info)
 
-    # ---- counted algorithmic bytes per sample (untimed, counting kernel variant, this rank's tiles)
-    pc = util.params_for(setup, W, H, args.counter_spp, precision=precision, tile_rank=rank, tile_world=world,
-                         seed=1, collect_counters=1)[1]
-    rc_ = render.DeviceRenderer(sc, cam, pc)
-    st = abi.Stats()
-    rc_.trace(st)
-    n = max(1, st.samples)
-    per_sample = dict(rays=st.rays / n, nodes=st.nodes_visited / n, prims=st.prims_tested / n, texels=st.texel_fetches / n)
-    b_alg = 32.0 * per_sample["nodes"] + 32.0 * per_sample["prims"] + 4.0 * per_sample["texels"] + 16.0 / spp
-    del rc_
+    def counted(prec):
+        """Algorithmic bytes per sample, counted by the counting kernel variant on this rank's tiles (untimed).
+        A BVH node visit is priced at the 32-B accounting record of BASELINE.md although the node records here are 64 B
+        and hold both children's boxes (one visit = one record fetch = two box tests)."""
+        cam_c, pc = util.params_for(setup, W, H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, collect_counters=1)
+        rc_ = render.DeviceRenderer(sc, cam_c, pc)
+        st = abi.Stats()
+        rc_.trace(st)
+        n = max(1, st.samples)
+        per = dict(rays=st.rays / n, nodes=st.nodes_visited / n, prims=st.prims_tested / n, texels=st.texel_fetches / n)
+        return 32.0 * per["nodes"] + 32.0 * per["prims"] + 4.0 * per["texels"] + 16.0 / spp, per, st.reserved
 
-    # ---- timed region
-    r = render.DeviceRenderer(sc, cam, p)
-    for _ in range(args.warmup):
-        r.step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()          # HIP events on the stream the trace kernel is launched on
-        r.trace()
-        ev[k][1].record()
-        r.collect()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
-    ms_per_step = elapsed * 1e3 / max(1, args.steps)
-    if use_dist:
-        t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms_per_step, kernel_ms = float(t[0]), float(t[1])
+    def timed(prec, steps, warmup):
+        """`steps` timed steps after `warmup` untimed ones: (ms_per_step over the barrier-bracketed region, mean device
+        time of the trace kernel(s) per step from the library's HIP events on the launch stream)."""
+        cam_t, p = util.params_for(setup, W, H, spp, precision=prec, tile_rank=rank, tile_world=world, seed=1)
+        r = render.DeviceRenderer(sc, cam_t, p)
+        for _ in range(warmup):
+            r.step()
+        st = abi.Stats()
+        kms = []
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.trace(st)             # rttnw_stats.kernel_ms: hipEvents around the trace kernel launch(es) on their own stream
+            kms.append(st.kernel_ms)
+            r.collect()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        ms_per_step = elapsed * 1e3 / max(1, steps)
+        kernel_ms = float(np.mean(kms)) if kms else 0.0
+        if use_dist:
+            t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_per_step, kernel_ms = float(t[0]), float(t[1])
+        del r
+        return ms_per_step, kernel_ms
 
     samples_total = float(W) * H * spp          # all ranks together
     samples_rank = samples_total / world
-    value = samples_total / (ms_per_step * 1e-3) / 1e6
-    achieved = b_alg * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
-    # ---- the same workload through the F64 kernels (the reference's arithmetic type), one step, N = 1 only
-    f64 = None
-    if world == 1 and precision == abi.F32 and not args.no_f64:
-        cam64, p64 = util.params_for(setup, W, H, spp, precision=abi.F64, seed=1)
-        r64 = render.DeviceRenderer(sc, cam64, p64)
-        r64.step()
-        torch.cuda.synchronize()
-        tq = time.perf_counter()
-        r64.step()
-        torch.cuda.synchronize()
-        dq = time.perf_counter() - tq
-        f64 = {"value": round(samples_total / dq / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dq * 1e3, 3), "steps": 1}
-        del r64
+    def roofline(prec, kernel_ms):
+        b_alg, per, form = counted(prec)
+        achieved = b_alg * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        pname = "f32" if prec == abi.F32 else "f64"
+        traffic, traffic_src = (committed_traffic(scene_name, pname) if world == 1 and not args.spp and not args.size else (None, None))
+        return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if form == 0 else "", "float" if prec == abi.F32 else "double"),
+                "kernel_ms": round(kernel_ms, 3), "alg_bytes_per_sample": round(b_alg, 2),
+                "alg_bytes_per_launch": round(b_alg * samples_rank),
+                "per_sample": {k: round(v, 3) for k, v in per.items()},
+                "note": "scene is L2/MALL-resident; achieved = counted algorithmic bytes / kernel time; a node visit is priced at 32 B "
+                        "(BASELINE.md) although a node record is 64 B (both children's boxes)"}
+
+    # ---- timed region (the reported precision)
+    ms_per_step, kernel_ms = timed(precision, args.steps, args.warmup)
+    value = samples_total / (ms_per_step * 1e-3) / 1e6
+    roof = roofline(precision, kernel_ms)
+
+    # ---- the same workload through the other precision's kernels, its own multi-step timing
+    other = None
+    if not args.no_other:
+        oprec = abi.F32 if precision == abi.F64 else abi.F64
+        osteps = max(1, min(args.steps, 5))
+        oms, okms = timed(oprec, osteps, 1)
+        other = {"value": round(samples_total / (oms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(oms, 3),
+                 "steps": osteps, "warmup": 1, "roofline": roofline(oprec, okms)}
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample
     cpu = None
@@ -180,21 +237,6 @@ def main():
                "sample": "%s %dx%d spp=%d (%.1f s), f64 CPU oracle (reference-shaped: list scan + reference BVH builder)"
                          % (scene_name, W, H, cspp, dt)}
 
-    # HBM traffic of one launch of the dominant kernel: PMC counters can only be collected under rocprofv3, so the
-    # figure is read from the committed summary of `profiles/collect_pmc.sh` for this workload and kernel
-    # (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, both in KB), or null when there is none.
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_%s_%s.txt" % (scene_name, args.precision))
-    if world == 1 and not args.spp and not args.size and os.path.exists(pmc):
-        vals = {}
-        for line in open(pmc):
-            f = line.split()
-            if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals[f[0]] = float(f[1])
-        if len(vals) == 2:
-            traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
-            traffic_src = "profiles/r01/" + os.path.basename(pmc)
-
     if rank == 0:
         out = {
             "metric": "Msamples/sec on final_scene 800x800 spp=1000; achieved HBM GB/s vs peak",
@@ -207,15 +249,9 @@ def main():
                        "scene_nodes": info.n_nodes, "scene_prims": info.n_prims, "scene_bytes_f32": info.scene_bytes,
                        "scene_build_s": round(build_s, 3), "bvh_builder": args.bvh, "bvh_lower_ms": round(binfo.lower_ms, 2),
                        "bvh_device_ms": round(binfo.device_ms, 3), "stack_depth": binfo.stack_depth},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if st.reserved == 0 else "", "float" if precision == abi.F32 else "double"),
-                         "kernel_ms": round(kernel_ms, 3),
-                         "alg_bytes_per_sample": round(b_alg, 2),
-                         "per_sample": {k: round(v, 3) for k, v in per_sample.items()},
-                         "note": "scene is L2/MALL-resident; achieved = counted algorithmic bytes / kernel time"},
+            "roofline": roof,
             "cpu_baseline": cpu,
-            "f64_kernels": f64,
+            ("f32_kernels" if precision == abi.F64 else "f64_kernels"): other,
         }
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -949,7 +949,9 @@ rttnw_id rto_constant_medium(rttnw_scene* s, rttnw_id boundary, double density, 
     m->phase_function->albedo = t;
     m->neg_inv_density = -1. / density; // hittable.rs:733
     m->medium_index = s->n_media++;
-    return push_hit(s, m);
+    const rttnw_id id = push_hit(s, m);
+    m->phase_function->id = id; // probes report the medium's own object id for its phase function (created in place, hittable.rs:733)
+    return id;
 }
 int rto_scene_set_world(rttnw_scene* s, rttnw_id world) {
     if (!s || world < 0 || size_t(world) >= s->objs.size() || s->objs[world].kind != rttnw_scene::LIST ||

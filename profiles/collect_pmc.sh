@@ -7,7 +7,7 @@ mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-f64 $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-other $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
 }
 BENCH_ARGS="$*"
 if [ -n "$PMC_QUICK" ]; then
@@ -26,10 +26,13 @@ run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 run tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
 fi
 # summarise: counter values of the trace kernel dispatches
-python3 - "$ROOT/$OUT" <<'PY'
+python3 - "$ROOT/$OUT" "$ROOT" <<'PY'
 import csv, glob, os, re, sys, collections
 out = sys.argv[1]
+sys.path.insert(0, sys.argv[2])
+import bench
 summ = collections.OrderedDict()
+summ["kernel_source_sha"] = [bench.kernel_source_sha()]   # bench.py reports `traffic` from this file only while the kernel sources are these
 for d in sorted(glob.glob(os.path.join(out, "*"))):
     if not os.path.isdir(d): continue
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

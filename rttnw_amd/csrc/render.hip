@@ -556,12 +556,15 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
     }
 }
 
-// Sum a pixel's chunk partials in chunk order, divide by spp (main.rs:217): packed pixel records
-// (r, g, b, 1).  Pad tiles (>= my_tiles) are zero-filled.
+// Sum a pixel's chunk partials of ONE PASS in chunk order and add them to the pixel's running sum (pass 0 starts it);
+// the last pass divides by the render's spp (main.rs:217): packed pixel records (r, g, b, 1).  Pad tiles
+// (>= my_tiles) are zero-filled.  The running sum lives in `packed` itself.
 template <typename R>
-__global__ void resolve_kernel(const R* __restrict__ partial, R* __restrict__ packed, RenderConsts rc, uint32_t pixels_per_rank) {
+__global__ void resolve_kernel(const R* __restrict__ partial, R* __restrict__ packed, RenderConsts rc, uint32_t pixels_per_rank,
+                               uint32_t first_pass, uint32_t last_pass, uint32_t total_spp) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= pixels_per_rank) return;
+    R* dst = packed + (unsigned long long)p * 4ull;
     R r = 0, g = 0, b = 0, a = 0;
     const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
     if (p < jobs_per_chunk) {
@@ -569,11 +572,13 @@ __global__ void resolve_kernel(const R* __restrict__ partial, R* __restrict__ pa
             const R* src = partial + ((unsigned long long)c * jobs_per_chunk + p) * 3ull;
             r = r + src[0]; g = g + src[1]; b = b + src[2];
         }
-        const R spp = R(rc.spp);
-        r = r / spp; g = g / spp; b = b / spp;
-        a = R(1);
+        if (!first_pass) { r = dst[0] + r; g = dst[1] + g; b = dst[2] + b; }
+        if (last_pass) {
+            const R spp = R(total_spp);
+            r = r / spp; g = g / spp; b = b / spp;
+            a = R(1);
+        }
     }
-    R* dst = packed + (unsigned long long)p * 4ull;
     dst[0] = r; dst[1] = g; dst[2] = b; dst[3] = a;
 }
 
@@ -805,17 +810,18 @@ int device_commit(::rttnw_scene* s, std::string& err) {
         err = "no HIP device available (this library has no CPU fallback)";
         return RTTNW_ERR_HIP;
     }
+    if (s->device) { device_release(s->device); s->device = nullptr; } // a commit that failed half-way and is retried
     DeviceState* d = new DeviceState();
-    s->device = d;
     hipError_t e = hipGetDevice(&d->device);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, d->device);
-    if (e != hipSuccess) { err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return RTTNW_ERR_HIP; }
+    if (e != hipSuccess) { err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); device_release(d); return RTTNW_ERR_HIP; }
     d->num_cus = prop.multiProcessorCount;
     e = hipMalloc((void**)&d->job_counter, sizeof(unsigned long long) + sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipEventCreate(&d->ev0);
     if (e == hipSuccess) e = hipEventCreate(&d->ev1);
-    if (e != hipSuccess) { err = std::string("device_commit: ") + hipGetErrorString(e); return RTTNW_ERR_HIP; }
+    if (e != hipSuccess) { err = std::string("device_commit: ") + hipGetErrorString(e); device_release(d); return RTTNW_ERR_HIP; }
+    s->device = d;
     // The scene arrays are uploaded per precision on first use (render), see ensure_scene().
     return 0;
 }
@@ -847,6 +853,9 @@ static int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_
     if (!p->width || !p->height || !p->spp || !p->max_depth) { set_last_error("render: empty image, spp or depth"); return RTTNW_ERR_INVALID; }
     if (p->precision != RTTNW_F32 && p->precision != RTTNW_F64) { set_last_error("render: bad precision"); return RTTNW_ERR_INVALID; }
     if (p->tile_world == 0 || p->tile_rank >= p->tile_world) { set_last_error("render: bad tile_rank / tile_world"); return RTTNW_ERR_INVALID; }
+    // the decoupled kernel packs a pixel as px | row << 16, and the free-flight draw of medium m uses RNG slot m < 16
+    if (p->width > 65535u || p->height > 65535u) { set_last_error("render: width and height are limited to 65535"); return RTTNW_ERR_UNSUPPORTED; }
+    if (s->flat.media.size() > SLOT_DIELECTRIC) { set_last_error("render: more than 16 constant media"); return RTTNW_ERR_UNSUPPORTED; }
     // moving-sphere bounds are built for the shutter interval [0,1] (BvhTree::from, hittable.rs:256)
     if (cam->open_time < 0.0 || cam->close_time > 1.0 || cam->open_time > cam->close_time) {
         set_last_error("render: shutter interval must lie inside [0,1]");
@@ -874,11 +883,10 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     rc.profile = p->collect_counters;
     rc.sample_begin = p->sample_begin;
-    plan_chunks(rc, p->spp, p->spp_chunk, uint64_t(rc.my_tiles) * 64, 3 * sizeof(R));
-    if (!plan_jobs(rc)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
-    const size_t n_jobs = rc.n_jobs;
     rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
-    if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(size_t(rc.jobs_per_chunk) * rc.n_chunks, 1) * 3 * sizeof(R))) return g;
+    // Passes over consecutive sample ranges (rt_types.hpp plan_passes): one for ordinary renders; more when the chunk
+    // sums of the whole render would not fit the workspace budget.  Decided by the image size and spp alone.
+    const uint32_t n_pass = plan_passes(p->spp, p->spp_chunk, uint64_t(L.n_tiles) * 64, 3 * sizeof(R));
 
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
@@ -906,55 +914,70 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
         grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + 3) / 4));
         return 0;
     };
-    if (plain) {
-        // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
-        // 1024 threads (4 waves/SIMD at <= 128 VGPRs) for f32, 512 threads (2 waves/SIMD, all the 256-VGPR f64 code allows)
-        constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : 512;
-        const size_t node_bytes = s->flat.nodes.size() * sizeof(BvhNode);
-        const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) &&
-                              node_bytes + size_t(rc.stack_depth) * LDS_BLOCK * 4 <= 160 * 1024;
-        rc.lds_nodes = want_lds ? uint32_t(s->flat.nodes.size()) : 0u;
-        const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
-        const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true>)
-                                      : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false>);
-        const size_t lds_bytes = (want_lds ? node_bytes : 0) + size_t(rc.stack_depth) * block * sizeof(int32_t);
-        if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
-        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
-        int blocks_per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, lds_bytes));
-        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
-        const size_t waves_per_block = size_t(block) / 64;
-        const size_t grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, ((n_jobs + 63) / 64 + waves_per_block - 1) / waves_per_block));
-        if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
-        if (n_jobs > 0) {
-            R bg0 = R(p->background[0]), bg1 = R(p->background[1]), bg2 = R(p->background[2]), tmin = R(p->t_min);
-            R* part = (R*)d->partial;
-            unsigned long long* jc = d->job_counter;
-            SceneView<R> view = ds.view;
-            CameraRec<R> camv = camr;
-            void* args[] = {&view, &camv, &rc, &bg0, &bg1, &bg2, &tmin, &part, &jc, &dc};
-            HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
+    // One pass: trace kernel over the pass's jobs, then the resolve step.
+    auto trace_pass = [&]() -> int {
+        const size_t n_jobs = rc.n_jobs;
+        if (plain) {
+            // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
+            // 1024 threads (4 waves/SIMD at <= 128 VGPRs) for f32, 512 threads (2 waves/SIMD, all the 256-VGPR f64 code allows)
+            constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : 512;
+            const size_t node_bytes = s->flat.nodes.size() * sizeof(BvhNode);
+            const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) &&
+                                  node_bytes + size_t(rc.stack_depth) * LDS_BLOCK * 4 <= 160 * 1024;
+            rc.lds_nodes = want_lds ? uint32_t(s->flat.nodes.size()) : 0u;
+            const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
+            const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true>)
+                                          : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false>);
+            const size_t lds_bytes = (want_lds ? node_bytes : 0) + size_t(rc.stack_depth) * block * sizeof(int32_t);
+            if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
+            HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+            int blocks_per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, lds_bytes));
+            blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+            const size_t waves_per_block = size_t(block) / 64;
+            const size_t grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, ((n_jobs + 63) / 64 + waves_per_block - 1) / waves_per_block));
+            if (n_jobs > 0) {
+                R bg0 = R(p->background[0]), bg1 = R(p->background[1]), bg2 = R(p->background[2]), tmin = R(p->t_min);
+                R* part = (R*)d->partial;
+                unsigned long long* jc = d->job_counter;
+                SceneView<R> view = ds.view;
+                CameraRec<R> camv = camr;
+                void* args[] = {&view, &camv, &rc, &bg0, &bg1, &bg2, &tmin, &part, &jc, &dc};
+                HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
+            }
+        } else {
+            auto kernel = count ? trace_kernel<R, true> : trace_kernel<R, false>;
+            const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
+            size_t grid = 1;
+            if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
+            const size_t n_slots = grid * (TRACE_BLOCK / 64) * SLOTS_PER_WAVE;
+            if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
+            if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
+            if (n_jobs > 0) {
+                hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
+                                   R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
+                                   (uint32_t*)d->pool_u, uint32_t(n_slots));
+                HIP_TRY(hipGetLastError());
+            }
         }
-    } else {
-        auto kernel = count ? trace_kernel<R, true> : trace_kernel<R, false>;
-        const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
-        size_t grid = 1;
-        if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
-        const size_t n_slots = grid * (TRACE_BLOCK / 64) * SLOTS_PER_WAVE;
-        if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
-        if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
-        if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
-        if (n_jobs > 0) {
-            hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
-                               R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
-                               (uint32_t*)d->pool_u, uint32_t(n_slots));
-            HIP_TRY(hipGetLastError());
-        }
+        return 0;
+    };
+    if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
+    for (uint32_t k = 0; k < n_pass; ++k) {
+        const uint32_t s0 = pass_begin(p->spp, n_pass, k), s1 = pass_begin(p->spp, n_pass, k + 1);
+        rc.spp = s1 - s0;                          // this pass's samples; the kernels see a render of [sample_begin, +spp)
+        rc.sample_begin = uint64_t(p->sample_begin) + s0;
+        plan_chunks(rc, rc.spp, p->spp_chunk, uint64_t(L.n_tiles) * 64, 3 * sizeof(R)); // whole image: the same schedule on every rank
+        if (!plan_jobs(rc)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
+        if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(size_t(rc.jobs_per_chunk) * rc.n_chunks, 1) * 3 * sizeof(R))) return g;
+        if (k) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long), stream)); // the job counter only: statistics add up
+        if (int g = trace_pass()) return g;
+        if (stats && k + 1 == n_pass) HIP_TRY(hipEventRecord(d->ev1, stream));
+        hipLaunchKernelGGL(resolve_kernel<R>, dim3((L.pixels_per_rank + 255) / 256), dim3(256), 0, stream, (const R*)d->partial,
+                           (R*)d_packed, rc, L.pixels_per_rank, uint32_t(k == 0), uint32_t(k + 1 == n_pass), p->spp);
+        HIP_TRY(hipGetLastError());
     }
-    if (stats) HIP_TRY(hipEventRecord(d->ev1, stream));
-    hipLaunchKernelGGL(resolve_kernel<R>, dim3((L.pixels_per_rank + 255) / 256), dim3(256), 0, stream, (const R*)d->partial,
-                       (R*)d_packed, rc, L.pixels_per_rank);
-    HIP_TRY(hipGetLastError());
+    rc.spp = p->spp;
 
     if (stats) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -1029,21 +1052,20 @@ int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
                 cam->focus_distance, cam->open_time, cam->close_time, cam64);
-    double* d_out = nullptr;
-    int32_t* d_n = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_out, (size_t(max_out) * PROBE_STRIDE + 4) * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&d_n, sizeof(int32_t)));
-    HIP_TRY(hipMemset(d_n, 0, sizeof(int32_t)));
+    DevBuf<double> d_out; // released on every exit path
+    DevBuf<int32_t> d_n;
+    if (int r = d_out.upload(std::vector<double>(size_t(max_out) * PROBE_STRIDE + 4, 0.0))) return r;
+    if (int r = d_n.upload(std::vector<int32_t>(1, 0))) { d_out.release(); return r; }
+    struct Release { DevBuf<double>& a; DevBuf<int32_t>& b; ~Release() { a.release(); b.release(); } } release{d_out, d_n};
     const size_t lds = size_t(rc.stack_depth) * 64 * sizeof(int32_t);
     hipLaunchKernelGGL(probe_path_kernel<R>, dim3(1), dim3(64), lds, 0, ds.view, narrow_camera<R>(cam64), rc, R(p->t_min), px, row,
-                       sample, d_out, max_out, d_n);
+                       sample, d_out.p, max_out, d_n.p);
     HIP_TRY(hipGetLastError());
     int32_t n = 0;
-    HIP_TRY(hipMemcpy(&n, d_n, sizeof(n), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out, d_out, size_t(n) * PROBE_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&n, d_n.p, sizeof(n), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out.p, size_t(n) * PROBE_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
     // radiance of the sample (path_step loop) is returned after the last possible bounce record
-    HIP_TRY(hipMemcpy(out + size_t(max_out) * PROBE_STRIDE, d_out + size_t(max_out) * PROBE_STRIDE, 4 * sizeof(double), hipMemcpyDeviceToHost));
-    (void)hipFree(d_out); (void)hipFree(d_n);
+    HIP_TRY(hipMemcpy(out + size_t(max_out) * PROBE_STRIDE, d_out.p + size_t(max_out) * PROBE_STRIDE, 4 * sizeof(double), hipMemcpyDeviceToHost));
     return n;
 }
 
@@ -1098,7 +1120,10 @@ int rttnw_render_tiles_device(rttnw_scene* s, const rttnw_camera_desc* cam, cons
 
 int rttnw_untile_device(uint32_t width, uint32_t height, uint32_t world, uint32_t precision, const void* d_gathered,
                         void* d_linear_rgb, uint8_t* d_rgba8, void* hip_stream) {
-    if (!width || !height || !world || !d_gathered) { rt::set_last_error("untile_device: bad arguments"); return RTTNW_ERR_INVALID; }
+    if (!width || !height || !world || !d_gathered || (precision != RTTNW_F32 && precision != RTTNW_F64)) {
+        rt::set_last_error("untile_device: bad arguments");
+        return RTTNW_ERR_INVALID;
+    }
     rttnw_tile_layout L;
     rt::fill_layout(width, height, world, L);
     dim3 block(32, 8), grid((width + 31) / 32, (height + 7) / 8);

@@ -6,6 +6,7 @@
 // that a lane's traversal is a loop over 64-byte node records and 16..64-byte primitive records.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -156,7 +157,7 @@ struct RenderConsts {
     uint32_t tiles_x, tiles_y, n_tiles;
     uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
     uint32_t quirks;
-    uint32_t sample_begin; // index of the render's first sample (rttnw_params::sample_begin)
+    uint32_t pad_sb;
     uint32_t stack_depth;
     FastDiv div_jobs_per_group, div_tiles_x; // job index -> (chunk, tile, pixel) without integer division (job_decode)
     uint32_t jobs_per_chunk;                 // my_tiles * 64: the sums of chunk c start at c * jobs_per_chunk
@@ -164,6 +165,7 @@ struct RenderConsts {
     uint32_t profile;   // counting variant: 2 = also bucket the leaf clock by record kinds (atomics: perturbs the other clocks)
     uint32_t lds_nodes; // lane-owns-path kernel: number of BVH nodes resident in LDS (0 = nodes read from global memory)
     uint64_t seed;
+    uint64_t sample_begin; // index of the first sample of this launch (rttnw_params::sample_begin + the pass's offset)
 };
 
 // A pixel's samples are split into CHUNKS; a job = (pixel, chunk) folds its samples sequentially (main.rs:211-216) and
@@ -174,19 +176,35 @@ struct RenderConsts {
 // Short jobs also keep a wave's lanes on the same few pixels: measured on final_scene, main chunks of 16 / 8 / 4 / 2
 // samples give 1140 / 1206 / 1245 / 1250 Msamples/s (cornell_box 1589 / 1600 / 1595 / 1582).
 // The main chunk grows (and for huge images the schedule falls back to uniform chunks) when the job count or the
-// buffer of chunk sums (bytes_per_sum each) would get out of hand.
-inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk, uint64_t jobs_per_chunk, uint64_t bytes_per_sum) {
+// buffer of chunk sums (bytes_per_sum each) would get out of hand — which plan_passes() below keeps from happening for
+// any spp: a long render is traced as several PASSES over consecutive sample ranges, each with this schedule.
+// Schedule and passes are functions of the WHOLE image (image_tile_pixels = n_tiles * 64) and of spp only — never of the
+// number of ranks or of which tiles a rank owns: the per-pixel fold, hence the image, is bit-identical for any
+// tile_world (each rank's share of the budget below is 1/tile_world of it).
+constexpr uint64_t CHUNK_SUM_BUDGET = 8ull << 30; // bytes of chunk sums alive at once, all ranks together
+// RTTNW_CHUNK_SUM_BUDGET=<bytes> overrides it (tests: makes the budget bind on small images; changes how a pixel's
+// sum is grouped, i.e. rounding only).
+inline uint64_t chunk_sum_budget() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (const char* e = getenv("RTTNW_CHUNK_SUM_BUDGET")) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v) return v;
+    }
+#endif
+    return CHUNK_SUM_BUDGET;
+}
+inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk, uint64_t image_tile_pixels, uint64_t bytes_per_sum) {
     if (user_chunk) {
         rc.spp_chunk = user_chunk;
         rc.n_chunks = rc.n_main = (spp + user_chunk - 1) / user_chunk;
         return;
     }
-    // chunks per pixel the launch can afford: job indices are 32-bit (16 chunks of padding, job_decode), and the chunk
-    // sums of a rank should not take more than 8 GB
-    const uint64_t per = jobs_per_chunk ? jobs_per_chunk : 1;
+    // chunks per pixel the launch can afford: job indices are 32-bit (16 chunks of padding, job_decode; a rank has at
+    // most as many jobs as the whole image), and the chunk sums stay within the budget
+    const uint64_t per = image_tile_pixels ? image_tile_pixels : 1;
     uint64_t max_chunks = ((1ull << 32) - 1) / per;
     max_chunks = max_chunks > 16 ? max_chunks - 16 : 1;
-    const uint64_t by_bytes = (8ull << 30) / (per * (bytes_per_sum ? bytes_per_sum : 1));
+    const uint64_t by_bytes = chunk_sum_budget() / (per * (bytes_per_sum ? bytes_per_sum : 1));
     if (by_bytes < max_chunks) max_chunks = by_bytes ? by_bytes : 1;
     const uint32_t tail = spp < 32u ? spp : spp / 32u;
     for (uint64_t m = 4; m <= spp; m *= 2) {
@@ -207,6 +225,35 @@ inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk, uin
     // an image so large that not even the single-sample tail fits: uniform chunks, as few as the budget allows
     rc.spp_chunk = uint32_t((spp + max_chunks - 1) / max_chunks);
     rc.n_chunks = rc.n_main = (spp + rc.spp_chunk - 1) / rc.spp_chunk;
+}
+// Passes.  The chunk sums of ONE launch must fit CHUNK_SUM_BUDGET with the tapered 4-sample schedule (short chunks are
+// worth 10 % of the rate, see above), so a render of many samples is split into n_pass launches over consecutive sample
+// ranges of near-equal size; the resolve step adds each pass's chunk sums (in chunk order) to the pixel's running sum (in
+// pass order).  Every pass ends on single-sample jobs, so a pass runs at the rate of a stand-alone render of its
+// size.  Returns n_pass >= 1; pass k covers samples [pass_begin(k), pass_begin(k + 1)).
+inline uint64_t tapered_chunks(uint64_t n, uint64_t m) {
+    const uint64_t tail = n < 32 ? n : n / 32, n_main = (n - tail) / m;
+    return n_main + (n - n_main * m);
+}
+inline uint32_t plan_passes(uint32_t spp, uint32_t user_chunk, uint64_t image_tile_pixels, uint64_t bytes_per_sum) {
+    const uint64_t per = image_tile_pixels ? image_tile_pixels : 1;
+    uint64_t max_chunks = ((1ull << 32) - 1) / per;
+    max_chunks = max_chunks > 16 ? max_chunks - 16 : 1;
+    const uint64_t by_bytes = chunk_sum_budget() / (per * (bytes_per_sum ? bytes_per_sum : 1));
+    if (by_bytes < max_chunks) max_chunks = by_bytes ? by_bytes : 1;
+    uint64_t n_max; // most samples one pass can take
+    if (user_chunk) {
+        n_max = max_chunks * user_chunk;
+    } else {
+        n_max = max_chunks * 4; // 4-sample chunks, tapered: a little under 3.66 samples per chunk
+        while (n_max > 1 && tapered_chunks(n_max, 4) > max_chunks) n_max -= (n_max + 63) / 64;
+    }
+    if (n_max < 1) n_max = 1;
+    return uint32_t((uint64_t(spp) + n_max - 1) / n_max);
+}
+RT_HD uint32_t pass_begin(uint32_t spp, uint32_t n_pass, uint32_t k) { // first sample of pass k (k == n_pass: spp)
+    const uint32_t base = spp / n_pass, extra = spp % n_pass;
+    return k * base + (k < extra ? k : extra);
 }
 RT_HD void chunk_samples(const RenderConsts& rc, uint32_t chunk, uint32_t& s, uint32_t& s_end) {
     if (chunk < rc.n_main) {

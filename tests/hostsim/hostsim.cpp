@@ -105,9 +105,9 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
     CameraRec<R> camr = narrow_camera<R>(cam64);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    plan_chunks(rc, p->spp, p->spp_chunk, uint64_t(p->width) * p->height, 3 * sizeof(R));
+    const uint64_t image_tile_pixels = uint64_t((p->width + 7) / 8) * ((p->height + 7) / 8) * 64;
+    const uint32_t n_pass = plan_passes(p->spp, p->spp_chunk, image_tile_pixels, 3 * sizeof(R));
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
-    rc.sample_begin = p->sample_begin;
     V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));
     const R t_min = R(p->t_min);
     if (n_threads <= 0) n_threads = int(std::thread::hardware_concurrency());
@@ -121,17 +121,26 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
             if (row >= rc.height) break;
             for (uint32_t px = 0; px < rc.width; ++px) {
                 V3<R> total;
-                for (uint32_t c = 0; c < rc.n_chunks; ++c) { // one job = (pixel, chunk), folded sequentially
-                    V3<R> acc;
-                    uint32_t s0, s1;
-                    chunk_samples(rc, c, s0, s1);
-                    for (uint32_t si = s0; si < s1; ++si) {
-                        PathState<R> ps;
-                        path_begin(ps, camr, rc, px, row, si);
-                        while (path_step(ps, hs.view, rc, background, t_min, stack, cnt)) {}
-                        acc = acc + ps.radiance;
+                for (uint32_t k = 0; k < n_pass; ++k) { // passes over consecutive sample ranges, as render.hip launches them
+                    RenderConsts rp = rc;
+                    const uint32_t b0 = pass_begin(p->spp, n_pass, k);
+                    rp.spp = pass_begin(p->spp, n_pass, k + 1) - b0;
+                    rp.sample_begin = uint64_t(p->sample_begin) + b0;
+                    plan_chunks(rp, rp.spp, p->spp_chunk, image_tile_pixels, 3 * sizeof(R));
+                    V3<R> pass_sum;
+                    for (uint32_t c = 0; c < rp.n_chunks; ++c) { // one job = (pixel, chunk), folded sequentially
+                        V3<R> acc;
+                        uint32_t s0, s1;
+                        chunk_samples(rp, c, s0, s1);
+                        for (uint32_t si = s0; si < s1; ++si) {
+                            PathState<R> ps;
+                            path_begin(ps, camr, rp, px, row, si);
+                            while (path_step(ps, hs.view, rp, background, t_min, stack, cnt)) {}
+                            acc = acc + ps.radiance;
+                        }
+                        pass_sum = pass_sum + acc; // chunk partials added in chunk order (resolve kernel)
                     }
-                    total = total + acc; // chunk partials added in chunk order (resolve kernel)
+                    total = k == 0 ? pass_sum : total + pass_sum; // ... and the passes in pass order
                 }
                 V3<R> mean = total / R(rc.spp);
                 size_t o = (size_t(row) * rc.width + px) * 3;
@@ -170,15 +179,19 @@ static int probe_path_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttn
     path_begin(ps, camr, rc, px, row, sample);
     HostStack stack; NoCounters cnt;
     uint32_t n = 0;
-    while (n < max_out) {
+    while (n < max_out) { // same record layout as rttnw_debug_probe_path (include/rttnw_hip.h): 20 doubles per bounce
         HitRecord<R> rec;
+        const Ray<R> ray = ps.ray;
         if (!world_hit(hs.view, ps.ray, R(p->t_min), ps.key, ps.bounce, rc.quirks, rec, stack, cnt)) break;
-        double* o = out + size_t(n) * 8;
+        double* o = out + size_t(n) * 20;
         o[0] = rec.t; o[1] = rec.p.x; o[2] = rec.p.y; o[3] = rec.p.z; o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z;
-        o[7] = double(rec.mat);
+        o[7] = double(rec.mat); o[8] = rec.u; o[9] = rec.v; o[10] = rec.front_face ? 1.0 : 0.0;
+        o[11] = ray.o.x; o[12] = ray.o.y; o[13] = ray.o.z; o[14] = ray.d.x; o[15] = ray.d.y; o[16] = ray.d.z; o[17] = ray.time;
         ++n;
         V3<R> att, em;
-        if (!shade(hs.view, rec, ps.key, ps.bounce, ps.ray, att, em, cnt)) break;
+        const bool cont = shade(hs.view, rec, ps.key, ps.bounce, ps.ray, att, em, cnt);
+        o[18] = em.x; o[19] = cont ? att.x : -1.0;
+        if (!cont) break;
         ps.bounce += 1;
         if (ps.bounce >= rc.max_depth) break;
     }
@@ -192,14 +205,17 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
                                      : render_t<double>(s, cam, p, out_linear, stats, n_threads);
 }
-// The chunk schedule of a render (rt_types.hpp plan_chunks + rt_core.hpp plan_jobs) for the given sizes:
-// out = {spp_chunk, n_main, n_chunks, n_jobs}; returns 0, or -1 when the job count does not fit.
-int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t my_tiles, uint32_t bytes_per_sum, uint32_t* out) {
+// Passes and chunk schedule of a render (rt_types.hpp plan_passes / plan_chunks + rt_core.hpp plan_jobs) of an image of n_tiles
+// 8x8 tiles as rank 0 of `world` ranks sees it: out = {spp_chunk, n_main, n_chunks, n_jobs of the FIRST (largest) pass, n_pass,
+// samples of the first pass}; returns 0, or -1 when the job count does not fit.
+int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t n_tiles, uint32_t world, uint32_t bytes_per_sum, uint32_t* out) {
     RenderConsts rc{};
-    rc.spp = spp; rc.my_tiles = my_tiles;
-    plan_chunks(rc, spp, user_chunk, uint64_t(my_tiles) * 64, bytes_per_sum);
+    rc.my_tiles = (n_tiles + world - 1) / world;
+    const uint32_t n_pass = plan_passes(spp, user_chunk, uint64_t(n_tiles) * 64, bytes_per_sum);
+    rc.spp = pass_begin(spp, n_pass, 1);
+    plan_chunks(rc, rc.spp, user_chunk, uint64_t(n_tiles) * 64, bytes_per_sum);
     const bool ok = plan_jobs(rc);
-    out[0] = rc.spp_chunk; out[1] = rc.n_main; out[2] = rc.n_chunks; out[3] = rc.n_jobs;
+    out[0] = rc.spp_chunk; out[1] = rc.n_main; out[2] = rc.n_chunks; out[3] = rc.n_jobs; out[4] = n_pass; out[5] = rc.spp;
     return ok ? 0 : -1;
 }
 // Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).

@@ -123,19 +123,64 @@ def test_sample_ranges_compose(hostsim, oracle, scenes_lib):
 
 
 def test_chunk_schedule_covers_every_sample_within_budget(hostsim):
-    """plan_chunks / plan_jobs for small, ordinary and very large renders: the chunks partition [0, spp) exactly, the
-    launch ends on single-sample chunks when it can, job indices stay below 2^32 and the chunk sums below 8 GB."""
-    out = (C.c_uint32 * 4)()
+    """plan_passes / plan_chunks / plan_jobs for small, ordinary and very large renders: the passes partition [0, spp), the
+    chunks of a pass partition its samples exactly, every pass ends on single-sample chunks, job indices stay below 2^32,
+    the chunk sums of all ranks together below 8 GB — and nothing depends on the number of ranks (the fold of a pixel,
+    hence the image, is the same for any tile_world), including at BASELINE's flagship sizes where the budget binds."""
+    out = (C.c_uint32 * 6)()
+    budget = 8 * 2**30
     cases = [(1, 1), (5, 10), (31, 10), (32, 10), (33, 10), (1000, 10000), (5000, 10000), (8000, 1250), (10000, 5000),
              (10000, 40000), (100000, 40000), (7, 40000), (1000000, 160000)]
     for spp, tiles in cases:
         for bytes_per_sum in (12, 24):
-            assert hostsim.lib.hostsim_plan(spp, 0, tiles, bytes_per_sum, out) == 0, (spp, tiles)
-            chunk, n_main, n_chunks, n_jobs = list(out)
-            covered = n_main * chunk if n_main < n_chunks else min(spp, n_main * chunk)
-            assert covered + (n_chunks - n_main) == spp or (n_main == n_chunks and (n_chunks - 1) * chunk < spp <= n_chunks * chunk), (spp, tiles, list(out))
-            assert n_chunks * tiles * 64 * bytes_per_sum <= 8 * 2**30 + tiles * 64 * bytes_per_sum
-            assert n_jobs >= n_chunks * tiles * 64 and n_jobs < 2**32
-            if spp * tiles * 64 * bytes_per_sum <= 2**30:  # ordinary sizes: the tapered schedule
-                assert chunk in (1, 4) and (n_chunks - n_main >= min(spp, max(1, spp // 32)) or chunk == 1)
-    assert hostsim.lib.hostsim_plan(40, 7, 100, 12, out) == 0 and list(out)[:3] == [7, 6, 6]   # explicit chunking is uniform
+            per_world = {}
+            for world in (1, 2, 3, 4, 8):
+                assert hostsim.lib.hostsim_plan(spp, 0, tiles, world, bytes_per_sum, out) == 0, (spp, tiles, world)
+                chunk, n_main, n_chunks, n_jobs, n_pass, pass_spp = list(out)
+                per_world[world] = (chunk, n_main, n_chunks, n_pass, pass_spp)
+                my_tiles = -(-tiles // world)
+                assert n_jobs >= n_chunks * my_tiles * 64 and n_jobs < 2**32
+            assert len(set(per_world.values())) == 1, (spp, tiles, per_world)
+            assert pass_spp == -(-spp // n_pass)                                     # near-equal passes, the first the largest
+            assert n_main * chunk + (n_chunks - n_main) == pass_spp, (spp, tiles, list(out))
+            assert n_chunks * tiles * 64 * bytes_per_sum <= budget
+            assert chunk in (1, 4) and (n_chunks - n_main >= min(pass_spp, max(1, pass_spp // 32)) or chunk == 1)  # always tapered
+    assert hostsim.lib.hostsim_plan(40, 7, 100, 1, 12, out) == 0 and list(out)[:3] == [7, 6, 6]   # explicit chunking is uniform
+    # BASELINE configs[2] and [3] (800x800 spp 5000; 1600x1600 spp 10000 over 8 ranks), f32: several passes of 4-sample chunks
+    assert hostsim.lib.hostsim_plan(5000, 0, 10000, 1, 12, out) == 0 and out[0] == 4 and out[4] == 2
+    assert hostsim.lib.hostsim_plan(10000, 0, 40000, 8, 12, out) == 0 and out[0] == 4 and out[4] >= 10
+    # the headline config is one pass
+    assert hostsim.lib.hostsim_plan(1000, 0, 10000, 1, 24, out) == 0 and out[4] == 1
+
+
+def test_core_multi_pass_equals_oracle(hostsim, oracle, scenes_lib, monkeypatch):
+    """A render split into passes (RTTNW_CHUNK_SUM_BUDGET makes the workspace budget bind on a small image): the pass-wise
+    fold differs from the oracle's flat fold by rounding only, for the tapered and for an explicit chunking."""
+    sh, setup = util.build(hostsim, scenes_lib, "cornell_box")
+    so, _ = util.build(oracle, scenes_lib, "cornell_box")
+    monkeypatch.setenv("RTTNW_CHUNK_SUM_BUDGET", str(48 * 48 * 24 * 6))          # six chunk planes of a 48x48 f64 image
+    out = (C.c_uint32 * 6)()
+    assert hostsim.lib.hostsim_plan(50, 0, 36, 1, 24, out) == 0 and out[4] >= 3 and out[2] <= 6
+    for chunk in (0, 3):
+        cam, p = util.params_for(setup, 48, 48, 50, spp_chunk=chunk, seed=4)
+        lin, _ = util.hostsim_render(hostsim, sh, cam, p)
+        lo, _, _ = rto.render(so, cam, p)
+        assert np.abs(lin - lo).max() <= 1e-12 * max(1.0, lo.max())
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "final_scene", "smoke_cornell_box", "random_scene"])
+def test_core_per_bounce_records_equal_oracle(hostsim, oracle, scenes_lib, earth, name):
+    """SURVEY section 4's second tier on the host build of the core: every world.hit() of 120 paths per scene — t, p, normal,
+    front_face, material, (u, v) — against the oracle's recursion (the device probe kernel runs the same comparison in
+    tests/test_gpu_parity.py)."""
+    so, setup = util.build(oracle, scenes_lib, name, earth)
+    sh, _ = util.build(hostsim, scenes_lib, name, earth)
+    cam, p = util.params_for(setup, 40, 40, 4, seed=9)
+    hostsim.lib.hostsim_probe_path.restype = C.c_int
+    hostsim.lib.hostsim_probe_path.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.Params), C.c_uint32, C.c_uint32,
+                                               C.c_uint32, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(5)
+    pairs = [(int(rng.integers(40)), int(rng.integers(40)), int(rng.integers(4))) for _ in range(120)]
+    n, bounces, _ = util.compare_paths(lambda x, y, s: util.product_probe(hostsim.lib.hostsim_probe_path, hostsim, sh, cam, p, x, y, s),
+                                       lambda x, y, s: rto.probe_path(so, cam, p, x, y, s), pairs)
+    assert n == 120 and bounces > 150

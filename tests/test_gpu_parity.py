@@ -32,10 +32,13 @@ def gpu_render(gpu, sc, cam, p):
     return lin, rgba, st
 
 
+@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH], ids=["sah", "lbvh"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_T1_f64_vs_golden(gpu, scenes_lib, earth, case):
+def test_T1_f64_vs_golden(gpu, scenes_lib, earth, case, bvh):
+    """Both BVH builders against the ORACLE's golden images (the device-built linear BVH meets the oracle directly,
+    not only the host-built tree)."""
     key, name, w, h, spp, chunk, param = case
-    sc, setup = util.build(gpu, scenes_lib, name, earth, param)
+    sc, setup = util.build(gpu, scenes_lib, name, earth, param, bvh=bvh)
     cam, p = util.params_for(setup, w, h, spp, spp_chunk=chunk, precision=abi.F64)
     lin, rgba, st = gpu_render(gpu, sc, cam, p)
     g = load()
@@ -274,3 +277,126 @@ def test_chunk_schedule_boundaries_and_sample_offsets(gpu, oracle, scenes_lib):
         assert st.samples == 19 * 11 * spp
         assert np.abs(lin - lo).max() <= T1_ABS, (spp, chunk, begin)
         assert np.array_equal(rgba, ro)
+
+
+@pytest.mark.parametrize("name,n_pairs", [("cornell_box", 120), ("final_scene", 160), ("smoke_cornell_box", 60), ("random_scene", 60)])
+@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH], ids=["sah", "lbvh"])
+def test_per_bounce_records_equal_oracle(gpu, oracle, scenes_lib, earth, name, n_pairs, bvh):
+    """SURVEY section 4's second tier: rttnw_debug_probe_path (one lane walks one sample's path on the DEVICE and dumps
+    every world.hit()) against rto_probe_path — t, p, normal, front_face, material and (u, v) of every bounce of 400
+    (pixel, sample) pairs within 1e-9 in f64 (hittable.rs:15-44: the HitRecord the reference would have built)."""
+    sg, setup = util.build(gpu, scenes_lib, name, earth, bvh=bvh)
+    so, _ = util.build(oracle, scenes_lib, name, earth)
+    cam, p = util.params_for(setup, 96, 96, 8, seed=21, precision=abi.F64)
+    rng = np.random.default_rng(17)
+    pairs = [(int(rng.integers(96)), int(rng.integers(96)), int(rng.integers(8))) for _ in range(n_pairs)]
+    n, bounces, mats = util.compare_paths(lambda x, y, s: util.product_probe(gpu.debug_probe_path, gpu, sg, cam, p, x, y, s),
+                                          lambda x, y, s: rto.probe_path(so, cam, p, x, y, s), pairs)
+    assert n == n_pairs and bounces >= n_pairs and len(mats) >= 3
+    # the probe's own tail: the sample's radiance through path_step() (what the trace kernel runs) == the oracle's color()
+    out = np.zeros(8 * util.PROBE_STRIDE + 4)
+    for (x, y, s) in pairs[:20]:
+        assert gpu.debug_probe_path(sg.handle, C.byref(cam), C.byref(p), x, y, s, out.ctypes.data, 8) >= 0
+        ref = np.zeros(3)
+        pb = util.params_for(setup, 96, 96, 8, seed=21)[1]
+        pb.background = abi.vec3(0.0, 0.0, 0.0)                                   # the probe takes the background as black
+        assert oracle.probe_sample(so.handle, C.byref(cam), C.byref(pb), x, y, s, ref.ctypes.data_as(C.POINTER(C.c_double))) == 0
+        assert np.abs(out[8 * util.PROBE_STRIDE:8 * util.PROBE_STRIDE + 3] - ref).max() <= 1e-9 * max(1.0, ref.max())
+
+
+@pytest.mark.parametrize("precision", [abi.F64, abi.F32], ids=["f64", "f32"])
+def test_passes_and_partition_when_the_workspace_budget_binds(gpu, oracle, scenes_lib, precision, monkeypatch):
+    """plan_passes: with the chunk-sum budget binding (RTTNW_CHUNK_SUM_BUDGET shrinks it to six chunk planes of this
+    image; at BASELINE configs[2]/[3] the real 8 GB binds the same way) the render runs as several passes — and the
+    pass split, like the chunk schedule, depends on the image and spp only: an 8-way tile partition is still
+    BIT-identical to the single-rank image, and f64 equals the oracle to rounding."""
+    import torch
+    sg, setup = util.build(gpu, scenes_lib, "cornell_box")
+    so, _ = util.build(oracle, scenes_lib, "cornell_box")
+    w, h, spp = 96, 56, 70
+    rsz = 8 if precision == abi.F64 else 4
+    monkeypatch.setenv("RTTNW_CHUNK_SUM_BUDGET", str(w * h * 3 * rsz * 6))
+    cam, p1 = util.params_for(setup, w, h, spp, precision=precision, seed=6)
+    one_lin, one_rgba, st = gpu_render(gpu, sg, cam, p1)
+    assert st.samples == w * h * spp
+    if precision == abi.F64:
+        lo, ro, _ = rto.render(so, cam, p1)
+        assert np.abs(one_lin - lo).max() <= T1_ABS
+    world = 8
+    lay = tiles.layout(w, h, world)
+    dt = torch.float32 if precision == abi.F32 else torch.float64
+    gathered = torch.zeros((world, lay["pixels_per_rank"], 4), dtype=dt, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        p = util.params_for(setup, w, h, spp, precision=precision, seed=6, tile_rank=r, tile_world=world)[1]
+        abi.check(gpu.render_tiles_device(sg.handle, C.byref(cam), C.byref(p), gathered[r].data_ptr(), stream, None), gpu, "render_tiles_device")
+    lin = torch.zeros((h, w, 3), dtype=dt, device="cuda")
+    abi.check(gpu.untile_device(w, h, world, precision, gathered.data_ptr(), lin.data_ptr(), None, stream), gpu, "untile_device")
+    torch.cuda.synchronize()
+    assert np.array_equal(lin.cpu().numpy().astype(np.float64), one_lin)
+    monkeypatch.delenv("RTTNW_CHUNK_SUM_BUDGET")
+    whole, _, _ = gpu_render(gpu, sg, cam, p1)                                    # one pass: the same samples, grouped differently
+    assert np.abs(whole - one_lin).max() <= (1e-12 if precision == abi.F64 else 2e-5) * max(1.0, whole.max())
+
+
+def test_config3_frame_across_eight_ranks(gpu, oracle, scenes_lib, earth):
+    """BASELINE configs[3]: final_scene 1600x1600 tile-sharded across 8 (spp 2 here — spp only lengthens the fold).  Every
+    rank's packed buffer is exactly `tiles.pack_rank` of the single-rank image (the gather + un-tile then reassemble it
+    bit for bit), in the f64 and the f32 kernels; and the f64 frame equals the ORACLE on a 64x64 crop through the glass /
+    blue-medium spheres and on one through the sphere cluster (oracle window render: same keys as the full frame)."""
+    import torch
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
+    so, _ = util.build(oracle, scenes_lib, "final_scene", earth)
+    w = h = 1600
+    for precision in (abi.F64, abi.F32):
+        cam, p1 = util.params_for(setup, w, h, 2, precision=precision, spp_chunk=2, seed=5)
+        one, rgba, st = gpu_render(gpu, sc, cam, p1)
+        assert st.samples == w * h * 2 and np.isfinite(one).all() and (rgba[..., 3] == 255).all()
+        gathered = []
+        for r in range(8):
+            cam8, p8 = util.params_for(setup, w, h, 2, precision=precision, spp_chunk=2, seed=5, tile_rank=r, tile_world=8)
+            dr = render.DeviceRenderer(sc, cam8, p8)
+            dr.trace()
+            torch.cuda.synchronize()
+            got = dr.packed.cpu().numpy().astype(np.float64)
+            want = tiles.pack_rank(one, r, 8)
+            assert np.array_equal(got[:, :3], want[:, :3]), (precision, r)
+            gathered.append(got)
+        assert np.array_equal(tiles.untile_reference(np.stack(gathered), w, h, 8), one)
+        if precision == abi.F64:
+            for (x0, y0) in [(500, 1100), (1000, 560)]:
+                lo, ro, _, _ = rto.render_window(so, cam, p1, x0, y0, x0 + 64, y0 + 64)
+                d = np.abs(one[y0:y0 + 64, x0:x0 + 64] - lo).max(axis=2)
+                assert (d <= T1_ABS).mean() >= 0.999, (x0, y0, d.max())
+                assert (rgba[y0:y0 + 64, x0:x0 + 64] == ro).all(axis=2).mean() >= 0.999
+
+
+@pytest.mark.parametrize("name,crops", [("final_scene", [(40, 440), (180, 540), (330, 330), (520, 300)]),
+                                        ("cornell_box", [(100, 100), (370, 420), (600, 300)])])
+def test_T2_f32_at_baseline_size(gpu, oracle, scenes_lib, earth, name, crops):
+    """SURVEY section 8(c) T2 as written: the F32 kernels at the BASELINE size (800x800) and spp >= 1000 against the f64
+    oracle on 64x64 crops (earth + blue sphere, glass sphere, noise sphere, sphere cluster / the Cornell blocks):
+      per pixel and channel  |delta| <= 6 sigma_hat / sqrt(spp) + 1/256   (sigma_hat: the oracle's per-pixel sample variance;
+                              equal seeds share every uniform's top 24 bits, so the two estimates are far closer than two
+                              independent ones; a pixel may fail only through f32-induced branch flips: <= 0.2 % allowed),
+      RGBA8 within 1 LSB on >= 99 % of the pixels, per-channel mean of the crop within 0.5 %."""
+    spp = 1000
+    sg, setup = util.build(gpu, scenes_lib, name, earth)
+    so, _ = util.build(oracle, scenes_lib, name, earth)
+    cam, p32 = util.params_for(setup, 800, 800, spp, precision=abi.F32)
+    lin, rgba, st = gpu_render(gpu, sg, cam, p32)
+    assert st.samples == 800 * 800 * spp and np.isfinite(lin).all()
+    p64 = util.params_for(setup, 800, 800, spp)[1]
+    n_px = n_bound = n_lsb = 0
+    for (x0, y0) in crops:
+        lo, ro, var, _ = rto.render_window(so, cam, p64, x0, y0, x0 + 64, y0 + 64, want_var=True)
+        g = lin[y0:y0 + 64, x0:x0 + 64]
+        bound = 6.0 * np.sqrt(np.maximum(var, 0.0) / spp) + 1.0 / 256
+        n_bound += int((np.abs(g - lo) <= bound).all(axis=2).sum())
+        lsb = np.abs(rgba[y0:y0 + 64, x0:x0 + 64, :3].astype(int) - ro[..., :3].astype(int)).max(axis=2)
+        n_lsb += int((lsb <= 1).sum())
+        n_px += 64 * 64
+        rel = np.abs(g.mean(axis=(0, 1)) - lo.mean(axis=(0, 1))) / lo.mean(axis=(0, 1))
+        assert rel.max() <= 0.005, (name, x0, y0, rel)
+    assert n_bound / n_px >= 0.998, (name, n_bound / n_px)
+    assert n_lsb / n_px >= 0.99, (name, n_lsb / n_px)

@@ -35,3 +35,40 @@ def block_means(rgb, n):
     bh, bw = h // n, w // n
     return np.array([[[rgb[r * bh:(r + 1) * bh, c * bw:(c + 1) * bw, ch].mean() for c in range(n)]
                       for r in range(n)] for ch in range(3)])
+
+
+# ---- per-bounce path dumps: product (device probe kernel, or the host build of the same core) vs the oracle
+PROBE_STRIDE = 20  # include/rttnw_hip.h rttnw_debug_probe_path
+
+
+def product_probe(fn, binding, sc, cam, p, px, row, sample, max_out=64):
+    """fn = gpu.debug_probe_path or hostsim.lib.hostsim_probe_path -> array [n_hits, 20]."""
+    out = np.zeros(max_out * PROBE_STRIDE + 4, dtype=np.float64)
+    n = fn(sc.handle, C.byref(cam), C.byref(p), px, row, sample, out.ctypes.data, max_out)
+    abi.check(n, binding, "probe_path")
+    return out[:n * PROBE_STRIDE].reshape(n, PROBE_STRIDE)
+
+
+def compare_paths(probe, oracle_probe, pairs, tol=1e-9):
+    """Every bounce of every (px, row, sample): t, p, normal, front_face equal within `tol` (relative to the magnitude of
+    the coordinate), the same material at every hit (the oracle reports graph ids, the product flat indices: the
+    mapping must be one-to-one and order preserving), (u, v) equal wherever the product computes them (it skips them
+    when no texture reads them).  Returns (paths, bounces compared, material map)."""
+    mat_map, bounces = {}, 0
+    for (px, row, s) in pairs:
+        a = probe(px, row, s)
+        b = oracle_probe(px, row, s)
+        assert len(a) == len(b), ("bounce count", px, row, s, len(a), len(b))
+        for k in range(len(a)):
+            scale = max(1.0, np.abs(b[k, 0:4]).max())
+            assert np.abs(a[k, 0:7] - b[k, 0:7]).max() <= tol * scale, ("t/p/normal", px, row, s, k, a[k, 0:7], b[k, 0:7])
+            assert a[k, 10] == b[k, 10], ("front_face", px, row, s, k)
+            if a[k, 8] != 0.0 or a[k, 9] != 0.0:
+                assert abs(a[k, 8] - b[k, 8]) <= tol and abs(a[k, 9] - b[k, 9]) <= tol, ("uv", px, row, s, k)
+            assert mat_map.setdefault(int(b[k, 7]), int(a[k, 7])) == int(a[k, 7]), ("material", px, row, s, k)
+            assert (a[k, 19] >= 0.0) == (b[k, 11] == 1.0), ("scattered", px, row, s, k)
+            bounces += 1
+    ids = sorted(mat_map)
+    flat = [mat_map[i] for i in ids]
+    assert flat == sorted(flat) and len(set(flat)) == len(flat), mat_map
+    return len(pairs), bounces, mat_map

@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override width = height")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--counter-spp", type=int, default=8)
+    ap.add_argument("--counter-level", type=int, default=1, help="collect_counters of the untimed counting pass (2, 3: more RTTNW_DEBUG_SCHED statistics)")
     ap.add_argument("--no-other", action="store_true", help="skip the timing of the other precision's kernels")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder at commit: host binned SAH (default) or device LBVH")
     args = ap.parse_args()
@@ -149,7 +150,7 @@ def main():
         """Algorithmic bytes per sample, counted by the counting kernel variant on this rank's tiles (untimed).
         A BVH node visit is priced at the 32-B accounting record of BASELINE.md although the node records here are 64 B
         and hold both children's boxes (one visit = one record fetch = two box tests)."""
-        cam_c, pc = util.params_for(setup, W, H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, collect_counters=1)
+        cam_c, pc = util.params_for(setup, W, H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, collect_counters=args.counter_level)
         rc_ = render.DeviceRenderer(sc, cam_c, pc)
         st = abi.Stats()
         rc_.trace(st)

@@ -175,7 +175,7 @@ typedef struct rttnw_stats {
     uint64_t prims_tested;   /* primitive records read (incl. medium boundaries) */
     uint64_t texel_fetches;  /* image-texture texel reads */
     double kernel_ms;        /* device time of the trace kernel(s), hipEvent-measured */
-    uint32_t n_nodes;        /* flat scene size */
+    uint32_t n_nodes;        /* flat scene size: 4-wide node records */
     uint32_t n_prims;
     uint32_t scene_bytes;    /* bytes of node+primitive arrays resident on the device */
     uint32_t reserved;       /* render: kernel form that ran (0 = lane-owns-path, 1 = decoupled); scene_info: stack depth */
@@ -227,7 +227,7 @@ int rttnw_scene_info(rttnw_scene* s, rttnw_stats* out);
 /* What rttnw_scene_commit's build cost (valid after commit). */
 typedef struct rttnw_build_info {
     uint32_t builder;     /* RTTNW_BVH_* */
-    uint32_t n_nodes;     /* 64-byte node records, all trees */
+    uint32_t n_nodes;     /* 128-byte 4-wide node records the kernels walk, all trees */
     uint32_t n_prims;     /* leaves of all trees */
     uint32_t stack_depth; /* traversal stack entries a lane needs */
     double lower_ms;      /* host wall time of the lowering, BVH builds included */
@@ -235,9 +235,15 @@ typedef struct rttnw_build_info {
 } rttnw_build_info;
 int rttnw_scene_build_info(const rttnw_scene* s, rttnw_build_info* out);
 
-/* Debug/inspection: copy up to max_nodes 64-byte node records (rt_types.hpp BvhNode: lo0[3] hi0[3] lo1[3] hi1[3]
- * child0 child1 pad pad; child >= 0 inner node, < 0 leaf bits) and the top-level root; returns the node count. */
+/* Debug/inspection: the BUILDERS' binary trees: copy up to max_nodes 64-byte node records (rt_types.hpp BvhNode: lo0[3]
+ * hi0[3] lo1[3] hi1[3] child0 child1 pad pad; child >= 0 inner node, < 0 leaf bits) and the top-level root; returns the
+ * node count.  (The kernels walk the 4-wide collapse of these trees, see rttnw_debug_scene_nodes4.) */
 int rttnw_debug_scene_nodes(const rttnw_scene* s, void* out_nodes, uint32_t max_nodes, int32_t* top_root);
+
+/* Debug/inspection: the records the kernels walk — the same trees collapsed to 4-WIDE nodes of 128 bytes (rt_types.hpp
+ * Bvh4Node: lo[3][4] hi[3][4] (planes by axis, then child) child[4] pad[4]; an unused slot has child == INT32_MIN and an
+ * inverted box).  Copies up to max_nodes records and the top-level root; returns the record count. */
+int rttnw_debug_scene_nodes4(const rttnw_scene* s, void* out_nodes, uint32_t max_nodes, int32_t* top_root);
 
 /* Debug/inspection: walk sample `sample` of pixel (px, row; row 0 = top) on the device with the kernels of
  * `p->precision` and dump every world.hit() of its path, 20 doubles per bounce:

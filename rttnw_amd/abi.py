@@ -105,6 +105,7 @@ PRODUCT_FUNCS = [
     ("scene_set_bvh_builder", C.c_int, [scene_p, C.c_uint32]),
     ("scene_build_info", C.c_int, [scene_p, C.POINTER(BuildInfo)]),
     ("debug_scene_nodes", C.c_int, [scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
+    ("debug_scene_nodes4", C.c_int, [scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
     ("builder", C.c_void_p, []),
     ("debug_probe_path", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint32,
                                    C.c_uint32, C.c_void_p, C.c_uint32]),

@@ -221,7 +221,7 @@ int rttnw_scene_build_info(const rttnw_scene* s, rttnw_build_info* out) {
     if (!s || !out) return fail(RTTNW_ERR_INVALID, "scene_build_info: NULL argument");
     if (!s->committed) return fail(RTTNW_ERR_STATE, "scene_build_info: scene is not committed");
     out->builder = s->bvh_builder;
-    out->n_nodes = uint32_t(s->flat.nodes.size());
+    out->n_nodes = uint32_t(s->flat.nodes4.size());
     out->n_prims = s->flat.n_prims_in_bvh;
     out->stack_depth = s->flat.stack_depth;
     out->lower_ms = s->lower_ms;
@@ -233,8 +233,16 @@ int rttnw_debug_scene_nodes(const rttnw_scene* s, void* out_nodes, uint32_t max_
     if (!s || !s->committed) return fail(RTTNW_ERR_STATE, "debug_scene_nodes: scene is not committed");
     const uint32_t n = uint32_t(std::min<size_t>(s->flat.nodes.size(), max_nodes));
     if (out_nodes && n) std::memcpy(out_nodes, s->flat.nodes.data(), size_t(n) * sizeof(rt::BvhNode));
-    if (top_root) *top_root = s->flat.top_root;
+    if (top_root) *top_root = s->flat.top_root2;
     return int(s->flat.nodes.size());
+}
+
+int rttnw_debug_scene_nodes4(const rttnw_scene* s, void* out_nodes, uint32_t max_nodes, int32_t* top_root) {
+    if (!s || !s->committed) return fail(RTTNW_ERR_STATE, "debug_scene_nodes4: scene is not committed");
+    const uint32_t n = uint32_t(std::min<size_t>(s->flat.nodes4.size(), max_nodes));
+    if (out_nodes && n) std::memcpy(out_nodes, s->flat.nodes4.data(), size_t(n) * sizeof(rt::Bvh4Node));
+    if (top_root) *top_root = s->flat.top_root;
+    return int(s->flat.nodes4.size());
 }
 
 const rttnw_builder_api* rttnw_builder(void) {

@@ -34,32 +34,36 @@ namespace rt {
 // ---------------------------------------------------------------------------------------------
 // device-side helpers
 // ---------------------------------------------------------------------------------------------
-// Traversal memory of a lane: its BVH stack in LDS (entry e of lane l at e*stride + l: conflict-free b32 accesses) and
+// Traversal memory of a lane: its BVH stack — the first LDS_STACK_ENTRIES entries in LDS (entry e of lane l at
+// e*stride + l: conflict-free b32 accesses), deeper ones in a strip of global memory (entry e of thread g at
+// e*spill_stride + g; a 4-wide walk can have three pending children per level but rarely has more than a dozen) — and
 // the way it reads node records.
 struct LdsStack {
-    int32_t* base;   // &lds[threadIdx.x]
-    uint32_t stride; // blockDim.x
-    __device__ __forceinline__ void set(int i, int32_t v) { base[uint32_t(i) * stride] = v; }
-    __device__ __forceinline__ int32_t get(int i) const { return base[uint32_t(i) * stride]; }
-    template <typename R> __device__ __forceinline__ BvhNode node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
+    int32_t* base;         // &lds[threadIdx.x]
+    uint32_t stride;       // blockDim.x
+    int32_t* spill;        // &spill_buffer[global thread]
+    uint32_t spill_stride; // threads of the launch
+    __device__ __forceinline__ void set(int i, int32_t v) {
+        if (uint32_t(i) < LDS_STACK_ENTRIES) base[uint32_t(i) * stride] = v;
+        else spill[size_t(uint32_t(i) - LDS_STACK_ENTRIES) * spill_stride] = v;
+    }
+    __device__ __forceinline__ int32_t get(int i) const {
+        if (uint32_t(i) < LDS_STACK_ENTRIES) return base[uint32_t(i) * stride];
+        return spill[size_t(uint32_t(i) - LDS_STACK_ENTRIES) * spill_stride];
+    }
+    template <typename R> __device__ __forceinline__ Bvh4Node node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
 };
-// Same, with the whole node array resident in LDS in QUARTER-MAJOR order: the q-th 16 bytes of node i at
-// quarter[q*n_nodes + i].  64 lanes fetching the same quarter of 64 unrelated nodes then spread over all sixteen
-// 16-byte bank slots (i mod 16); in node-major order they would share four (the 64-byte records start at 0/64/128/
-// 192 mod 256) — measured 31 % of the LDS cycles were bank conflicts that way.
-struct LdsStackNodes {
-    int32_t* base;
-    uint32_t stride;
-    const int4* quarter; // LDS
+// Same, with the whole node array resident in LDS in PIECE-MAJOR order: the q-th 16 bytes of node i at
+// piece[q*n_nodes + i] (q < 7: the pad is left out).  64 lanes fetching the same piece of 64 unrelated nodes then spread
+// over all the 16-byte bank slots (i mod 16); in node-major order the 128-byte records would all start at the same two
+// — measured on the 64-byte binary records: 31 % of the LDS cycles were bank conflicts that way.
+struct LdsStackNodes : LdsStack {
+    const int4* piece; // LDS
     uint32_t n_nodes;
-    __device__ __forceinline__ void set(int i, int32_t v) { base[uint32_t(i) * stride] = v; }
-    __device__ __forceinline__ int32_t get(int i) const { return base[uint32_t(i) * stride]; }
-    template <typename R> __device__ __forceinline__ BvhNode node(const SceneView<R>&, int32_t i) const {
-        union { int4 q[4]; BvhNode n; } u;
-        u.q[0] = quarter[uint32_t(i)];
-        u.q[1] = quarter[n_nodes + uint32_t(i)];
-        u.q[2] = quarter[2u * n_nodes + uint32_t(i)];
-        u.q[3] = quarter[3u * n_nodes + uint32_t(i)];
+    template <typename R> __device__ __forceinline__ Bvh4Node node(const SceneView<R>&, int32_t i) const {
+        union { int4 q[8]; Bvh4Node n; } u;
+#pragma unroll
+        for (uint32_t k = 0; k < BVH4_USED_SIXTEENTHS; ++k) u.q[k] = piece[k * n_nodes + uint32_t(i)];
         return u.n;
     }
 };
@@ -106,7 +110,7 @@ enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, 
 enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
 // bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
 template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
-    return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + stack_depth * 64u * 4u;
+    return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (stack_depth < LDS_STACK_ENTRIES ? stack_depth : LDS_STACK_ENTRIES) * 64u * 4u;
 }
 constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
 
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,
-                                                            uint32_t* __restrict__ pool_u, uint32_t n_slots) {
+                                                            uint32_t* __restrict__ pool_u, uint32_t n_slots, int32_t* __restrict__ spill) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typename CounterSel<COUNT>::type cnt;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
     int32_t* const hq_prim = reinterpret_cast<int32_t*>(rq_slot + QCAP);
     int32_t* const hq_inst = hq_prim + QCAP;
     uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
-    LdsStack stack{reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane, 64u};
+    LdsStack stack{reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane, 64u, spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x), gridDim.x * TRACE_BLOCK};
 
     const uint32_t wave_global = blockIdx.x * (TRACE_BLOCK / 64) + wave_in_block;
     const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;
@@ -360,24 +364,26 @@ template <typename R, bool COUNT, int BLOCK, bool LDSN>
 __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
-                                                            DeviceCounters* __restrict__ counters) {
-    // LDSN: the whole node array is copied into LDS (quarter-major, see LdsStackNodes) in front of the stacks — small
+                                                            DeviceCounters* __restrict__ counters, int32_t* __restrict__ spill) {
+    // LDSN: the whole node array is copied into LDS (piece-major, see LdsStackNodes) in front of the stacks — small
     // scenes: one dependent ~100-cycle LDS read per node visit instead of an L1/L2 round trip
     extern __shared__ __align__(16) int32_t lds_stack[];
     typename std::conditional<LDSN, LdsStackNodes, LdsStack>::type stack;
+    stack.stride = blockDim.x;
+    stack.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    stack.spill_stride = gridDim.x * blockDim.x;
     if constexpr (LDSN) {
         const uint32_t n = rc.lds_nodes;
         const int4* src = reinterpret_cast<const int4*>(sc.nodes);
         int4* dst = reinterpret_cast<int4*>(lds_stack);
-        for (uint32_t i = threadIdx.x; i < n * 4u; i += blockDim.x) dst[(i & 3u) * n + (i >> 2)] = src[i];
+        for (uint32_t i = threadIdx.x; i < n * 8u; i += blockDim.x)
+            if ((i & 7u) < BVH4_USED_SIXTEENTHS) dst[(i & 7u) * n + (i >> 3)] = src[i];
         __syncthreads();
-        stack.base = lds_stack + n * uint32_t(sizeof(BvhNode) / 4) + threadIdx.x;
-        stack.stride = blockDim.x;
-        stack.quarter = dst;
+        stack.base = lds_stack + n * (4u * BVH4_USED_SIXTEENTHS) + threadIdx.x;
+        stack.piece = dst;
         stack.n_nodes = n;
     } else {
         stack.base = lds_stack + threadIdx.x;
-        stack.stride = blockDim.x;
     }
     typename CounterSel<COUNT>::type cnt;
 
@@ -604,10 +610,11 @@ __global__ void untile_kernel(const R* __restrict__ gathered, R* __restrict__ li
 constexpr int PROBE_STRIDE = 20;
 template <typename R>
 __global__ void probe_path_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R t_min, uint32_t px, uint32_t row,
-                                  uint32_t sample, double* __restrict__ out, uint32_t max_out, int32_t* __restrict__ n_out) {
+                                  uint32_t sample, double* __restrict__ out, uint32_t max_out, int32_t* __restrict__ n_out,
+                                  int32_t* __restrict__ spill) {
     extern __shared__ int32_t lds_stack[];
     if (threadIdx.x != 0) return;
-    LdsStack stack{lds_stack, blockDim.x};
+    LdsStack stack{lds_stack, blockDim.x, spill, 1u};
     NoCounters cnt;
     PathState<R> ps;
     path_begin(ps, cam, rc, px, row, sample);
@@ -669,7 +676,7 @@ template <typename T> struct DevBuf {
 
 template <typename R> struct DeviceScene {
     bool ready = false;
-    DevBuf<BvhNode> nodes;
+    DevBuf<Bvh4Node> nodes;
     DevBuf<SphereRec<R>> spheres;
     DevBuf<int32_t> sphere_mat, sphere_seq;
     DevBuf<MovingSphereRec<R>> moving;
@@ -725,7 +732,7 @@ template <typename R> struct DeviceScene {
         for (double v : f.perlin_vec) pv.push_back(R(v));
 
         int rc;
-        if ((rc = nodes.upload(f.nodes)) || (rc = spheres.upload(sp)) || (rc = sphere_mat.upload(f.sphere_mat)) ||
+        if ((rc = nodes.upload(f.nodes4)) || (rc = spheres.upload(sp)) || (rc = sphere_mat.upload(f.sphere_mat)) ||
             (rc = sphere_seq.upload(f.sphere_seq)) || (rc = moving.upload(mv)) || (rc = rects.upload(rc_)) ||
             (rc = boxes.upload(bx)) || (rc = insts.upload(in)) || (rc = media.upload(md)) || (rc = mats.upload(mt)) ||
             (rc = texs.upload(tx)) || (rc = images.upload(f.images)) || (rc = texels.upload(f.texels)) ||
@@ -737,7 +744,7 @@ template <typename R> struct DeviceScene {
         view.perlin_vec = perlin_vec.p; view.perlin_perm = perlin_perm.p;
         view.top_root = f.top_root;
         view.n_media = int32_t(f.media.size());
-        bytes = f.nodes.size() * sizeof(BvhNode) + sp.size() * sizeof(SphereRec<R>) + mv.size() * sizeof(MovingSphereRec<R>) +
+        bytes = f.nodes4.size() * sizeof(Bvh4Node) + sp.size() * sizeof(SphereRec<R>) + mv.size() * sizeof(MovingSphereRec<R>) +
                 rc_.size() * sizeof(RectRec<R>) + bx.size() * sizeof(BoxRec<R>) + in.size() * sizeof(InstanceRec<R>);
         ready = true;
         return 0;
@@ -760,6 +767,7 @@ struct DeviceState {
     size_t partial_bytes = 0;
     void* pool_r = nullptr; size_t pool_r_bytes = 0; // path-slot state (reals / words), SoA over all slots
     void* pool_u = nullptr; size_t pool_u_bytes = 0;
+    void* spill = nullptr; size_t spill_bytes = 0;   // traversal-stack entries beyond LDS_STACK_ENTRIES, per thread of the launch
     unsigned long long* job_counter = nullptr; // [0] job counter, then DeviceCounters
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // scratch for the blocking host-output render()
@@ -783,6 +791,7 @@ void device_release(DeviceState* d) {
     if (d->partial) (void)hipFree(d->partial);
     if (d->pool_r) (void)hipFree(d->pool_r);
     if (d->pool_u) (void)hipFree(d->pool_u);
+    if (d->spill) (void)hipFree(d->spill);
     if (d->job_counter) (void)hipFree(d->job_counter);
     if (d->packed) (void)hipFree(d->packed);
     if (d->linear) (void)hipFree(d->linear);
@@ -898,7 +907,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     // scenes (cornell_box, final_scene: <= ~1k nodes), the decoupled form on deep BVHs where traversal lengths vary
     // most (1M spheres).  RTTNW_KERNEL=plain|wave overrides the choice (experiments only).
     const char* kv = getenv("RTTNW_KERNEL");
-    bool plain = s->flat.nodes.size() < 65536;
+    bool plain = s->flat.nodes4.size() < 32768; // (about 65536 nodes of the binary tree)
     if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
@@ -914,6 +923,11 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
         grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + 3) / 4));
         return 0;
     };
+    // stack entries beyond the LDS-resident ones, for every thread of a launch
+    auto grow_spill = [&](size_t threads) -> int {
+        const size_t extra = rc.stack_depth > LDS_STACK_ENTRIES ? rc.stack_depth - LDS_STACK_ENTRIES : 0;
+        return grow(&d->spill, &d->spill_bytes, std::max<size_t>(threads * extra, 1) * sizeof(int32_t));
+    };
     // One pass: trace kernel over the pass's jobs, then the resolve step.
     auto trace_pass = [&]() -> int {
         const size_t n_jobs = rc.n_jobs;
@@ -921,14 +935,13 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
             // 1024 threads (4 waves/SIMD at <= 128 VGPRs) for f32, 512 threads (2 waves/SIMD, all the 256-VGPR f64 code allows)
             constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : 512;
-            const size_t node_bytes = s->flat.nodes.size() * sizeof(BvhNode);
-            const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) &&
-                                  node_bytes + size_t(rc.stack_depth) * LDS_BLOCK * 4 <= 160 * 1024;
-            rc.lds_nodes = want_lds ? uint32_t(s->flat.nodes.size()) : 0u;
+            const uint32_t n4 = uint32_t(s->flat.nodes4.size());
+            const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) <= 160 * 1024;
+            rc.lds_nodes = want_lds ? n4 : 0u;
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
             const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true>)
                                           : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false>);
-            const size_t lds_bytes = (want_lds ? node_bytes : 0) + size_t(rc.stack_depth) * block * sizeof(int32_t);
+            const size_t lds_bytes = lds_form_bytes(want_lds ? n4 : 0u, rc.stack_depth, uint32_t(block));
             if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
             HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
             int blocks_per_cu = 0;
@@ -936,13 +949,15 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
             const size_t waves_per_block = size_t(block) / 64;
             const size_t grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, ((n_jobs + 63) / 64 + waves_per_block - 1) / waves_per_block));
+            if (int g = grow_spill(grid * size_t(block))) return g;
             if (n_jobs > 0) {
                 R bg0 = R(p->background[0]), bg1 = R(p->background[1]), bg2 = R(p->background[2]), tmin = R(p->t_min);
                 R* part = (R*)d->partial;
                 unsigned long long* jc = d->job_counter;
                 SceneView<R> view = ds.view;
                 CameraRec<R> camv = camr;
-                void* args[] = {&view, &camv, &rc, &bg0, &bg1, &bg2, &tmin, &part, &jc, &dc};
+                int32_t* sp = (int32_t*)d->spill;
+                void* args[] = {&view, &camv, &rc, &bg0, &bg1, &bg2, &tmin, &part, &jc, &dc, &sp};
                 HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
             }
         } else {
@@ -953,10 +968,11 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             const size_t n_slots = grid * (TRACE_BLOCK / 64) * SLOTS_PER_WAVE;
             if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
             if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
+            if (int g = grow_spill(grid * size_t(TRACE_BLOCK))) return g;
             if (n_jobs > 0) {
                 hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
                                    R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
-                                   (uint32_t*)d->pool_u, uint32_t(n_slots));
+                                   (uint32_t*)d->pool_u, uint32_t(n_slots), (int32_t*)d->spill);
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -1030,7 +1046,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
                         hc.dbg[9] ? double(hc.dbg[10]) / hc.dbg[9] : 0.0, hc.dbg[11] / w64, hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
             }
         }
-        stats->n_nodes = uint32_t(s->flat.nodes.size());
+        stats->n_nodes = uint32_t(s->flat.nodes4.size());
         stats->n_prims = s->flat.n_prims_in_bvh;
         stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
         stats->reserved = plain ? 0u : 1u; // which kernel form ran: 0 lane-owns-path, 1 decoupled
@@ -1057,9 +1073,12 @@ int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     if (int r = d_out.upload(std::vector<double>(size_t(max_out) * PROBE_STRIDE + 4, 0.0))) return r;
     if (int r = d_n.upload(std::vector<int32_t>(1, 0))) { d_out.release(); return r; }
     struct Release { DevBuf<double>& a; DevBuf<int32_t>& b; ~Release() { a.release(); b.release(); } } release{d_out, d_n};
-    const size_t lds = size_t(rc.stack_depth) * 64 * sizeof(int32_t);
+    DevBuf<int32_t> d_spill;
+    if (int r = d_spill.upload(std::vector<int32_t>(std::max<size_t>(rc.stack_depth, 1), 0))) { d_out.release(); d_n.release(); return r; }
+    struct Release2 { DevBuf<int32_t>& a; ~Release2() { a.release(); } } release2{d_spill};
+    const size_t lds = size_t(LDS_STACK_ENTRIES) * 64 * sizeof(int32_t);
     hipLaunchKernelGGL(probe_path_kernel<R>, dim3(1), dim3(64), lds, 0, ds.view, narrow_camera<R>(cam64), rc, R(p->t_min), px, row,
-                       sample, d_out.p, max_out, d_n.p);
+                       sample, d_out.p, max_out, d_n.p, d_spill.p);
     HIP_TRY(hipGetLastError());
     int32_t n = 0;
     HIP_TRY(hipMemcpy(&n, d_n.p, sizeof(n), hipMemcpyDeviceToHost));
@@ -1098,10 +1117,10 @@ int rttnw_tile_layout_get(uint32_t width, uint32_t height, uint32_t world, rttnw
 int rttnw_scene_info(rttnw_scene* s, rttnw_stats* out) {
     if (!s || !out || !s->committed) { rt::set_last_error("scene_info: scene not committed"); return RTTNW_ERR_STATE; }
     std::memset(out, 0, sizeof(*out));
-    out->n_nodes = uint32_t(s->flat.nodes.size());
+    out->n_nodes = uint32_t(s->flat.nodes4.size());
     out->n_prims = s->flat.n_prims_in_bvh;
     const auto& f = s->flat;
-    size_t b32 = f.nodes.size() * sizeof(rt::BvhNode) + f.spheres.size() * sizeof(rt::SphereRec<float>) +
+    size_t b32 = f.nodes4.size() * sizeof(rt::Bvh4Node) + f.spheres.size() * sizeof(rt::SphereRec<float>) +
                  f.moving.size() * sizeof(rt::MovingSphereRec<float>) + f.rects.size() * sizeof(rt::RectRec<float>) +
                  f.boxes.size() * sizeof(rt::BoxRec<float>) + f.insts.size() * sizeof(rt::InstanceRec<float>);
     out->scene_bytes = uint32_t(std::min<size_t>(b32, 0xFFFFFFFFu));

@@ -229,36 +229,46 @@ template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     }
     return sr;
 }
-RT_HD bool slab_hit(const float* lo, const float* hi, V3<double>, const SlabRay<double>& sr, double tmin, double tmax, double& t_enter) {
+// Child c of a 4-wide record (rt_types.hpp Bvh4Node: planes stored by axis).  `e` = the entry distance as a float >= tmin
+// (ordering key only).
+RT_HD bool slab_hit4(const Bvh4Node& nd, int c, V3<double>, const SlabRay<double>& sr, double tmin, double tmax, float& e) {
     float lo_t = float(tmin), hi_t = float(tmax);
     lo_t = __builtin_fmaf(-rt_fabs(lo_t), 2.4e-7f, lo_t); // outward: float() rounds to nearest
     hi_t = __builtin_fmaf(rt_fabs(hi_t), 2.4e-7f, hi_t);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float t0 = (lo[a] - sr.o[a]) * sr.inv[a], t1 = (hi[a] - sr.o[a]) * sr.inv[a];
+        const float t0 = (nd.lo[a][c] - sr.o[a]) * sr.inv[a], t1 = (nd.hi[a][c] - sr.o[a]) * sr.inv[a];
         float n = sr.inv[a] < 0.f ? t1 : t0, f = sr.inv[a] < 0.f ? t0 : t1;
         n = __builtin_fmaf(-rt_fabs(n), 2.4e-7f, n) - sr.slack[a];
         f = __builtin_fmaf(rt_fabs(f), 2.4e-7f, f) + sr.slack[a];
         lo_t = rt_max(n, lo_t); // maxNum / minNum: a NaN plane (0 * inf) drops out
         hi_t = rt_min(f, hi_t);
     }
-    t_enter = double(lo_t);
+    e = lo_t;
     return !(hi_t < lo_t);
 }
-template <typename R>
-RT_HD bool slab_hit(const float* lo, const float* hi, V3<R> o, const SlabRay<R>& sr, R tmin, R tmax, R& t_enter) {
-    const V3<R> inv = sr.inv;
-    R t0x = (R(lo[0]) - o.x) * inv.x, t1x = (R(hi[0]) - o.x) * inv.x;
-    R t0y = (R(lo[1]) - o.y) * inv.y, t1y = (R(hi[1]) - o.y) * inv.y;
-    R t0z = (R(lo[2]) - o.z) * inv.z, t1z = (R(hi[2]) - o.z) * inv.z;
-    R nx = inv.x < R(0) ? t1x : t0x, fx = inv.x < R(0) ? t0x : t1x;
-    R ny = inv.y < R(0) ? t1y : t0y, fy = inv.y < R(0) ? t0y : t1y;
-    R nz = inv.z < R(0) ? t1z : t0z, fz = inv.z < R(0) ? t0z : t1z;
+RT_HD bool slab_hit4(const Bvh4Node& nd, int c, V3<float> o, const SlabRay<float>& sr, float tmin, float tmax, float& e) {
+    const V3<float> inv = sr.inv;
+    const float t0x = (nd.lo[0][c] - o.x) * inv.x, t1x = (nd.hi[0][c] - o.x) * inv.x;
+    const float t0y = (nd.lo[1][c] - o.y) * inv.y, t1y = (nd.hi[1][c] - o.y) * inv.y;
+    const float t0z = (nd.lo[2][c] - o.z) * inv.z, t1z = (nd.hi[2][c] - o.z) * inv.z;
+    const float nx = inv.x < 0.f ? t1x : t0x, fx = inv.x < 0.f ? t0x : t1x;
+    const float ny = inv.y < 0.f ? t1y : t0y, fy = inv.y < 0.f ? t0y : t1y;
+    const float nz = inv.z < 0.f ? t1z : t0z, fz = inv.z < 0.f ? t0z : t1z;
     tmin = rt_max(nz, rt_max(ny, rt_max(nx, tmin)));
     tmax = rt_min(fz, rt_min(fy, rt_min(fx, tmax)));
-    t_enter = tmin;
+    e = tmin;
     // f32: absorb the rounding of (bound - o) * inv and of the 1-2 ulp reciprocal (boxes are already padded)
-    return !((tmax > R(0) ? tmax * R(1.0000005) : tmax) < tmin);
+    return !((tmax > 0.f ? tmax * 1.0000005f : tmax) < tmin);
+}
+RT_HD uint32_t float_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return u;
+#endif
 }
 
 // ---------------------------------------------------------------- primitive tests: t only
@@ -458,25 +468,35 @@ template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray
     tr.node = node;
 }
 
-// One inner node (tr.node >= 0): test both child boxes, descend into the nearer hit child, push the other.
+// One inner node (tr.node >= 0): test the (up to) four child boxes, descend into the nearest hit child, push the others
+// farthest first.  The hit children are ordered by a 4-key sorting network on integers: key = the bits of the (positive)
+// entry distance with the slot number in the two lowest bits (4 ulps of ordering noise, which only ever changes the
+// order of visits, never a result), 0xFFFFFFFF for a miss — five min/max pairs instead of compare-and-select chains.
+RT_HD void key_swap(uint32_t& a, uint32_t& b) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo; b = hi;
+}
+RT_HD int32_t child_of(const Bvh4Node& nd, uint32_t slot) {
+    const int32_t c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3]; // scalar copies: no pointer select
+    return (slot & 1u) ? ((slot & 2u) ? c3 : c1) : ((slot & 2u) ? c2 : c0);
+}
 template <typename R, typename Stack, typename Cnt>
 RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
-    const BvhNode nd = stack.node(sc, tr.node); // from global memory, or from LDS when the kernel keeps the tree there
+    const Bvh4Node nd = stack.node(sc, tr.node); // from global memory, or from LDS when the kernel keeps the tree there
     cnt.node();
-    R e0, e1;
-    const bool h0 = slab_hit(nd.lo0, nd.hi0, tr.ray.o, tr.sr, t_min, tr.closest, e0);
-    const bool h1 = slab_hit(nd.lo1, nd.hi1, tr.ray.o, tr.sr, t_min, tr.closest, e1);
-    if (h0 && h1) {
-        const bool swap = e1 < e0; // nearer child first
-        stack.set(tr.sp++, swap ? nd.child0 : nd.child1);
-        tr.node = swap ? nd.child1 : nd.child0;
-    } else if (h0) {
-        tr.node = nd.child0;
-    } else if (h1) {
-        tr.node = nd.child1;
-    } else {
-        trav_pop(tr, wray, stack);
+    uint32_t k[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float e;
+        const bool h = slab_hit4(nd, c, tr.ray.o, tr.sr, t_min, tr.closest, e) && nd.child[c] != CHILD_EMPTY;
+        k[c] = h ? ((float_bits(e) & ~3u) | uint32_t(c)) : 0xFFFFFFFFu;
     }
+    key_swap(k[0], k[1]); key_swap(k[2], k[3]); key_swap(k[0], k[2]); key_swap(k[1], k[3]); key_swap(k[1], k[2]);
+    if (k[0] == 0xFFFFFFFFu) { trav_pop(tr, wray, stack); return; }
+    if (k[3] != 0xFFFFFFFFu) stack.set(tr.sp++, child_of(nd, k[3] & 3u));
+    if (k[2] != 0xFFFFFFFFu) stack.set(tr.sp++, child_of(nd, k[2] & 3u));
+    if (k[1] != 0xFFFFFFFFu) stack.set(tr.sp++, child_of(nd, k[1] & 3u));
+    tr.node = child_of(nd, k[0] & 3u);
 }
 
 // One step at a leaf (tr.node < 0, not TRAV_DONE): enter an instance, or test ONE primitive record.  WHOLE_LEAF tests

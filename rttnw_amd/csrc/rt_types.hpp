@@ -54,6 +54,28 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// What the kernels walk: a 4-WIDE node, one 128-byte record (one L2 line) holding the boxes of up to FOUR children,
+// made by collapsing the builders' binary tree (scene_lower.cpp collapse4).  A walk then has about half the dependent
+// steps — in a wave whose 64 lanes wait for the longest walk of every bounce, the number of lockstep steps, not the
+// number of box tests, is what the time goes to.  Boxes are stored by axis (lo[axis][child]) so that the four children's
+// planes of one axis arrive as one 16-byte read; an unused slot has child == CHILD_EMPTY and an inverted box.
+struct alignas(16) Bvh4Node {
+    float lo[3][4];
+    float hi[3][4];
+    int32_t child[4];
+    int32_t pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
+constexpr uint32_t BVH4_USED_SIXTEENTHS = 7; // 16-byte pieces of a record that carry data (the LDS copy leaves the pad out)
+// Traversal stack: the first LDS_STACK_ENTRIES entries of a lane live in LDS, deeper ones (a 4-wide walk can have three
+// pending children per level, but rarely has) in a per-lane strip of global memory.
+constexpr uint32_t LDS_STACK_ENTRIES = 16;
+// LDS bytes of the lane-owns-path kernel's resident form: node records (without their pad) + the lanes' stacks.
+inline size_t lds_form_bytes(uint32_t n_nodes4, uint32_t stack_depth, uint32_t block) {
+    const uint32_t in_lds = stack_depth < LDS_STACK_ENTRIES ? stack_depth : LDS_STACK_ENTRIES;
+    return size_t(n_nodes4) * 16 * BVH4_USED_SIXTEENTHS + size_t(in_lds) * block * sizeof(int32_t);
+}
+
 // `seq` in the records below: position of the object in the reference's traversal order of the
 // world List (depth-first).  List::hit lets a LATER item replace an earlier one at exactly equal t
 // (hittable.rs:157-159) — e.g. the Cornell blocks' bottom faces coincide with the floor — so exact
@@ -110,7 +132,7 @@ template <typename R> struct CameraRec { // Camera — camera.rs:18-29
 
 // Everything a lane needs, by pointer.  Same struct for HBM- and LDS-resident node/primitive arrays.
 template <typename R> struct SceneView {
-    const BvhNode* nodes;
+    const Bvh4Node* nodes;
     const SphereRec<R>* spheres;
     const int32_t* sphere_mat;
     const int32_t* sphere_seq; // list-order sequence numbers, read only to break exact ties in t

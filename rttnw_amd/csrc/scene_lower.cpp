@@ -517,6 +517,59 @@ struct Lowering {
         }
     }
 
+    // ---- binary tree -> 4-wide records (rt_types.hpp Bvh4Node).  A node takes its two children and then, while it has
+    // fewer than four, replaces the inner child of largest surface area by that child's two children.  Returns the
+    // index of the record; `need` = stack entries a walk below this record can have pending at once: a visit pushes
+    // every hit child but the one it descends into, so need = (children - 1) + the largest need among the children.
+    struct Slot { float lo[3], hi[3]; int32_t child; };
+    static double slot_area(const Slot& s) {
+        const double d[3] = {double(s.hi[0]) - s.lo[0], double(s.hi[1]) - s.lo[1], double(s.hi[2]) - s.lo[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0;
+        return 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+    static void child_slots(const BvhNode& nd, Slot* out, int& n) { // the non-empty children of a binary node
+        if (nd.child0 != CHILD_EMPTY) { Slot& s = out[n++]; std::memcpy(s.lo, nd.lo0, 12); std::memcpy(s.hi, nd.hi0, 12); s.child = nd.child0; }
+        if (nd.child1 != CHILD_EMPTY) { Slot& s = out[n++]; std::memcpy(s.lo, nd.lo1, 12); std::memcpy(s.hi, nd.hi1, 12); s.child = nd.child1; }
+    }
+    int32_t collapse4(int32_t b, uint32_t& need) {
+        Slot slots[5];
+        int n = 0;
+        child_slots(fs.nodes[b], slots, n);
+        while (n < 4) {
+            int pick = -1;
+            double best = -1.0;
+            for (int i = 0; i < n; ++i)
+                if (slots[i].child >= 0 && slot_area(slots[i]) > best) { best = slot_area(slots[i]); pick = i; }
+            if (pick < 0) break;
+            const BvhNode inner = fs.nodes[slots[pick].child];
+            for (int i = pick; i + 1 < n; ++i) slots[i] = slots[i + 1]; // keep the order of the others
+            --n;
+            child_slots(inner, slots, n);
+        }
+        const int32_t me = int32_t(fs.nodes4.size());
+        fs.nodes4.emplace_back();
+        Bvh4Node out{};
+        uint32_t deepest = 0;
+        for (int c = 0; c < 4; ++c) {
+            if (c < n) {
+                for (int a = 0; a < 3; ++a) { out.lo[a][c] = slots[c].lo[a]; out.hi[a][c] = slots[c].hi[a]; }
+                if (slots[c].child >= 0) {
+                    uint32_t sub = 0;
+                    out.child[c] = collapse4(slots[c].child, sub);
+                    deepest = std::max(deepest, sub);
+                } else {
+                    out.child[c] = slots[c].child;
+                }
+            } else {
+                for (int a = 0; a < 3; ++a) { out.lo[a][c] = INFINITY; out.hi[a][c] = -INFINITY; }
+                out.child[c] = CHILD_EMPTY;
+            }
+        }
+        fs.nodes4[me] = out;
+        need = uint32_t(n > 0 ? n - 1 : 0) + deepest;
+        return me;
+    }
+
     int run() {
         if (g.world < 0 || g.objs[g.world].kind != GraphObj::LIST_K) return fail(-2, "commit: world not set");
         lower_textures_materials();
@@ -528,10 +581,22 @@ struct Lowering {
             if (ref_kind(md.boundary) == PRIM_NONE) return fail(ERR_UNSUPPORTED, "a constant_medium was created but is not in the world list");
         uint32_t top_depth = 0;
         Box3 wb;
-        fs.top_root = build_root(top, top_depth, wb);
-        // Entries a lane's stack can hold at once: one pending sibling per level of inner nodes of the top tree, and
-        // while inside an instance one sentinel plus the same for the instance's tree.  +1 spare.
-        fs.stack_depth = top_depth + (fs.insts.empty() ? 0u : 1u + inst_depth) + 1u;
+        fs.top_root2 = build_root(top, top_depth, wb);
+        if (rc) return rc;
+        // The kernels walk 4-wide records: collapse the top tree and every instance's tree.
+        uint32_t top_need = 0, inst_need = 0;
+        fs.top_root = collapse4(fs.top_root2, top_need);
+        bool any_tree = false;
+        for (auto& in : fs.insts) {
+            if (in.root < 0) continue; // a medium's transform chain: no tree
+            uint32_t need = 0;
+            in.root = collapse4(in.root, need);
+            inst_need = std::max(inst_need, need);
+            any_tree = true;
+        }
+        // Entries a lane's stack can hold at once: the pending children of the top tree and, while inside an instance,
+        // one sentinel plus the pending children of the instance's tree.  +1 spare.
+        fs.stack_depth = top_need + (any_tree ? 1u + inst_need : 0u) + 1u;
         return 0;
     }
 };
@@ -544,7 +609,7 @@ struct Lowering {
 // instead of 891 no longer fit beside the stacks, -14 %).  So: the finest of 1 / 2 / 4 records per leaf whose tree
 // still fits; big scenes (which never fit) take 4 and save a third of the node memory.
 static bool fits_lds_form(const FlatScene& f) {
-    return f.nodes.size() * sizeof(BvhNode) + size_t(f.stack_depth) * 1024 * sizeof(int32_t) <= 160 * 1024;
+    return lds_form_bytes(uint32_t(f.nodes4.size()), f.stack_depth, 1024) <= 160 * 1024;
 }
 int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder) {
     const bool small = g.objs.size() <= 8192 && builder == nullptr;

@@ -38,7 +38,9 @@ struct SceneGraph {
 
 // ---------------------------------------------------------------- lowered scene (f64 master copy)
 struct FlatScene {
-    std::vector<BvhNode> nodes;
+    std::vector<BvhNode> nodes;   // the builders' binary trees (kept for inspection: rttnw_debug_scene_nodes); not uploaded
+    std::vector<Bvh4Node> nodes4; // what the kernels walk: the same trees collapsed to 4-wide records
+    int32_t top_root2 = 0;        // root of the top-level binary tree in `nodes`
     std::vector<SphereRec<double>> spheres;
     std::vector<int32_t> sphere_mat;
     std::vector<int32_t> sphere_seq;
@@ -54,7 +56,7 @@ struct FlatScene {
     std::vector<double> perlin_vec;   // [n][256][3]
     std::vector<uint8_t> perlin_perm; // [n][3][256]
     int32_t top_root = 0;
-    uint32_t stack_depth = 4;         // entries a lane's traversal stack needs
+    uint32_t stack_depth = 4;         // entries a lane's traversal stack can need (exact bound for the 4-wide trees)
     uint32_t n_prims_in_bvh = 0;
 };
 

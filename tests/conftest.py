@@ -42,7 +42,9 @@ def hostsim():
     _make("tests/hostsim")
     lib = C.CDLL(so)
     b = abi.Binding(lib, "rttnw_", abi.BUILDER_FUNCS)
-    b.add([("builder", C.c_void_p, [])])
+    b.add([("builder", C.c_void_p, []),
+           ("debug_scene_nodes", C.c_int, [abi.scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
+           ("debug_scene_nodes4", C.c_int, [abi.scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)])])
     lib.hostsim_render.restype = C.c_int
     lib.hostsim_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.Params), C.c_void_p,
                                    C.POINTER(abi.Stats), C.c_int]

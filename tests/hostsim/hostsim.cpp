@@ -33,7 +33,7 @@ struct HostStack {
         while (i + 1 > seen && !g_max_stack.compare_exchange_weak(seen, i + 1, std::memory_order_relaxed)) {}
     }
     int32_t get(int i) const { return data[i]; }
-    template <typename R> BvhNode node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
+    template <typename R> Bvh4Node node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
 };
 
 template <typename R> struct HostScene {
@@ -75,7 +75,7 @@ template <typename R> struct HostScene {
         for (auto& m : f.mats) mats.push_back({m.type, m.tex, {R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2])}, R(m.param)});
         for (auto& t : f.texs) texs.push_back({t.type, t.a, t.b, 0, {R(t.color[0]), R(t.color[1]), R(t.color[2])}, R(t.scale)});
         for (double v : f.perlin_vec) perlin_vec.push_back(R(v));
-        view.nodes = f.nodes.data();
+        view.nodes = f.nodes4.data();
         view.spheres = spheres.data(); view.sphere_mat = f.sphere_mat.data(); view.sphere_seq = f.sphere_seq.data();
         view.moving = moving.data(); view.rects = rects.data(); view.boxes = boxes.data();
         view.insts = insts.data(); view.media = media.data(); view.mats = mats.data(); view.texs = texs.data();
@@ -158,7 +158,7 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
         for (auto& c : counters) {
             stats->rays += c.rays; stats->nodes_visited += c.nodes; stats->prims_tested += c.prims; stats->texel_fetches += c.texels;
         }
-        stats->n_nodes = uint32_t(s->flat.nodes.size());
+        stats->n_nodes = uint32_t(s->flat.nodes4.size());
         stats->n_prims = s->flat.n_prims_in_bvh;
     }
     return RTTNW_OK;
@@ -198,7 +198,47 @@ static int probe_path_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttn
     return int(n);
 }
 
+// Walk-length statistics of a render: hist[k] = walks that took k trips round the walk loop of `node_steps` node steps + a
+// leaf step (what a wave's lanes do in lockstep); out2 = {walks, node visits, record tests}.  Experiment support.
+static void walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, int node_steps, uint64_t* hist,
+                           uint64_t* out2) {
+    HostScene<float> hs(s->flat);
+    CameraRec<double> cam64;
+    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
+                cam->focus_distance, cam->open_time, cam->close_time, cam64);
+    CameraRec<float> camr = narrow_camera<float>(cam64);
+    RenderConsts rc{};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth; rc.quirks = p->quirks; rc.seed = p->seed;
+    V3<float> background(float(p->background[0]), float(p->background[1]), float(p->background[2]));
+    HostStack stack; LaneCounters cnt;
+    for (uint32_t row = 0; row < rc.height; ++row)
+        for (uint32_t px = 0; px < rc.width; ++px)
+            for (uint32_t si = 0; si < rc.spp; ++si) {
+                PathState<float> ps;
+                path_begin(ps, camr, rc, px, row, si);
+                for (;;) {
+                    Trav<float> tr;
+                    trav_begin(tr, hs.view, ps.ray);
+                    uint32_t trips = 0;
+                    while (tr.node != TRAV_DONE) {
+                        ++trips;
+                        for (int k = 0; k < node_steps; ++k)
+                            if (tr.node >= 0) trav_node_step(tr, hs.view, ps.ray, float(p->t_min), stack, cnt);
+                        if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, hs.view, ps.ray, float(p->t_min), stack, cnt);
+                    }
+                    hist[trips < 63 ? trips : 63]++;
+                    out2[0]++;
+                    if (!path_shade(ps, hs.view, rc, background, float(p->t_min), tr.found, tr.closest, tr.best, cnt)) break;
+                }
+            }
+    out2[1] = cnt.nodes; out2[2] = cnt.prims;
+}
+
 extern "C" {
+void hostsim_walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, int node_steps, uint64_t* hist,
+                            uint64_t* out2) {
+    walk_histogram(s, cam, p, node_steps, hist, out2);
+}
 int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
                    rttnw_stats* stats, int n_threads) {
     if (!s || !s->committed || !cam || !p || !out_linear) return RTTNW_ERR_INVALID;
@@ -222,7 +262,7 @@ int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t n_tiles, uint32_t w
 int hostsim_max_stack() { return g_max_stack.exchange(0); }
 int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, rects, boxes, insts, media, stack_depth */) {
     if (!s || !s->committed) return RTTNW_ERR_INVALID;
-    out[0] = uint32_t(s->flat.nodes.size()); out[1] = uint32_t(s->flat.spheres.size()); out[2] = uint32_t(s->flat.moving.size());
+    out[0] = uint32_t(s->flat.nodes4.size()); out[1] = uint32_t(s->flat.spheres.size()); out[2] = uint32_t(s->flat.moving.size());
     out[3] = uint32_t(s->flat.rects.size()); out[4] = uint32_t(s->flat.boxes.size()); out[5] = uint32_t(s->flat.insts.size());
     out[6] = uint32_t(s->flat.media.size()); out[7] = s->flat.stack_depth;
     return RTTNW_OK;

@@ -15,9 +15,7 @@ from rttnw_amd import scene as S
 
 pytestmark = pytest.mark.gpu
 
-NODE = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("child", "<i4", 2), ("pad", "<i4", 2)])
-assert NODE.itemsize == 64
-CHILD_EMPTY = -2**31
+CHILD_EMPTY = util.CHILD_EMPTY
 
 # (scene, param, width, height, spp): every primitive kind, instances, media, an un-BVH'd list, a deep tree
 SCENES = [("cornell_box", 0, 64, 64, 8), ("smoke_cornell_box", 0, 48, 48, 4), ("final_scene", 0, 64, 64, 4),
@@ -26,11 +24,7 @@ SCENES = [("cornell_box", 0, 64, 64, 8), ("smoke_cornell_box", 0, 48, 48, 4), ("
 
 
 def nodes_of(gpu, sc):
-    n = gpu.debug_scene_nodes(sc.handle, None, 0, None)
-    buf = np.zeros(n, dtype=NODE)
-    root = C.c_int32()
-    assert gpu.debug_scene_nodes(sc.handle, buf.ctypes.data, n, C.byref(root)) == n
-    return buf, root.value
+    return util.nodes_of(gpu, sc)
 
 
 @pytest.mark.parametrize("case", SCENES, ids=[c[0] for c in SCENES])
@@ -78,7 +72,11 @@ def test_lbvh_structure(gpu, scenes_lib):
                 seen_leaf.add(key)
     assert len(seen_node) == len(nodes) and len(seen_leaf) == bi.n_prims
     assert sum(1 for k, _ in seen_leaf if k == 0) == n_spheres  # PRIM_SPHERE = 0
-    assert depth_max + 1 == bi.stack_depth  # one pending sibling per inner level, + 1 spare (no instances here)
+    # the kernels walk the 4-wide collapse of this tree: the same leaves, and a stack bound that covers its deepest walk
+    n4, root4 = util.nodes_of(gpu, sc, wide=True)
+    leaves4, need, seen4 = util.check_wide_tree(n4, root4)
+    assert len(seen4) == len(n4) == bi.n_nodes and len(leaves4) == bi.n_prims
+    assert need + 1 == bi.stack_depth and bi.stack_depth <= 3 * ((depth_max + 1) // 2) + 1  # three pending children per wide level at most
 
 
 def test_lbvh_small_and_empty_worlds(gpu):
@@ -124,7 +122,8 @@ def test_full_size_config5_invariants(gpu, scenes_lib):
     a run repeats exactly, and the partition over 8 ranks reassembles to the single-rank image."""
     s_sah, setup = util.build(gpu, scenes_lib, "spheres_1m", None, 0)
     s_lbvh, _ = util.build(gpu, scenes_lib, "spheres_1m", None, 0, bvh=abi.BVH_DEVICE_LBVH)
-    assert s_sah.build_info().n_prims == 1000001 and s_lbvh.build_info().n_nodes == 1000000
+    assert s_sah.build_info().n_prims == 1000001 and gpu.debug_scene_nodes(s_lbvh.handle, None, 0, None) == 1000000
+    assert 330000 <= s_lbvh.build_info().n_nodes <= 520000                       # 4-wide records: a third to a half of the binary nodes
     cam, p = util.params_for(setup, 1024, 1024, 2, precision=abi.F32, seed=7)
     a, rgba_a, st = render.render_host(s_sah, cam, p)
     b, rgba_b, _ = render.render_host(s_lbvh, cam, p)

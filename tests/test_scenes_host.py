@@ -77,3 +77,20 @@ def test_oracle_reproduces_goldens(oracle, scenes_lib, earth, case):
     lin, rgba, _ = rto.render(sc, cam, p)
     g = load()
     assert np.array_equal(lin, g[key + "_linear"]) and np.array_equal(rgba, g[key + "_rgba8"])
+
+
+@pytest.mark.parametrize("name,param", [("cornell_box", 0), ("final_scene", 0), ("random_scene", 0), ("smoke_cornell_box", 0),
+                                        ("spheres_1m", 5000), ("two_spheres", 0)])
+def test_wide_nodes_are_the_collapsed_binary_tree(hostsim, scenes_lib, earth, name, param):
+    """The kernels walk 4-wide records made by collapsing the builder's binary tree (scene_lower.cpp collapse4): the top-level
+    wide tree holds exactly the leaves of the top-level binary tree, boxes nest, every record of every tree is reached
+    from the top root or an instance's root, and the traversal-stack bound the lowering reports covers the deepest walk."""
+    sc, _ = util.build(hostsim, scenes_lib, name, earth, param)
+    n2, root2 = util.nodes_of(hostsim, sc)
+    n4, root4 = util.nodes_of(hostsim, sc, wide=True)
+    leaves4, need, seen = util.check_wide_tree(n4, root4)
+    assert leaves4 == util.leaves_of_binary(n2, root2)
+    assert len(n4) <= max(1, (len(n2) + 1) // 2 + 2) or len(n2) < 8          # about half as many records (a third when the tree is full)
+    dims = (C.c_uint32 * 8)()
+    hostsim.lib.hostsim_scene_dims(sc.handle, dims)
+    assert need + 1 <= dims[7]   # (+ the instances' trees, held against real walks by test_core_f64_equals_golden)

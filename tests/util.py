@@ -72,3 +72,58 @@ def compare_paths(probe, oracle_probe, pairs, tol=1e-9):
     flat = [mat_map[i] for i in ids]
     assert flat == sorted(flat) and len(set(flat)) == len(flat), mat_map
     return len(pairs), bounces, mat_map
+
+
+# ---- node records (include/rttnw_hip.h rttnw_debug_scene_nodes / rttnw_debug_scene_nodes4)
+NODE2 = np.dtype([("lo0", "<f4", 3), ("hi0", "<f4", 3), ("lo1", "<f4", 3), ("hi1", "<f4", 3), ("child", "<i4", 2), ("pad", "<i4", 2)])
+NODE4 = np.dtype([("lo", "<f4", (3, 4)), ("hi", "<f4", (3, 4)), ("child", "<i4", 4), ("pad", "<i4", 4)])
+assert NODE2.itemsize == 64 and NODE4.itemsize == 128
+CHILD_EMPTY = -2**31
+
+
+def nodes_of(binding, sc, wide=False):
+    fn = binding.debug_scene_nodes4 if wide else binding.debug_scene_nodes
+    n = fn(sc.handle, None, 0, None)
+    buf = np.zeros(n, dtype=NODE4 if wide else NODE2)
+    root = C.c_int32()
+    assert fn(sc.handle, buf.ctypes.data, n, C.byref(root)) == n
+    return buf, root.value
+
+
+def leaves_of_binary(nodes, root):
+    out, stack = [], [root]
+    while stack:
+        nd = nodes[stack.pop()]
+        for ch in nd["child"]:
+            if ch >= 0:
+                stack.append(int(ch))
+            elif ch != CHILD_EMPTY:
+                out.append(int(ch))
+    return sorted(out)
+
+
+def check_wide_tree(nodes4, root):
+    """Walk a 4-wide tree: every record reached once, a child's boxes inside the slot box its parent holds for it, unused
+    slots empty.  Returns (sorted leaf codes, stack entries a walk can have pending = what the lowering must bound)."""
+    leaves, seen = [], set()
+
+    def visit(i, plo, phi):
+        assert i not in seen
+        seen.add(i)
+        nd = nodes4[i]
+        k, deepest = 0, 0
+        for c in range(4):
+            ch, lo, hi = int(nd["child"][c]), nd["lo"][:, c], nd["hi"][:, c]
+            if ch == CHILD_EMPTY:
+                assert (lo > hi).all()
+                continue
+            k += 1
+            assert (lo <= hi).all() and (lo >= plo).all() and (hi <= phi).all()
+            if ch >= 0:
+                deepest = max(deepest, visit(ch, lo, hi))
+            else:
+                leaves.append(ch)
+        return max(k - 1, 0) + deepest
+
+    need = visit(root, np.full(3, -np.inf, np.float32), np.full(3, np.inf, np.float32))
+    return sorted(leaves), need, seen

@@ -41,6 +41,7 @@ WORKLOADS = {
     "final_scene_1600": ("final_scene", 1600, 1600, 1250, 0),   # configs[3] when run on 8 GPUs (spp = 1250 x N)
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+NODE_VISIT_BYTES = 64.0  # accounting price of one visit of a 4-wide (128-byte, four-box) node record: 16 B per child box, as in round 1
 PROFILE_ROUND = "r02"
 KERNEL_SOURCES = ["rttnw_amd/csrc/render.hip", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp", "rttnw_amd/csrc/Makefile"]
 
@@ -148,15 +149,16 @@ def main():
 
     def counted(prec):
         """Algorithmic bytes per sample, counted by the counting kernel variant on this rank's tiles (untimed).
-        A BVH node visit is priced at the 32-B accounting record of BASELINE.md although the node records here are 64 B
-        and hold both children's boxes (one visit = one record fetch = two box tests)."""
+        Node records are priced per child box at the rate round 1 used — its 64-byte two-box record counted as ONE 32-B
+        accounting record of BASELINE.md, so the 128-byte four-box record the kernels walk now counts as TWO (64 B): half
+        the bytes a visit physically reads, in both rounds."""
         cam_c, pc = util.params_for(setup, W, H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, collect_counters=args.counter_level)
         rc_ = render.DeviceRenderer(sc, cam_c, pc)
         st = abi.Stats()
         rc_.trace(st)
         n = max(1, st.samples)
         per = dict(rays=st.rays / n, nodes=st.nodes_visited / n, prims=st.prims_tested / n, texels=st.texel_fetches / n)
-        return 32.0 * per["nodes"] + 32.0 * per["prims"] + 4.0 * per["texels"] + 16.0 / spp, per, st.reserved
+        return NODE_VISIT_BYTES * per["nodes"] + 32.0 * per["prims"] + 4.0 * per["texels"] + 16.0 / spp, per, st.reserved
 
     def timed(prec, steps, warmup):
         """`steps` timed steps after `warmup` untimed ones: (ms_per_step over the barrier-bracketed region, mean device
@@ -202,8 +204,9 @@ def main():
                 "kernel_ms": round(kernel_ms, 3), "alg_bytes_per_sample": round(b_alg, 2),
                 "alg_bytes_per_launch": round(b_alg * samples_rank),
                 "per_sample": {k: round(v, 3) for k, v in per.items()},
-                "note": "scene is L2/MALL-resident; achieved = counted algorithmic bytes / kernel time; a node visit is priced at 32 B "
-                        "(BASELINE.md) although a node record is 64 B (both children's boxes)"}
+                "note": "scene is L2/MALL-resident; achieved = counted algorithmic bytes / kernel time; alg bytes = 64 B x node visits "
+                        "(a 128-byte 4-wide record priced at two 32-B accounting records: 16 B per child box, the rate round 1 "
+                        "applied to its 64-byte 2-box records) + 32 B x primitive tests + 4 B x texels + 16 B / spp"}
 
     # ---- timed region (the reported precision)
     ms_per_step, kernel_ms = timed(precision, args.steps, args.warmup)

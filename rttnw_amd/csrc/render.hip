@@ -29,6 +29,10 @@
 #include <string>
 #include <vector>
 
+#ifndef RT_F64_BLOCK
+#define RT_F64_BLOCK 768 // threads per block of the LDS-resident f64 kernel: 3 waves/SIMD at 168 VGPRs (512 / 768 / 1024: 718 / 885 / 874 Msamples/s on final_scene, 1004 / 1344 / 1166 on cornell_box; the spills at 768 are kernel-invariant values reloaded in shade)
+#endif
+
 namespace rt {
 
 // ---------------------------------------------------------------------------------------------
@@ -38,33 +42,55 @@ namespace rt {
 // e*stride + l: conflict-free b32 accesses), deeper ones in a strip of global memory (entry e of thread g at
 // e*spill_stride + g; a 4-wide walk can have three pending children per level but rarely has more than a dozen) — and
 // the way it reads node records.
-struct LdsStack {
-    int32_t* base;         // &lds[threadIdx.x]
-    uint32_t stride;       // blockDim.x
-    int32_t* spill;        // &spill_buffer[global thread]
+typedef __attribute__((address_space(3))) int32_t* LdsIntPtr;    // explicit address spaces: the compiler otherwise merges
+typedef __attribute__((address_space(1))) int32_t* GlobalIntPtr; // the two halves of get() into one FLAT load
+template <uint32_t STRIDE> struct LdsStack { // STRIDE = lanes sharing the LDS stack area: entry e of a lane at base[e * STRIDE]
+    static constexpr int SPARE = int(LDS_STACK_ENTRIES); // a lane's extra LDS slot: target of the node step's masked-off stores
+    LdsIntPtr base;        // &lds[threadIdx.x]
+    GlobalIntPtr spill;    // &spill_buffer[global thread]
     uint32_t spill_stride; // threads of the launch
     __device__ __forceinline__ void set(int i, int32_t v) {
-        if (uint32_t(i) < LDS_STACK_ENTRIES) base[uint32_t(i) * stride] = v;
+        if (uint32_t(i) < LDS_STACK_ENTRIES) base[uint32_t(i) * STRIDE] = v;
         else spill[size_t(uint32_t(i) - LDS_STACK_ENTRIES) * spill_stride] = v;
     }
     __device__ __forceinline__ int32_t get(int i) const {
-        if (uint32_t(i) < LDS_STACK_ENTRIES) return base[uint32_t(i) * stride];
+        if (uint32_t(i) < LDS_STACK_ENTRIES) return base[uint32_t(i) * STRIDE];
         return spill[size_t(uint32_t(i) - LDS_STACK_ENTRIES) * spill_stride];
     }
-    template <typename R> __device__ __forceinline__ Bvh4Node node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
+    // a node step that finds entries i, i+1, i+2 inside the LDS part writes them without looking at the spill strip
+    __device__ __forceinline__ bool room_for_three(int i) const { return uint32_t(i) + 3u <= LDS_STACK_ENTRIES; }
+    __device__ __forceinline__ void set_fast(int i, int32_t v) { base[uint32_t(i) * STRIDE] = v; }
+    // node records in global memory: a plane piece is addressed by its index inside the 128-byte record
+    __device__ __forceinline__ uint32_t plane_off(uint32_t q) const { return q; }
+    template <typename R> __device__ __forceinline__ void fetch(const SceneView<R>& sc, int32_t i, const uint32_t* near_off, Planes4& out) const {
+        const int4* rec = reinterpret_cast<const int4*>(sc.nodes + i);
+        union { int4 q[7]; struct { float nr[3][4], fr[3][4]; int32_t child[4]; } p; } u;
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a) {
+            u.q[a] = rec[near_off[a]];
+            u.q[3 + a] = rec[2u * a + 3u - near_off[a]]; // the other one of (a, a + 3)
+        }
+        u.q[6] = rec[6];
+        __builtin_memcpy(&out, &u, sizeof(out));
+    }
 };
 // Same, with the whole node array resident in LDS in PIECE-MAJOR order: the q-th 16 bytes of node i at
 // piece[q*n_nodes + i] (q < 7: the pad is left out).  64 lanes fetching the same piece of 64 unrelated nodes then spread
 // over all the 16-byte bank slots (i mod 16); in node-major order the 128-byte records would all start at the same two
 // — measured on the 64-byte binary records: 31 % of the LDS cycles were bank conflicts that way.
-struct LdsStackNodes : LdsStack {
+template <uint32_t STRIDE> struct LdsStackNodes : LdsStack<STRIDE> {
     const int4* piece; // LDS
     uint32_t n_nodes;
-    template <typename R> __device__ __forceinline__ Bvh4Node node(const SceneView<R>&, int32_t i) const {
-        union { int4 q[8]; Bvh4Node n; } u;
+    __device__ __forceinline__ uint32_t plane_off(uint32_t q) const { return q * n_nodes; }
+    template <typename R> __device__ __forceinline__ void fetch(const SceneView<R>&, int32_t i, const uint32_t* near_off, Planes4& out) const {
+        union { int4 q[7]; struct { float nr[3][4], fr[3][4]; int32_t child[4]; } p; } u;
 #pragma unroll
-        for (uint32_t k = 0; k < BVH4_USED_SIXTEENTHS; ++k) u.q[k] = piece[k * n_nodes + uint32_t(i)];
-        return u.n;
+        for (uint32_t a = 0; a < 3; ++a) {
+            u.q[a] = piece[near_off[a] + uint32_t(i)];
+            u.q[3 + a] = piece[(2u * a + 3u) * n_nodes - near_off[a] + uint32_t(i)];
+        }
+        u.q[6] = piece[6u * n_nodes + uint32_t(i)];
+        __builtin_memcpy(&out, &u, sizeof(out));
     }
 };
 
@@ -110,7 +136,7 @@ enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, 
 enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
 // bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
 template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
-    return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (stack_depth < LDS_STACK_ENTRIES ? stack_depth : LDS_STACK_ENTRIES) * 64u * 4u;
+    return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (LDS_STACK_ENTRIES + 1u) * 64u * 4u; // stack: + the spare slot
 }
 constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
 
@@ -162,7 +188,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
     int32_t* const hq_prim = reinterpret_cast<int32_t*>(rq_slot + QCAP);
     int32_t* const hq_inst = hq_prim + QCAP;
     uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
-    LdsStack stack{reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane, 64u, spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x), gridDim.x * TRACE_BLOCK};
+    LdsStack<64> stack{(LdsIntPtr)(reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane), (GlobalIntPtr)(spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x)), gridDim.x * TRACE_BLOCK};
 
     const uint32_t wave_global = blockIdx.x * (TRACE_BLOCK / 64) + wave_in_block;
     const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
                 wray.time = rq_f[6u * QCAP + e];
                 slot = rq_slot[e];
                 cnt.ray();
-                trav_begin(tr, sc, wray);
+                trav_begin(tr, sc, wray, stack);
                 has_ray = true;
             }
             ray_n -= take;
@@ -368,9 +394,8 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
     // LDSN: the whole node array is copied into LDS (piece-major, see LdsStackNodes) in front of the stacks — small
     // scenes: one dependent ~100-cycle LDS read per node visit instead of an L1/L2 round trip
     extern __shared__ __align__(16) int32_t lds_stack[];
-    typename std::conditional<LDSN, LdsStackNodes, LdsStack>::type stack;
-    stack.stride = blockDim.x;
-    stack.spill = spill + (blockIdx.x * blockDim.x + threadIdx.x);
+    typename std::conditional<LDSN, LdsStackNodes<BLOCK>, LdsStack<BLOCK>>::type stack;
+    stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * blockDim.x + threadIdx.x));
     stack.spill_stride = gridDim.x * blockDim.x;
     if constexpr (LDSN) {
         const uint32_t n = rc.lds_nodes;
@@ -379,11 +404,11 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
         for (uint32_t i = threadIdx.x; i < n * 8u; i += blockDim.x)
             if ((i & 7u) < BVH4_USED_SIXTEENTHS) dst[(i & 7u) * n + (i >> 3)] = src[i];
         __syncthreads();
-        stack.base = lds_stack + n * (4u * BVH4_USED_SIXTEENTHS) + threadIdx.x;
+        stack.base = (LdsIntPtr)(lds_stack + n * (4u * BVH4_USED_SIXTEENTHS) + threadIdx.x);
         stack.piece = dst;
         stack.n_nodes = n;
     } else {
-        stack.base = lds_stack + threadIdx.x;
+        stack.base = (LdsIntPtr)(lds_stack + threadIdx.x);
     }
     typename CounterSel<COUNT>::type cnt;
 
@@ -463,7 +488,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
             if (alive) {
                 cnt.ray();
                 Trav<R> tr;
-                trav_begin(tr, sc, ps.ray);
+                trav_begin(tr, sc, ps.ray, stack);
                 while (tr.node != TRAV_DONE) {
                     ++my_trips;
                     // the loop body of closest_solid() (two node steps, then a leaf step for the lanes at a leaf by then), tallied
@@ -614,7 +639,7 @@ __global__ void probe_path_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConst
                                   int32_t* __restrict__ spill) {
     extern __shared__ int32_t lds_stack[];
     if (threadIdx.x != 0) return;
-    LdsStack stack{lds_stack, blockDim.x, spill, 1u};
+    LdsStack<64> stack{(LdsIntPtr)lds_stack, (GlobalIntPtr)spill, 1u};
     NoCounters cnt;
     PathState<R> ps;
     path_begin(ps, cam, rc, px, row, sample);
@@ -934,7 +959,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
         if (plain) {
             // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
             // 1024 threads (4 waves/SIMD at <= 128 VGPRs) for f32, 512 threads (2 waves/SIMD, all the 256-VGPR f64 code allows)
-            constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : 512;
+            constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : RT_F64_BLOCK;
             const uint32_t n4 = uint32_t(s->flat.nodes4.size());
             const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) <= 160 * 1024;
             rc.lds_nodes = want_lds ? n4 : 0u;
@@ -1076,7 +1101,7 @@ int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     DevBuf<int32_t> d_spill;
     if (int r = d_spill.upload(std::vector<int32_t>(std::max<size_t>(rc.stack_depth, 1), 0))) { d_out.release(); d_n.release(); return r; }
     struct Release2 { DevBuf<int32_t>& a; ~Release2() { a.release(); } } release2{d_spill};
-    const size_t lds = size_t(LDS_STACK_ENTRIES) * 64 * sizeof(int32_t);
+    const size_t lds = size_t(LDS_STACK_ENTRIES + 1) * 64 * sizeof(int32_t);
     hipLaunchKernelGGL(probe_path_kernel<R>, dim3(1), dim3(64), lds, 0, ds.view, narrow_camera<R>(cam64), rc, R(p->t_min), px, row,
                        sample, d_out.p, max_out, d_n.p, d_spill.p);
     HIP_TRY(hipGetLastError());

@@ -11,6 +11,10 @@
 #include "rt_types.hpp"
 #include <math.h>
 
+#ifndef RT_NODE_STEPS
+#define RT_NODE_STEPS 2 // node steps per trip round the walk loop (closest_solid)
+#endif
+
 namespace rt {
 
 // ---------------------------------------------------------------- math wrappers
@@ -229,16 +233,23 @@ template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     }
     return sr;
 }
-// Child c of a 4-wide record (rt_types.hpp Bvh4Node: planes stored by axis).  `e` = the entry distance as a float >= tmin
-// (ordering key only).
-RT_HD bool slab_hit4(const Bvh4Node& nd, int c, V3<double>, const SlabRay<double>& sr, double tmin, double tmax, float& e) {
-    float lo_t = float(tmin), hi_t = float(tmax);
-    lo_t = __builtin_fmaf(-rt_fabs(lo_t), 2.4e-7f, lo_t); // outward: float() rounds to nearest
-    hi_t = __builtin_fmaf(rt_fabs(hi_t), 2.4e-7f, hi_t);
+// A 4-wide record as a lane holds it for a node step: the NEAR and the FAR plane of every axis for the four children
+// (which of lo / hi is the near one depends on the sign of the ray direction only, so the lane fetches them by address —
+// NodePlanes::near_q, set once per walk — instead of selecting per child), and the four child slots.
+struct Planes4 {
+    float nr[3][4], fr[3][4];
+    int32_t child[4];
+};
+// piece of the record (16-byte units: 0-2 lo.xyz, 3-5 hi.xyz, 6 children) holding the near planes of axis a
+template <typename R> RT_HD uint32_t near_piece(int a, const SlabRay<R>& sr) {
+    if constexpr (sizeof(R) == 8) return uint32_t(a) + (sr.inv[a] < 0.f ? 3u : 0u);
+    else return uint32_t(a) + ((a == 0 ? sr.inv.x : (a == 1 ? sr.inv.y : sr.inv.z)) < R(0) ? 3u : 0u);
+}
+// Child c of the record: `e` = the entry distance as a float >= tmin (ordering key only).
+RT_HD bool slab_hit4(const Planes4& nd, int c, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float& e) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float t0 = (nd.lo[a][c] - sr.o[a]) * sr.inv[a], t1 = (nd.hi[a][c] - sr.o[a]) * sr.inv[a];
-        float n = sr.inv[a] < 0.f ? t1 : t0, f = sr.inv[a] < 0.f ? t0 : t1;
+        float n = (nd.nr[a][c] - sr.o[a]) * sr.inv[a], f = (nd.fr[a][c] - sr.o[a]) * sr.inv[a];
         n = __builtin_fmaf(-rt_fabs(n), 2.4e-7f, n) - sr.slack[a];
         f = __builtin_fmaf(rt_fabs(f), 2.4e-7f, f) + sr.slack[a];
         lo_t = rt_max(n, lo_t); // maxNum / minNum: a NaN plane (0 * inf) drops out
@@ -247,20 +258,24 @@ RT_HD bool slab_hit4(const Bvh4Node& nd, int c, V3<double>, const SlabRay<double
     e = lo_t;
     return !(hi_t < lo_t);
 }
-RT_HD bool slab_hit4(const Bvh4Node& nd, int c, V3<float> o, const SlabRay<float>& sr, float tmin, float tmax, float& e) {
+RT_HD bool slab_hit4(const Planes4& nd, int c, V3<float> o, const SlabRay<float>& sr, float tmin, float tmax, float& e) {
     const V3<float> inv = sr.inv;
-    const float t0x = (nd.lo[0][c] - o.x) * inv.x, t1x = (nd.hi[0][c] - o.x) * inv.x;
-    const float t0y = (nd.lo[1][c] - o.y) * inv.y, t1y = (nd.hi[1][c] - o.y) * inv.y;
-    const float t0z = (nd.lo[2][c] - o.z) * inv.z, t1z = (nd.hi[2][c] - o.z) * inv.z;
-    const float nx = inv.x < 0.f ? t1x : t0x, fx = inv.x < 0.f ? t0x : t1x;
-    const float ny = inv.y < 0.f ? t1y : t0y, fy = inv.y < 0.f ? t0y : t1y;
-    const float nz = inv.z < 0.f ? t1z : t0z, fz = inv.z < 0.f ? t0z : t1z;
+    const float nx = (nd.nr[0][c] - o.x) * inv.x, fx = (nd.fr[0][c] - o.x) * inv.x;
+    const float ny = (nd.nr[1][c] - o.y) * inv.y, fy = (nd.fr[1][c] - o.y) * inv.y;
+    const float nz = (nd.nr[2][c] - o.z) * inv.z, fz = (nd.fr[2][c] - o.z) * inv.z;
     tmin = rt_max(nz, rt_max(ny, rt_max(nx, tmin)));
     tmax = rt_min(fz, rt_min(fy, rt_min(fx, tmax)));
     e = tmin;
     // f32: absorb the rounding of (bound - o) * inv and of the 1-2 ulp reciprocal (boxes are already padded)
     return !((tmax > 0.f ? tmax * 1.0000005f : tmax) < tmin);
 }
+// the walk's [t_min, closest] as the floats the slab tests compare against (f64: rounded outward once per node)
+RT_HD void slab_range(double tmin, double tmax, float& lo_t, float& hi_t) {
+    lo_t = float(tmin); hi_t = float(tmax);
+    lo_t = __builtin_fmaf(-rt_fabs(lo_t), 2.4e-7f, lo_t); // outward: float() rounds to nearest
+    hi_t = __builtin_fmaf(rt_fabs(hi_t), 2.4e-7f, hi_t);
+}
+RT_HD void slab_range(float tmin, float tmax, float& lo_t, float& hi_t) { lo_t = tmin; hi_t = tmax; }
 RT_HD uint32_t float_bits(float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __float_as_uint(f);
@@ -429,6 +444,7 @@ constexpr int32_t TRAV_DONE = INT32_MIN + 2; // Trav::node once the stack has ru
 template <typename R> struct Trav {
     Ray<R> ray;       // the ray in the current space (world, or an instance's object space)
     SlabRay<R> sr;    // 1 / ray.d (and the f32 FMA-form products)
+    uint32_t near_off[3]; // where the near planes of axis a lie in a node record, in the stack's addressing (Stack::plane_off)
     R closest;
     HitRef best;
     int32_t node;     // >= 0: inner node to visit; < 0: leaf bits (or CHILD_EMPTY); TRAV_DONE: finished
@@ -439,9 +455,14 @@ template <typename R> struct Trav {
 };
 
 
-template <typename R> RT_HD void trav_begin(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray) {
-    tr.ray = wray;
-    tr.sr = slab_ray(wray.o, wray.d);
+template <typename R, typename Stack> RT_HD void trav_set_ray(Trav<R>& tr, const Ray<R>& ray, const Stack& stack) {
+    tr.ray = ray;
+    tr.sr = slab_ray(ray.o, ray.d);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) tr.near_off[a] = stack.plane_off(near_piece(a, tr.sr));
+}
+template <typename R, typename Stack> RT_HD void trav_begin(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, const Stack& stack) {
+    trav_set_ray(tr, wray, stack);
     tr.closest = Lim<R>::max(); // world.hit(ray, t_min, f64::MAX) — main.rs:33
     tr.best.prim = make_ref(PRIM_NONE, 0);
     tr.best.inst = -1;
@@ -459,8 +480,7 @@ template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray
     if (tr.sp == 0) { tr.node = TRAV_DONE; return; }
     int32_t node = stack.get(--tr.sp);
     if (node == STACK_SENTINEL) {
-        tr.ray = wray;
-        tr.sr = slab_ray(wray.o, wray.d);
+        trav_set_ray(tr, wray, stack);
         tr.cur_inst = -1;
         if (tr.sp == 0) { tr.node = TRAV_DONE; return; }
         node = stack.get(--tr.sp);
@@ -472,31 +492,48 @@ template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray
 // farthest first.  The hit children are ordered by a 4-key sorting network on integers: key = the bits of the (positive)
 // entry distance with the slot number in the two lowest bits (4 ulps of ordering noise, which only ever changes the
 // order of visits, never a result), 0xFFFFFFFF for a miss — five min/max pairs instead of compare-and-select chains.
-RT_HD void key_swap(uint32_t& a, uint32_t& b) {
-    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-    a = lo; b = hi;
-}
-RT_HD int32_t child_of(const Bvh4Node& nd, uint32_t slot) {
-    const int32_t c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3]; // scalar copies: no pointer select
-    return (slot & 1u) ? ((slot & 2u) ? c3 : c1) : ((slot & 2u) ? c2 : c0);
+RT_HD void pair_swap(uint32_t& ka, int32_t& ca, uint32_t& kb, int32_t& cb) { // (key, child) pairs: smaller key first
+    const bool sw = kb < ka;
+    const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int32_t c0 = sw ? cb : ca, c1 = sw ? ca : cb;
+    ka = k0; kb = k1; ca = c0; cb = c1;
 }
 template <typename R, typename Stack, typename Cnt>
 RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
-    const Bvh4Node nd = stack.node(sc, tr.node); // from global memory, or from LDS when the kernel keeps the tree there
+    Planes4 nd;
+    stack.fetch(sc, tr.node, tr.near_off, nd); // from global memory, or from LDS when the kernel keeps the tree there
     cnt.node();
+    float lo_t, hi_t;
+    slab_range(t_min, tr.closest, lo_t, hi_t);
+    constexpr uint32_t MISS = 0xFFFFFFFFu;
     uint32_t k[4];
+    int32_t ch[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float e;
-        const bool h = slab_hit4(nd, c, tr.ray.o, tr.sr, t_min, tr.closest, e) && nd.child[c] != CHILD_EMPTY;
-        k[c] = h ? ((float_bits(e) & ~3u) | uint32_t(c)) : 0xFFFFFFFFu;
+        ch[c] = nd.child[c];
+        const bool h = slab_hit4(nd, c, tr.ray.o, tr.sr, lo_t, hi_t, e) && ch[c] != CHILD_EMPTY;
+        k[c] = h ? float_bits(e) : MISS; // entry distances are positive: their bit patterns order like the values
     }
-    key_swap(k[0], k[1]); key_swap(k[2], k[3]); key_swap(k[0], k[2]); key_swap(k[1], k[3]); key_swap(k[1], k[2]);
-    if (k[0] == 0xFFFFFFFFu) { trav_pop(tr, wray, stack); return; }
-    if (k[3] != 0xFFFFFFFFu) stack.set(tr.sp++, child_of(nd, k[3] & 3u));
-    if (k[2] != 0xFFFFFFFFu) stack.set(tr.sp++, child_of(nd, k[2] & 3u));
-    if (k[1] != 0xFFFFFFFFu) stack.set(tr.sp++, child_of(nd, k[1] & 3u));
-    tr.node = child_of(nd, k[0] & 3u);
+    pair_swap(k[0], ch[0], k[1], ch[1]); pair_swap(k[2], ch[2], k[3], ch[3]); pair_swap(k[0], ch[0], k[2], ch[2]);
+    pair_swap(k[1], ch[1], k[3], ch[3]); pair_swap(k[1], ch[1], k[2], ch[2]);
+    if (k[0] == MISS) { trav_pop(tr, wray, stack); return; }
+    // the other hit children become pending, farthest first
+    const int32_t n_push = int32_t(k[1] != MISS) + int32_t(k[2] != MISS) + int32_t(k[3] != MISS);
+    const int32_t sp = tr.sp;
+    if (stack.room_for_three(sp)) {
+        // the usual case, branch-free: three stores inside the LDS part of the stack, a store for a child that is not
+        // pending goes to the lane's spare slot
+        stack.set_fast(k[3] != MISS ? sp : Stack::SPARE, ch[3]);
+        stack.set_fast(k[2] != MISS ? sp + n_push - 2 : Stack::SPARE, ch[2]);
+        stack.set_fast(k[1] != MISS ? sp + n_push - 1 : Stack::SPARE, ch[1]);
+    } else {
+        if (k[3] != MISS) stack.set(sp, ch[3]);
+        if (k[2] != MISS) stack.set(sp + n_push - 2, ch[2]);
+        if (k[1] != MISS) stack.set(sp + n_push - 1, ch[1]);
+    }
+    tr.sp = sp + n_push;
+    tr.node = ch[0];
 }
 
 // One step at a leaf (tr.node < 0, not TRAV_DONE): enter an instance, or test ONE primitive record.  WHOLE_LEAF tests
@@ -538,8 +575,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
             return;
         }
         stack.set(tr.sp++, STACK_SENTINEL);
-        tr.ray = to_object(in, wray);
-        tr.sr = slab_ray(tr.ray.o, tr.ray.d);
+        trav_set_ray(tr, to_object(in, wray), stack);
         tr.cur_inst = int32_t(first);
         tr.node = in.root;
         return;
@@ -560,15 +596,16 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
 template <typename R, typename Stack, typename Cnt>
 RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R& closest, HitRef& best, Stack& stack, Cnt& cnt) {
     Trav<R> tr;
-    trav_begin(tr, sc, wray);
+    trav_begin(tr, sc, wray, stack);
     while (tr.node != TRAV_DONE) {
         // one trip: two node steps, then a leaf step for the lanes at a leaf by then.  A lane whose node step arrives at
         // a leaf tests it in the same trip, together with the lanes that were already waiting at theirs; the second node
         // step halves the trips of node-heavy walks and with them the executions of the (wide, poorly filled) leaf
         // code.  Measured, node steps per trip 1 / 2 / 3 / 4: final_scene 1288 / 1368 / 1357 / 1356 Msamples/s,
         // cornell_box 1707 / 1718 / 1665 / 1691.
-        if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
-        if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
+#pragma unroll
+        for (int k = 0; k < RT_NODE_STEPS; ++k)
+            if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
         if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
     }
     closest = tr.closest;

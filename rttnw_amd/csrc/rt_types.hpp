@@ -72,8 +72,8 @@ constexpr uint32_t BVH4_USED_SIXTEENTHS = 7; // 16-byte pieces of a record that 
 constexpr uint32_t LDS_STACK_ENTRIES = 16;
 // LDS bytes of the lane-owns-path kernel's resident form: node records (without their pad) + the lanes' stacks.
 inline size_t lds_form_bytes(uint32_t n_nodes4, uint32_t stack_depth, uint32_t block) {
-    const uint32_t in_lds = stack_depth < LDS_STACK_ENTRIES ? stack_depth : LDS_STACK_ENTRIES;
-    return size_t(n_nodes4) * 16 * BVH4_USED_SIXTEENTHS + size_t(in_lds) * block * sizeof(int32_t);
+    (void)stack_depth; // the LDS part of a stack has a fixed size (+ 1: the spare slot of the branch-free pushes)
+    return size_t(n_nodes4) * 16 * BVH4_USED_SIXTEENTHS + size_t(LDS_STACK_ENTRIES + 1) * block * sizeof(int32_t);
 }
 
 // `seq` in the records below: position of the object in the reference's traversal order of the

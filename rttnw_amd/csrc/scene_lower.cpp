@@ -613,7 +613,9 @@ static bool fits_lds_form(const FlatScene& f) {
 }
 int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder) {
     const bool small = g.objs.size() <= 8192 && builder == nullptr;
+    const char* forced = getenv("RTTNW_MAX_LEAF"); // experiments: force the leaf size of the host SAH build (1, 2 or 4)
     for (size_t max_leaf : {size_t(1), size_t(2), size_t(4)}) {
+        if (forced && *forced && size_t(atoi(forced)) != max_leaf && max_leaf != 4) continue;
         if (!small && max_leaf != 4) continue;
         out = FlatScene();
         Lowering lw{g, out, err, {}, {}, 0, builder, max_leaf};

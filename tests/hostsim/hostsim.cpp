@@ -25,15 +25,28 @@ using namespace rt;
 
 std::atomic<int> g_max_stack{0}; // deepest traversal-stack index written since the last hostsim_max_stack() call
 
-struct HostStack {
-    int32_t data[256];
+struct HostStack { // shaped like the device's: 16 entries + a spare slot "in LDS", the rest in a spill strip
+    static constexpr int SPARE = 16;
+    int32_t lds[17];
+    int32_t spill[256];
     void set(int i, int32_t v) {
-        data[i] = v;
+        (i < 16 ? lds[i] : spill[i - 16]) = v;
         int seen = g_max_stack.load(std::memory_order_relaxed);
         while (i + 1 > seen && !g_max_stack.compare_exchange_weak(seen, i + 1, std::memory_order_relaxed)) {}
     }
-    int32_t get(int i) const { return data[i]; }
-    template <typename R> Bvh4Node node(const SceneView<R>& sc, int32_t i) const { return sc.nodes[i]; }
+    int32_t get(int i) const { return i < 16 ? lds[i] : spill[i - 16]; }
+    bool room_for_three(int i) const { return i + 3 <= 16; } // both push forms of the node step get exercised
+    void set_fast(int i, int32_t v) { if (i == SPARE) lds[16] = v; else set(i, v); }
+    uint32_t plane_off(uint32_t q) const { return q; }
+    template <typename R> void fetch(const SceneView<R>& sc, int32_t i, const uint32_t* near_off, Planes4& out) const {
+        const Bvh4Node& nd = sc.nodes[i];
+        for (uint32_t a = 0; a < 3; ++a) {
+            const float* nr = near_off[a] == a ? nd.lo[a] : nd.hi[a];
+            const float* fr = near_off[a] == a ? nd.hi[a] : nd.lo[a];
+            for (int c = 0; c < 4; ++c) { out.nr[a][c] = nr[c]; out.fr[a][c] = fr[c]; }
+        }
+        for (int c = 0; c < 4; ++c) out.child[c] = nd.child[c];
+    }
 };
 
 template <typename R> struct HostScene {
@@ -218,7 +231,7 @@ static void walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const r
                 path_begin(ps, camr, rc, px, row, si);
                 for (;;) {
                     Trav<float> tr;
-                    trav_begin(tr, hs.view, ps.ray);
+                    trav_begin(tr, hs.view, ps.ray, stack);
                     uint32_t trips = 0;
                     while (tr.node != TRAV_DONE) {
                         ++trips;

@@ -199,6 +199,17 @@ int rttnw_tile_layout_get(uint32_t width, uint32_t height, uint32_t world, rttnw
 int rttnw_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p,
                  double* out_linear_rgb, uint8_t* out_rgba8, rttnw_stats* stats);
 
+/* `render()` on the GPUs of ONE NODE, in one call from one host thread ("library owns its HIP
+ * streams / RCCL comms"): the framebuffer's 8x8 tiles are interleaved over `ngpu` ranks, rank r traces its tiles on
+ * device `device_ids[r]` (the scene is replicated there on first use), the packed tiles are gathered on rank 0's device —
+ * grouped ncclSend/ncclRecv over xGMI between different devices (RCCL is loaded at the first call that needs it), a
+ * device-to-device copy for ranks that share rank 0's device — and un-tiled there.  A device may appear more than once
+ * (logical ranks; they run one after the other on it), so any partition can be exercised on a single GPU.  The image is
+ * bit-identical to rttnw_render's for every ngpu.  Outputs as rttnw_render; `p->tile_rank` / `p->tile_world` are ignored;
+ * `stats` (optional) points to ngpu records: samples and device time (trace + resolve) of each rank.  Blocking. */
+int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t ngpu,
+                       const int32_t* device_ids, double* out_linear_rgb, uint8_t* out_rgba8, rttnw_stats* stats);
+
 /* Device-resident form, asynchronous on `hip_stream` (a hipStream_t; NULL = default stream).
  * Traces the tiles owned by (tile_rank, tile_world) and writes them in packed order into
  * `d_packed`: pixels_per_rank pixel records of 4 reals (mean r, g, b, 1) of the kernel's

@@ -95,6 +95,8 @@ PRODUCT_FUNCS = [
     ("tile_layout_get", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(TileLayout)]),
     ("render", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_void_p, C.c_void_p,
                          C.POINTER(Stats)]),
+    ("render_multi", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.POINTER(C.c_int32), C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
     ("render_tiles_device", C.c_int, [scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_void_p,
                                       C.c_void_p, C.POINTER(Stats)]),
     ("untile_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,

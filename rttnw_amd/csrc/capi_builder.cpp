@@ -50,6 +50,7 @@ int rttnw_scene_create(uint64_t scene_seed, rttnw_scene** out) {
 void rttnw_scene_destroy(rttnw_scene* s) {
     if (!s) return;
     if (s->device) rt::device_release(s->device);
+    for (rt::DeviceState* d : s->more_devices) rt::device_release(d);
     delete s;
 }
 

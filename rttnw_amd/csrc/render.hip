@@ -20,6 +20,8 @@
 #include "scene_handle.hpp"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -795,6 +797,9 @@ struct DeviceState {
     void* spill = nullptr; size_t spill_bytes = 0;   // traversal-stack entries beyond LDS_STACK_ENTRIES, per thread of the launch
     unsigned long long* job_counter = nullptr; // [0] job counter, then DeviceCounters
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;              // rttnw_render_multi: this device's launch stream
+    void* multi_packed = nullptr; size_t multi_packed_bytes = 0; // packed tiles of the logical ranks living on this device
+    void* gathered = nullptr; size_t gathered_bytes = 0;         // root device: every rank's packed tiles
     // scratch for the blocking host-output render()
     void* packed = nullptr; size_t packed_bytes = 0;
     void* linear = nullptr; size_t linear_bytes = 0;
@@ -812,6 +817,10 @@ static int grow(void** p, size_t* have, size_t want) {
 
 void device_release(DeviceState* d) {
     if (!d) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (d->device >= 0) (void)hipSetDevice(d->device);
+    struct Restore { int dev; ~Restore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore{prev};
     d->s32.release(); d->s64.release();
     if (d->partial) (void)hipFree(d->partial);
     if (d->pool_r) (void)hipFree(d->pool_r);
@@ -821,6 +830,9 @@ void device_release(DeviceState* d) {
     if (d->packed) (void)hipFree(d->packed);
     if (d->linear) (void)hipFree(d->linear);
     if (d->rgba) (void)hipFree(d->rgba);
+    if (d->multi_packed) (void)hipFree(d->multi_packed);
+    if (d->gathered) (void)hipFree(d->gathered);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     delete d;
@@ -838,13 +850,8 @@ int device_bvh_builder(::rttnw_scene* s, BvhBuilder& out, std::string& err) {
     return 0;
 }
 
-int device_commit(::rttnw_scene* s, std::string& err) {
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-        err = "no HIP device available (this library has no CPU fallback)";
-        return RTTNW_ERR_HIP;
-    }
-    if (s->device) { device_release(s->device); s->device = nullptr; } // a commit that failed half-way and is retried
+// State on the CURRENT device (job counter, events; the scene arrays follow on first use).
+static int device_state_create(DeviceState*& out, std::string& err) {
     DeviceState* d = new DeviceState();
     hipError_t e = hipGetDevice(&d->device);
     hipDeviceProp_t prop;
@@ -854,11 +861,22 @@ int device_commit(::rttnw_scene* s, std::string& err) {
     e = hipMalloc((void**)&d->job_counter, sizeof(unsigned long long) + sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipEventCreate(&d->ev0);
     if (e == hipSuccess) e = hipEventCreate(&d->ev1);
-    if (e != hipSuccess) { err = std::string("device_commit: ") + hipGetErrorString(e); device_release(d); return RTTNW_ERR_HIP; }
-    s->device = d;
-    // The scene arrays are uploaded per precision on first use (render), see ensure_scene().
+    if (e != hipSuccess) { err = std::string("device state: ") + hipGetErrorString(e); device_release(d); return RTTNW_ERR_HIP; }
+    out = d;
     return 0;
 }
+
+int device_commit(::rttnw_scene* s, std::string& err) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        err = "no HIP device available (this library has no CPU fallback)";
+        return RTTNW_ERR_HIP;
+    }
+    if (s->device) { device_release(s->device); s->device = nullptr; } // a commit that failed half-way and is retried
+    // The scene arrays are uploaded per precision on first use (render), see render_tiles_t.
+    return device_state_create(s->device, err);
+}
+
 
 template <typename R> DeviceScene<R>& scene_of(DeviceState* d);
 template <> DeviceScene<float>& scene_of<float>(DeviceState* d) { return d->s32; }
@@ -899,9 +917,8 @@ static int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_
 }
 
 template <typename R>
-int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
-                   rttnw_stats* stats) {
-    DeviceState* d = s->device;
+int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
+                   rttnw_stats* stats, bool sync_for_stats = true) {
     HIP_TRY(hipSetDevice(d->device));
     DeviceScene<R>& ds = scene_of<R>(d);
     if (!ds.ready)
@@ -1021,11 +1038,13 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
     rc.spp = p->spp;
 
     if (stats) {
-        HIP_TRY(hipStreamSynchronize(stream));
         std::memset(stats, 0, sizeof(*stats));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, d->ev0, d->ev1));
-        stats->kernel_ms = ms;
+        if (sync_for_stats) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+            stats->kernel_ms = ms;
+        }
         // samples traced by this rank: pixels of its tiles that lie inside the image
         uint64_t px_count = 0;
         for (uint32_t t = 0; t < rc.my_tiles; ++t) {
@@ -1035,7 +1054,7 @@ int render_tiles_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_p
             px_count += uint64_t(w) * h;
         }
         stats->samples = px_count * rc.spp;
-        if (count) {
+        if (count && sync_for_stats) {
             DeviceCounters hc;
             HIP_TRY(hipMemcpy(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
             stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
@@ -1158,8 +1177,8 @@ int rttnw_render_tiles_device(rttnw_scene* s, const rttnw_camera_desc* cam, cons
     if (int rc = rt::validate(s, cam, p)) return rc;
     if (!d_packed) { rt::set_last_error("render_tiles_device: d_packed is NULL"); return RTTNW_ERR_INVALID; }
     hipStream_t stream = (hipStream_t)hip_stream;
-    return p->precision == RTTNW_F32 ? rt::render_tiles_t<float>(s, cam, p, d_packed, stream, stats)
-                                     : rt::render_tiles_t<double>(s, cam, p, d_packed, stream, stats);
+    return p->precision == RTTNW_F32 ? rt::render_tiles_t<float>(s, s->device, cam, p, d_packed, stream, stats)
+                                     : rt::render_tiles_t<double>(s, s->device, cam, p, d_packed, stream, stats);
 }
 
 int rttnw_untile_device(uint32_t width, uint32_t height, uint32_t world, uint32_t precision, const void* d_gathered,
@@ -1219,3 +1238,172 @@ int rttnw_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_param
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// rttnw_render_multi: the whole of main.rs:202-229 on the GPUs of one node, in one call.
+// ---------------------------------------------------------------------------------------------
+namespace rt {
+// RCCL, bound at first use (a single device, or logical ranks that share one device, never touch it).
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Send = (decltype(Send))dlsym(lib, "ncclSend");
+        Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !GetErrorString) { err = "RCCL lacks an expected entry point"; return false; }
+        return true;
+    }
+};
+static Rccl g_rccl;
+struct MultiComms { // one communicator set per distinct list of devices, kept for the life of the process
+    std::vector<int> devices;
+    std::vector<ncclComm_t> comms;
+};
+static std::vector<MultiComms*> g_comms;
+
+static DeviceState* state_on(::rttnw_scene* s, int device, std::string& err) {
+    if (s->device && s->device->device == device) return s->device;
+    for (DeviceState* d : s->more_devices)
+        if (d->device == device) return d;
+    if (hipSetDevice(device) != hipSuccess) { err = "hipSetDevice failed"; return nullptr; }
+    DeviceState* d = nullptr;
+    if (device_state_create(d, err)) return nullptr;
+    s->more_devices.push_back(d);
+    return d;
+}
+} // namespace rt
+
+extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p_in, uint32_t ngpu, const int32_t* device_ids,
+                                  double* out_linear_rgb, uint8_t* out_rgba8, rttnw_stats* stats) {
+    using namespace rt;
+    if (!p_in || !ngpu || ngpu > 64 || !device_ids) { set_last_error("render_multi: bad arguments"); return RTTNW_ERR_INVALID; }
+    rttnw_params p = *p_in;
+    p.tile_rank = 0; p.tile_world = ngpu;
+    if (int rc = validate(s, cam, &p)) return rc;
+    const int n_dev = rttnw_device_count();
+    for (uint32_t r = 0; r < ngpu; ++r)
+        if (device_ids[r] < 0 || device_ids[r] >= n_dev) { set_last_error("render_multi: no such device"); return RTTNW_ERR_INVALID; }
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
+    struct Restore { int dev; ~Restore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore{prev_dev};
+
+    std::string err;
+    std::vector<DeviceState*> st(ngpu);
+    std::vector<int> distinct; // devices in order of first appearance; distinct[0] = the root's (rank 0's) device
+    std::vector<uint32_t> slot(ngpu), per_dev;
+    for (uint32_t r = 0; r < ngpu; ++r) {
+        st[r] = state_on(s, device_ids[r], err);
+        if (!st[r]) { set_last_error("render_multi: " + err); return RTTNW_ERR_HIP; }
+        size_t k = 0;
+        while (k < distinct.size() && distinct[k] != device_ids[r]) ++k;
+        if (k == distinct.size()) { distinct.push_back(device_ids[r]); per_dev.push_back(0); }
+        slot[r] = per_dev[k]++; // this rank's place among the ranks of its device
+    }
+    rttnw_tile_layout L;
+    fill_layout(p.width, p.height, ngpu, L);
+    const size_t rsz = p.precision == RTTNW_F32 ? sizeof(float) : sizeof(double);
+    const size_t chunk = size_t(L.pixels_per_rank) * 4 * rsz, npx = size_t(p.width) * p.height;
+    for (size_t k = 0; k < distinct.size(); ++k) {
+        DeviceState* d = state_on(s, distinct[k], err);
+        HIP_TRY(hipSetDevice(d->device));
+        if (!d->stream) HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        if (int g = grow(&d->multi_packed, &d->multi_packed_bytes, chunk * per_dev[k])) return g;
+    }
+    DeviceState* root = st[0];
+    HIP_TRY(hipSetDevice(root->device));
+    if (int g = grow(&root->gathered, &root->gathered_bytes, chunk * ngpu)) return g;
+    if (int g = grow(&root->linear, &root->linear_bytes, npx * 3 * rsz)) return g;
+    if (int g = grow((void**)&root->rgba, &root->rgba_bytes, npx * 4)) return g;
+
+    // ---- every rank traces its tiles, on its device's stream; ranks that share a device run one after the other
+    std::vector<hipEvent_t> ev(size_t(ngpu) * 2, nullptr);
+    struct EvFree { std::vector<hipEvent_t>& v; ~EvFree() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } ev_free{ev};
+    for (uint32_t r = 0; r < ngpu; ++r) {
+        DeviceState* d = st[r];
+        HIP_TRY(hipSetDevice(d->device));
+        rttnw_params pr = p;
+        pr.tile_rank = r;
+        void* dst = (char*)d->multi_packed + chunk * slot[r];
+        HIP_TRY(hipEventCreate(&ev[2 * r]));
+        HIP_TRY(hipEventCreate(&ev[2 * r + 1]));
+        HIP_TRY(hipEventRecord(ev[2 * r], d->stream));
+        int rc = p.precision == RTTNW_F32 ? render_tiles_t<float>(s, d, cam, &pr, dst, d->stream, stats ? &stats[r] : nullptr, false)
+                                          : render_tiles_t<double>(s, d, cam, &pr, dst, d->stream, stats ? &stats[r] : nullptr, false);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev[2 * r + 1], d->stream));
+    }
+
+    // ---- gather to the root: a device-to-device copy for ranks on the root's device, RCCL send/recv over xGMI for the others
+    if (distinct.size() > 1) {
+        if (!g_rccl.load(err)) { set_last_error("render_multi: " + err); return RTTNW_ERR_HIP; }
+        MultiComms* mc = nullptr;
+        for (MultiComms* c : g_comms)
+            if (c->devices == distinct) mc = c;
+        if (!mc) {
+            mc = new MultiComms();
+            mc->devices = distinct;
+            mc->comms.resize(distinct.size());
+            ncclResult_t nr = g_rccl.CommInitAll(mc->comms.data(), int(distinct.size()), distinct.data());
+            if (nr != ncclSuccess) { set_last_error(std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr)); delete mc; return RTTNW_ERR_HIP; }
+            g_comms.push_back(mc);
+        }
+        ncclResult_t nr = g_rccl.GroupStart();
+        for (uint32_t r = 0; r < ngpu && nr == ncclSuccess; ++r) {
+            size_t k = 0;
+            while (distinct[k] != device_ids[r]) ++k;
+            if (k == 0) continue; // on the root's device: copied below
+            const void* src = (const char*)st[r]->multi_packed + chunk * slot[r];
+            nr = g_rccl.Send(src, chunk, ncclChar, 0, mc->comms[k], st[r]->stream);
+            if (nr == ncclSuccess) nr = g_rccl.Recv((char*)root->gathered + chunk * r, chunk, ncclChar, int(k), mc->comms[0], root->stream);
+        }
+        ncclResult_t ne = g_rccl.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) { set_last_error(std::string("RCCL gather: ") + g_rccl.GetErrorString(nr)); return RTTNW_ERR_HIP; }
+    }
+    HIP_TRY(hipSetDevice(root->device));
+    for (uint32_t r = 0; r < ngpu; ++r)
+        if (device_ids[r] == root->device)
+            HIP_TRY(hipMemcpyAsync((char*)root->gathered + chunk * r, (const char*)root->multi_packed + chunk * slot[r], chunk, hipMemcpyDeviceToDevice, root->stream));
+    int rc = rttnw_untile_device(p.width, p.height, ngpu, p.precision, root->gathered, root->linear, root->rgba, root->stream);
+    if (rc) return rc;
+    for (size_t k = 0; k < distinct.size(); ++k) {
+        DeviceState* d = state_on(s, distinct[k], err);
+        HIP_TRY(hipSetDevice(d->device));
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
+    HIP_TRY(hipSetDevice(root->device));
+    if (stats)
+        for (uint32_t r = 0; r < ngpu; ++r) {
+            float ms = 0;
+            HIP_TRY(hipSetDevice(st[r]->device));
+            HIP_TRY(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
+            stats[r].kernel_ms = ms; // trace + resolve of this rank
+        }
+    HIP_TRY(hipSetDevice(root->device));
+    if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, root->rgba, npx * 4, hipMemcpyDeviceToHost));
+    if (out_linear_rgb) {
+        if (p.precision == RTTNW_F64) {
+            HIP_TRY(hipMemcpy(out_linear_rgb, root->linear, npx * 3 * sizeof(double), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<float> tmp(npx * 3);
+            HIP_TRY(hipMemcpy(tmp.data(), root->linear, npx * 3 * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < npx * 3; ++i) out_linear_rgb[i] = double(tmp[i]);
+        }
+    }
+    return RTTNW_OK;
+}

@@ -4,6 +4,7 @@
 #include "scene_lower.hpp"
 
 #include <string>
+#include <vector>
 
 namespace rt {
 struct DeviceState; // defined in render.hip
@@ -24,5 +25,6 @@ struct rttnw_scene {
     uint32_t bvh_builder = 0;      // RTTNW_BVH_*
     double lower_ms = 0;           // host wall time of rttnw_scene_commit's lowering (BVH builds included)
     double build_kernel_ms = 0;    // device time of the BVH build kernels (device builder only)
-    rt::DeviceState* device = nullptr;
+    rt::DeviceState* device = nullptr;              // state on the device that was current at commit
+    std::vector<rt::DeviceState*> more_devices;     // states on further devices (rttnw_render_multi), created on first use
 };

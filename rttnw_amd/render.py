@@ -24,6 +24,21 @@ def render_host(scene, cam, params, want_stats=True):
     return lin, rgba, st
 
 
+def render_multi(scene, cam, params, device_ids, want_stats=True):
+    """`rttnw_render_multi`: one call, the GPUs (or logical ranks) of `device_ids`; (linear, rgba8, [Stats per rank])."""
+    b = library.product()
+    h, w = params.height, params.width
+    lin = np.zeros((h, w, 3), dtype=np.float64)
+    rgba = np.zeros((h, w, 4), dtype=np.uint8)
+    n = len(device_ids)
+    ids = (C.c_int32 * n)(*device_ids)
+    st = (Stats * n)()
+    rc = b.render_multi(scene.handle, C.byref(cam), C.byref(params), n, ids, lin.ctypes.data, rgba.ctypes.data,
+                        C.cast(st, C.c_void_p) if want_stats else None)
+    check(rc, b, "rttnw_render_multi")
+    return lin, rgba, list(st)
+
+
 def render_host_passes(scene, cam, params, passes, on_pass=None):
     """The same image as `render_host`, in `passes` passes over disjoint sample ranges (`rttnw_params.sample_begin`):
     after every pass the running mean is a complete, displayable estimate — progressive display and a natural

@@ -711,6 +711,7 @@ template <typename R> struct DeviceScene {
     DevBuf<BoxRec<R>> boxes;
     DevBuf<InstanceRec<R>> insts;
     DevBuf<MediumRec<R>> media;
+    DevBuf<int32_t> medium_refs;
     DevBuf<MaterialRec<R>> mats;
     DevBuf<TextureRec<R>> texs;
     DevBuf<ImageRec> images;
@@ -750,7 +751,7 @@ template <typename R> struct DeviceScene {
             in.push_back(o);
         }
         std::vector<MediumRec<R>> md;
-        for (auto& m : f.media) md.push_back({m.boundary, m.inst, m.mat, 0, R(m.neg_inv_density)});
+        for (auto& m : f.media) md.push_back({m.b_first, m.b_count, m.inst, m.n_outer, m.mat, 0, R(m.neg_inv_density)});
         std::vector<MaterialRec<R>> mt;
         for (auto& m : f.mats) mt.push_back({m.type, m.tex, {R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2])}, R(m.param)});
         std::vector<TextureRec<R>> tx;
@@ -761,12 +762,12 @@ template <typename R> struct DeviceScene {
         int rc;
         if ((rc = nodes.upload(f.nodes4)) || (rc = spheres.upload(sp)) || (rc = sphere_mat.upload(f.sphere_mat)) ||
             (rc = sphere_seq.upload(f.sphere_seq)) || (rc = moving.upload(mv)) || (rc = rects.upload(rc_)) ||
-            (rc = boxes.upload(bx)) || (rc = insts.upload(in)) || (rc = media.upload(md)) || (rc = mats.upload(mt)) ||
+            (rc = boxes.upload(bx)) || (rc = insts.upload(in)) || (rc = media.upload(md)) || (rc = medium_refs.upload(f.medium_refs)) || (rc = mats.upload(mt)) ||
             (rc = texs.upload(tx)) || (rc = images.upload(f.images)) || (rc = texels.upload(f.texels)) ||
             (rc = perlin_vec.upload(pv)) || (rc = perlin_perm.upload(f.perlin_perm)))
             return rc;
         view.nodes = nodes.p; view.spheres = spheres.p; view.sphere_mat = sphere_mat.p; view.sphere_seq = sphere_seq.p;
-        view.moving = moving.p; view.rects = rects.p; view.boxes = boxes.p; view.insts = insts.p; view.media = media.p;
+        view.moving = moving.p; view.rects = rects.p; view.boxes = boxes.p; view.insts = insts.p; view.media = media.p; view.medium_refs = medium_refs.p;
         view.mats = mats.p; view.texs = texs.p; view.images = images.p; view.texels = texels.p;
         view.perlin_vec = perlin_vec.p; view.perlin_perm = perlin_perm.p;
         view.top_root = f.top_root;
@@ -778,7 +779,7 @@ template <typename R> struct DeviceScene {
     }
     void release() {
         nodes.release(); spheres.release(); sphere_mat.release(); sphere_seq.release(); moving.release(); rects.release();
-        boxes.release(); insts.release(); media.release(); mats.release(); texs.release(); images.release();
+        boxes.release(); insts.release(); media.release(); medium_refs.release(); mats.release(); texs.release(); images.release();
         texels.release(); perlin_vec.release(); perlin_perm.release();
         ready = false;
     }
@@ -908,10 +909,29 @@ static int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_
     // the decoupled kernel packs a pixel as px | row << 16, and the free-flight draw of medium m uses RNG slot m < 16
     if (p->width > 65535u || p->height > 65535u) { set_last_error("render: width and height are limited to 65535"); return RTTNW_ERR_UNSUPPORTED; }
     if (s->flat.media.size() > SLOT_DIELECTRIC) { set_last_error("render: more than 16 constant media"); return RTTNW_ERR_UNSUPPORTED; }
-    // moving-sphere bounds are built for the shutter interval [0,1] (BvhTree::from, hittable.rs:256)
-    if (cam->open_time < 0.0 || cam->close_time > 1.0 || cam->open_time > cam->close_time) {
-        set_last_error("render: shutter interval must lie inside [0,1]");
-        return RTTNW_ERR_UNSUPPORTED;
+    if (!(cam->open_time <= cam->close_time)) { set_last_error("render: open_time > close_time"); return RTTNW_ERR_INVALID; }
+    // The boxes of moving spheres are built for the shutter interval [0, 1] (what BvhTree::from uses, hittable.rs:256).  A
+    // camera whose shutter reaches outside it (BvhTree::from_time, hittable.rs:261) makes the library rebuild the trees
+    // for the wider interval, once, and drop the device copies (they are uploaded again on use).
+    if (!s->flat.moving.empty() && (cam->open_time < s->flat.time0 || cam->close_time > s->flat.time1)) {
+        const double t0 = std::min(s->flat.time0, cam->open_time), t1 = std::max(s->flat.time1, cam->close_time);
+        std::string err;
+        BvhBuilder device_builder;
+        const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
+        if (on_device)
+            if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
+        FlatScene wider;
+        if (int rc = lower_scene(s->graph, wider, err, on_device ? &device_builder : nullptr, t0, t1)) { set_last_error(err); return rc; }
+        s->flat = std::move(wider);
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        std::vector<DeviceState*> all = s->more_devices;
+        all.push_back(s->device);
+        for (DeviceState* d : all) {
+            (void)hipSetDevice(d->device);
+            d->s32.release(); d->s64.release();
+        }
+        if (prev >= 0) (void)hipSetDevice(prev);
     }
     return 0;
 }

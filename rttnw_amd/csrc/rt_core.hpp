@@ -367,22 +367,58 @@ RT_HD bool box_t(const BoxRec<R>& bx, const Ray<R>& ray, R t_min, R t_max, R& t_
     return any;
 }
 
-// Ray -> object space through an instance's ops (Translate::hit :600-604, YRotate::hit :687-697)
-template <typename R> RT_HD Ray<R> to_object(const InstanceRec<R>& in, Ray<R> ray) {
-#pragma unroll
-    for (int i = 0; i < MAX_INSTANCE_OPS; ++i) {
-        if (i < in.n_ops) {
-            if (in.ops[i].type == OP_TRANSLATE) {
-                ray.o = ray.o - V3<R>(in.ops[i].v);
-            } else {
-                R s = in.ops[i].v[0], c = in.ops[i].v[1];
-                R ox = c * ray.o.x - s * ray.o.z, oz = s * ray.o.x + c * ray.o.z;
-                R dx = c * ray.d.x - s * ray.d.z, dz = s * ray.d.x + c * ray.d.z;
-                ray.o.x = ox; ray.o.z = oz; ray.d.x = dx; ray.d.z = dz;
-            }
+template <typename R> RT_HD void face_normal(V3<R> dir, V3<R> outward, V3<R>& normal, bool& front);
+// Ray -> object space through the first `n` ops of an instance (Translate::hit :600-604, YRotate::hit :687-697).  The record
+// is read through a reference, op by op: chains are short (two ops in the reference's scenes) and entered rarely.
+template <typename R> RT_HD Ray<R> to_object_n(const InstanceRec<R>& in, Ray<R> ray, int n) {
+    for (int i = 0; i < n; ++i) {
+        const int32_t type = in.ops[i].type;
+        const R v0 = in.ops[i].v[0], v1 = in.ops[i].v[1], v2 = in.ops[i].v[2];
+        if (type == OP_TRANSLATE) {
+            ray.o = ray.o - V3<R>(v0, v1, v2);
+        } else {
+            const R s = v0, c = v1;
+            const R ox = c * ray.o.x - s * ray.o.z, oz = s * ray.o.x + c * ray.o.z;
+            const R dx = c * ray.d.x - s * ray.d.z, dz = s * ray.d.x + c * ray.d.z;
+            ray.o.x = ox; ray.o.z = oz; ray.d.x = dx; ray.d.z = dz;
         }
     }
     return ray;
+}
+template <typename R> RT_HD Ray<R> to_object(const InstanceRec<R>& in, Ray<R> ray) { return to_object_n(in, ray, in.n_ops); }
+// The ray DIRECTION after ops[0..upto] (what level `upto`'s face_normal sees: Translate's `moved_ray` :607, YRotate's rotated ray :706).
+template <typename R> RT_HD V3<R> dir_after(const InstanceRec<R>& in, V3<R> d, int upto) {
+    for (int i = 0; i <= upto; ++i)
+        if (in.ops[i].type == OP_ROTATE_Y) {
+            const R s = in.ops[i].v[0], c = in.ops[i].v[1];
+            const R dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
+            d.x = dx; d.z = dz;
+        }
+    return d;
+}
+// Unwind a hit record (p, normal, front_face) through ops[n-1] .. ops[0], innermost first, with the reference's
+// face_normal call at every level and — under quirk Q1 — its overwritten-x back-rotation (hittable.rs:700-706, :607-611).
+template <typename R>
+RT_HD void unwind_record(const InstanceRec<R>& in, int n, V3<R> world_dir, uint32_t quirks, V3<R>& p, V3<R>& normal, bool& front_face) {
+    for (int i = n - 1; i >= 0; --i) {
+        if (in.ops[i].type == OP_ROTATE_Y) { // hittable.rs:700-706
+            const R s = in.ops[i].v[0], c = in.ops[i].v[1];
+            const R px = c * p.x + s * p.z;
+            const R nx = c * normal.x + s * normal.z;
+            // Q1: the reference's z line reads the x it has just overwritten
+            const R pxz = (quirks & 1u) ? px : p.x;
+            const R nxz = (quirks & 1u) ? nx : normal.x;
+            const R pz = -s * pxz + c * p.z;
+            const R nz = -s * nxz + c * normal.z;
+            p.x = px; p.z = pz;
+            normal.x = nx; normal.z = nz;
+        } else { // hittable.rs:607-611
+            p = p + V3<R>(in.ops[i].v[0], in.ops[i].v[1], in.ops[i].v[2]);
+        }
+        V3<R> nn; bool ff;
+        face_normal(dir_after(in, world_dir, i), normal, nn, ff);
+        normal = nn; front_face = ff;
+    }
 }
 
 // Rectangle hit coordinates at parameter t, no range checks (used to rebuild the winner's record).
@@ -561,7 +597,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     const uint32_t kind = leaf_kind(tr.node), count = leaf_count(tr.node), first = leaf_first(tr.node);
     if (kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
         cnt.prim();
-        const InstanceRec<R> in = sc.insts[first];
+        const InstanceRec<R>& in = sc.insts[first];
         if (in.single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk
             const Ray<R> outer = tr.ray;
             const int32_t outer_inst = tr.cur_inst;
@@ -644,8 +680,7 @@ template <typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim), idx = ref_index(ref.prim);
     Ray<R> ray = wray;
-    InstanceRec<R> in{};
-    if (ref.inst >= 0) { in = sc.insts[ref.inst]; ray = to_object(in, wray); }
+    if (ref.inst >= 0) ray = to_object(sc.insts[ref.inst], wray);
     rec.t = t;
     V3<R> outward;
     if (kind == PRIM_SPHERE) { // hittable.rs:109-113
@@ -693,45 +728,8 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
     face_normal(ray.d, outward, rec.normal, rec.front_face);
 
     if (ref.inst >= 0) {
-        // Unwind the wrappers innermost-first.  Level i's face_normal uses the ray as it was AFTER
-        // ops[0..i] were applied (Translate: `moved_ray` :607; YRotate: the rotated `ray` :706).
-        V3<R> dirs[MAX_INSTANCE_OPS];
-        {
-            Ray<R> r = wray;
-#pragma unroll
-            for (int i = 0; i < MAX_INSTANCE_OPS; ++i) {
-                if (i < in.n_ops) {
-                    if (in.ops[i].type == OP_ROTATE_Y) {
-                        R s = in.ops[i].v[0], c = in.ops[i].v[1];
-                        R dx = c * r.d.x - s * r.d.z, dz = s * r.d.x + c * r.d.z;
-                        r.d.x = dx; r.d.z = dz;
-                    }
-                }
-                dirs[i] = r.d;
-            }
-        }
-#pragma unroll
-        for (int i = MAX_INSTANCE_OPS - 1; i >= 0; --i) {
-            if (i < in.n_ops) {
-                if (in.ops[i].type == OP_ROTATE_Y) { // hittable.rs:700-706
-                    R s = in.ops[i].v[0], c = in.ops[i].v[1];
-                    R px = c * rec.p.x + s * rec.p.z;
-                    R nx = c * rec.normal.x + s * rec.normal.z;
-                    // Q1: the reference's z line reads the x it has just overwritten
-                    R pxz = (quirks & 1u) ? px : rec.p.x;
-                    R nxz = (quirks & 1u) ? nx : rec.normal.x;
-                    R pz = -s * pxz + c * rec.p.z;
-                    R nz = -s * nxz + c * rec.normal.z;
-                    rec.p.x = px; rec.p.z = pz;
-                    rec.normal.x = nx; rec.normal.z = nz;
-                } else { // hittable.rs:607-611
-                    rec.p = rec.p + V3<R>(in.ops[i].v);
-                }
-                V3<R> n; bool ff;
-                face_normal(dirs[i], rec.normal, n, ff);
-                rec.normal = n; rec.front_face = ff;
-            }
-        }
+        const InstanceRec<R>& in = sc.insts[ref.inst];
+        unwind_record(in, in.n_ops, wray.d, quirks, rec.p, rec.normal, rec.front_face);
     }
 }
 
@@ -753,15 +751,15 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
     for (int32_t m = 0; m < sc.n_media; ++m) {
         const MediumRec<R> md = sc.media[m];
         Ray<R> bray = ray;
-        if (md.inst >= 0) { const InstanceRec<R> in = sc.insts[md.inst]; bray = to_object(in, ray); }
-        const uint32_t bk = ref_kind(md.boundary), bi = ref_index(md.boundary);
+        if (md.inst >= 0) bray = to_object(sc.insts[md.inst], ray);
+        const int32_t ref0 = sc.medium_refs[md.b_first];
         R t1, t2;
         cnt.prim(); // first boundary query; the second is counted once the first has hit, as the reference would call it
-        if (bk == PRIM_SPHERE) {
+        if (md.b_count == 1 && ref_kind(ref0) == PRIM_SPHERE) {
             // boundary.hit(ray, -inf, +inf) then boundary.hit(ray, t1 + 0.0001, +inf) (hittable.rs:745-751) are two
             // evaluations of ONE quadratic: same discriminant, near root first, far root if the near one is out of
             // range.  Evaluated once here, with Sphere::hit's range tests kept literally (NaN behaviour included).
-            const SphereRec<R> sp = sc.spheres[bi];
+            const SphereRec<R> sp = sc.spheres[ref_index(ref0)];
             const V3<R> oc = bray.o - V3<R>(sp.cx, sp.cy, sp.cz);
             const R a = dot(bray.d, bray.d), half_b = dot(oc, bray.d);
             const R disc = sphere_discriminant(oc, bray.d, a, half_b, sp.r);
@@ -781,16 +779,37 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
                 if (t2 < lo2 || Lim<R>::inf() < t2) continue;
             }
         } else {
-            int aux;
-            if (!prim_t(sc, bk, bi, bray, -Lim<R>::inf(), Lim<R>::inf(), t1, aux)) continue;
-            cnt.prim();
-            if (!prim_t(sc, bk, bi, bray, t1 + medium_sep(t1), Lim<R>::inf(), t2, aux)) continue;
+            // any boundary: a cube, or a List / BvhTree of spheres and cubes (ConstantMedium takes any Hittable and treats it
+            // as convex, hittable.rs:731,739): List::hit over the members with a shrinking t_max (hittable.rs:153-163), twice
+            bool any = false;
+            R cur = Lim<R>::inf();
+            for (int32_t k = 0; k < md.b_count; ++k) {
+                const int32_t ref = sc.medium_refs[md.b_first + k];
+                R t; int aux;
+                if (k) cnt.prim();
+                if (prim_t(sc, ref_kind(ref), ref_index(ref), bray, -Lim<R>::inf(), cur, t, aux)) { cur = t; any = true; }
+            }
+            if (!any) continue;
+            t1 = cur;
+            any = false;
+            cur = Lim<R>::inf();
+            const R lo2 = t1 + medium_sep(t1);
+            for (int32_t k = 0; k < md.b_count; ++k) {
+                const int32_t ref = sc.medium_refs[md.b_first + k];
+                R t; int aux;
+                cnt.prim();
+                if (prim_t(sc, ref_kind(ref), ref_index(ref), bray, lo2, cur, t, aux)) { cur = t; any = true; }
+            }
+            if (!any) continue;
+            t2 = cur;
         }
         t1 = rt_max(t1, t_min);
         t2 = rt_min(t2, closest);
         if (t1 >= t2) continue; // before any draw
         t1 = rt_max(t1, R(0));
-        R ray_length = magnitude(ray.d);
+        // the ray as the medium itself sees it: inside a transformed group, the group's object-space ray
+        const V3<R> mdir = md.n_outer > 0 ? dir_after(sc.insts[md.inst], ray.d, md.n_outer - 1) : ray.d;
+        R ray_length = magnitude(mdir);
         R distance_inside = (t2 - t1) * ray_length;
         R hit_distance = md.neg_inv_density * rt_log(uniform01_log<R>(key, rng_ctr(bounce + 1, SLOT_MEDIUM + uint32_t(m))));
         if (hit_distance > distance_inside) continue;
@@ -800,12 +819,19 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
     }
     if (!found) return false;
     if (medium >= 0) { // hittable.rs:770-789
+        const MediumRec<R> md = sc.media[medium];
         rec.t = closest;
-        rec.p = ray.at(closest);
         rec.normal = V3<R>(R(1), R(0), R(0));
         rec.front_face = true;
         rec.u = R(0); rec.v = R(0);
-        rec.mat = sc.media[medium].mat;
+        rec.mat = md.mat;
+        if (md.n_outer > 0) { // a medium inside a transformed group: its record goes through the group's wrappers like any other
+            const InstanceRec<R>& in = sc.insts[md.inst];
+            rec.p = to_object_n(in, ray, md.n_outer).at(closest);
+            unwind_record(in, md.n_outer, ray.d, quirks, rec.p, rec.normal, rec.front_face);
+        } else {
+            rec.p = ray.at(closest);
+        }
     } else {
         make_record(sc, ray, best, closest, quirks, rec);
     }

@@ -88,9 +88,11 @@ template <typename R> struct alignas(sizeof(R) * 4) RectRec { R a0, a1, b0, b1, 
 template <typename R> struct alignas(sizeof(R) * 4) BoxRec { R mn[3], mx[3]; int32_t mat; int32_t seq; };
 
 enum : int32_t { OP_TRANSLATE = 0, OP_ROTATE_Y = 1 };
-constexpr int MAX_INSTANCE_OPS = 3;
+constexpr int MAX_INSTANCE_OPS = 8;
 // ops[0] is the OUTERMOST wrapper (applied to the ray first): `x.rotate_y(a).translate(v)`
-// = Translate(YRotate(x)) lowers to ops = { translate v, rotate a }.
+// = Translate(YRotate(x)) lowers to ops = { translate v, rotate a }.  A transformed object inside a transformed group is
+// lowered as an instance of its own whose chain is the group's wrappers followed by its own (scene_lower.cpp), so
+// instances never nest; only the first n_ops entries of a record are ever read.
 template <typename R> struct alignas(16) InstanceRec {
     int32_t n_ops;
     int32_t root;        // sub-BVH root node
@@ -100,8 +102,11 @@ template <typename R> struct alignas(16) InstanceRec {
 };
 
 template <typename R> struct MediumRec {
-    int32_t boundary; // make_ref(kind, index) of the boundary primitive (sphere / box)
-    int32_t inst;     // instance whose ops wrap the boundary, or -1
+    int32_t b_first;  // boundary = medium_refs[b_first .. b_first + b_count): make_ref(kind, index) of spheres / boxes; more than
+    int32_t b_count;  //   one = a List / BvhTree boundary (ConstantMedium takes any Hittable, hittable.rs:731)
+    int32_t inst;     // instance record whose ops take the world ray to the boundary's space, or -1
+    int32_t n_outer;  // how many of those ops (the leading ones) wrap the MEDIUM itself (a medium inside a transformed
+                      //   group): its hit record is unwound through them like any other record of the group
     int32_t mat;      // Isotropic material
     int32_t pad;
     R neg_inv_density;
@@ -141,6 +146,7 @@ template <typename R> struct SceneView {
     const BoxRec<R>* boxes;
     const InstanceRec<R>* insts;
     const MediumRec<R>* media;
+    const int32_t* medium_refs; // boundary primitives of the media
     const MaterialRec<R>* mats;
     const TextureRec<R>* texs;
     const ImageRec* images;

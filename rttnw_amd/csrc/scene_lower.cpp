@@ -114,6 +114,7 @@ struct Lowering {
     int rc = 0;
     const BvhBuilder* builder = nullptr;
     size_t max_leaf = 4; // records per leaf of the host SAH build (lower_scene picks it)
+    double time0 = 0.0, time1 = 1.0; // shutter interval the moving spheres' boxes must cover
 
     int fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return code; }
 
@@ -127,7 +128,7 @@ struct Lowering {
             break;
         case GraphObj::MOVING_K: {
             double r = std::fabs(o.v[8]);
-            for (double time : {0.0, 1.0}) {
+            for (double time : {time0, time1}) { // the centre moves linearly: the box over an interval is the hull of its ends
                 double f = (time - o.v[6]) / (o.v[7] - o.v[6]);
                 double c[3];
                 for (int k = 0; k < 3; ++k) c[k] = o.v[k] + f * (o.v[3 + k] - o.v[k]);
@@ -354,7 +355,7 @@ struct Lowering {
         int32_t cur = id;
         while (g.objs[cur].kind == GraphObj::TRANSLATE_K || g.objs[cur].kind == GraphObj::ROTATE_K) {
             const GraphObj& o = g.objs[cur];
-            if (in.n_ops >= MAX_INSTANCE_OPS) { fail(ERR_UNSUPPORTED, "more than 3 nested translate/rotate_y wrappers"); return -1; }
+            if (in.n_ops >= MAX_INSTANCE_OPS) { fail(ERR_UNSUPPORTED, "more than 8 nested translate/rotate_y wrappers around one object"); return -1; }
             auto& op = in.ops[in.n_ops++];
             if (o.kind == GraphObj::TRANSLATE_K) {
                 op.type = OP_TRANSLATE;
@@ -382,9 +383,44 @@ struct Lowering {
     }
 
     // ---- collection of solids
+    // `outer`: the Translate / YRotate wrappers around the list being collected, outermost first (empty at world level).
+    // A transformed object inside a transformed group becomes an instance of its own at the TOP level whose chain is
+    // outer + its own wrappers — the closest hit does not care how the reference nests its lists — so instances never nest.
+    struct Chain { int32_t n = 0; InstanceRec<double>::Op ops[MAX_INSTANCE_OPS]; };
     int32_t next_seq = 0;
     int nesting = 0; // recursion guard: a list that (transitively) contains itself
-    void collect(int32_t id, std::vector<Item>& out, bool inside_instance, uint32_t& inst_depth) {
+    std::vector<Item>* top_items = nullptr;
+    uint32_t inst_need_dummy = 0;
+
+    bool append_ops(Chain& c, const InstanceRec<double>& in) {
+        for (int i = 0; i < in.n_ops; ++i) {
+            if (c.n >= MAX_INSTANCE_OPS) { fail(ERR_UNSUPPORTED, "more than 8 nested translate/rotate_y wrappers around one object"); return false; }
+            c.ops[c.n++] = in.ops[i];
+        }
+        return true;
+    }
+    static void chain_to_inst(const Chain& c, InstanceRec<double>& in) {
+        in = InstanceRec<double>{};
+        in.n_ops = c.n;
+        for (int i = 0; i < c.n; ++i) in.ops[i] = c.ops[i];
+    }
+    // boundary of a medium: spheres and cubes, directly or in (nested) lists / BvhTrees, all in one space
+    bool boundary_members(int32_t id, std::vector<int32_t>& refs) {
+        const GraphObj& o = g.objs[id];
+        if (o.kind == GraphObj::SPHERE_K) { refs.push_back(make_ref(PRIM_SPHERE, emit({PRIM_SPHERE, id, Box3(), 0}))); return true; }
+        if (o.kind == GraphObj::CUBE_K) { refs.push_back(make_ref(PRIM_BOX, emit({PRIM_BOX, id, Box3(), 0}))); return true; }
+        if (o.kind == GraphObj::LIST_K || o.kind == GraphObj::BVH_K) {
+            if (++nesting > 64) { fail(ERR_UNSUPPORTED, "scene graph nests deeper than 64 levels (cycle?)"); return false; }
+            for (int32_t it : o.items)
+                if (!boundary_members(it, refs)) { --nesting; return false; }
+            --nesting;
+            return true;
+        }
+        fail(ERR_UNSUPPORTED, "constant_medium boundary must be a sphere, a cube or a list / bvh_tree of those (optionally translated/rotated as a whole)");
+        return false;
+    }
+
+    void collect(int32_t id, std::vector<Item>& out, const Chain& outer) {
         if (rc) return;
         struct Guard { int& n; Guard(int& x) : n(x) { ++n; } ~Guard() { --n; } } guard(nesting);
         if (nesting > 64) { fail(ERR_UNSUPPORTED, "scene graph nests deeper than 64 levels (cycle?)"); return; }
@@ -396,61 +432,71 @@ struct Lowering {
         case GraphObj::CUBE_K: out.push_back({PRIM_BOX, id, bounds_of(o), next_seq++}); break;
         case GraphObj::LIST_K:
         case GraphObj::BVH_K:
-            for (int32_t it : o.items) collect(it, out, inside_instance, inst_depth);
+            for (int32_t it : o.items) collect(it, out, outer);
             break;
         case GraphObj::TRANSLATE_K:
         case GraphObj::ROTATE_K: {
-            if (inside_instance) { fail(ERR_UNSUPPORTED, "translate/rotate_y nested inside another transformed group"); return; }
+            InstanceRec<double> own;
+            int32_t inner = peel_ops(id, own);
+            if (rc) return;
+            Chain full = outer;
+            if (!append_ops(full, own)) return;
             InstanceRec<double> in;
-            int32_t inner = peel_ops(id, in);
-            if (rc) return;
+            chain_to_inst(full, in);
             std::vector<Item> sub;
-            uint32_t dummy = 0;
-            collect(inner, sub, true, dummy);
+            collect(inner, sub, full);
             if (rc) return;
+            if (sub.empty()) break; // nothing but nested instances / media inside: they went to the top level themselves
             uint32_t depth = 0;
             Box3 ob;
             in.root = build_root(sub, depth, ob);
-            inst_depth = std::max(inst_depth, depth);
             // a wrapped single object (the Cornell blocks: `cube.rotate_y(a).translate(v)`): build_root made a node whose
             // only child is that record's leaf; the walk tests the record in place instead of entering a one-node tree
             in.single_leaf = 0;
-            if (sub.size() == 1 && sub[0].kind != PRIM_INSTANCE && fs.nodes[in.root].child0 < 0 && fs.nodes[in.root].child1 == CHILD_EMPTY &&
+            if (sub.size() == 1 && fs.nodes[in.root].child0 < 0 && fs.nodes[in.root].child1 == CHILD_EMPTY &&
                 leaf_count(fs.nodes[in.root].child0) == 1)
                 in.single_leaf = fs.nodes[in.root].child0;
             Box3 wb;
-            if (!sub.empty()) {
-                for (int c = 0; c < 8; ++c) {
-                    double p[3] = {(c & 1) ? ob.hi[0] : ob.lo[0], (c & 2) ? ob.hi[1] : ob.lo[1], (c & 4) ? ob.hi[2] : ob.lo[2]};
-                    to_world(in, p);
-                    wb.grow_pt(p);
-                }
-                // guard the sin/cos rounding of the corner transform
-                for (int k = 0; k < 3; ++k) {
-                    double pad = 1e-9 * std::max(1.0, std::max(std::fabs(wb.lo[k]), std::fabs(wb.hi[k])));
-                    wb.lo[k] -= pad; wb.hi[k] += pad;
-                }
+            for (int c = 0; c < 8; ++c) {
+                double p[3] = {(c & 1) ? ob.hi[0] : ob.lo[0], (c & 2) ? ob.hi[1] : ob.lo[1], (c & 4) ? ob.hi[2] : ob.lo[2]};
+                to_world(in, p);
+                wb.grow_pt(p);
+            }
+            // guard the sin/cos rounding of the corner transform
+            for (int k = 0; k < 3; ++k) {
+                double pad = 1e-9 * std::max(1.0, std::max(std::fabs(wb.lo[k]), std::fabs(wb.hi[k])));
+                wb.lo[k] -= pad; wb.hi[k] += pad;
             }
             fs.insts.push_back(in);
-            out.push_back({PRIM_INSTANCE, int32_t(fs.insts.size() - 1), wb, 0});
+            top_items->push_back({PRIM_INSTANCE, int32_t(fs.insts.size() - 1), wb, 0}); // always a leaf of the TOP tree
             break;
         }
         case GraphObj::MEDIUM_K: {
-            if (inside_instance) { fail(ERR_UNSUPPORTED, "constant_medium inside a transformed group"); return; }
-            InstanceRec<double> in;
-            int32_t base = peel_ops(o.a, in);
+            InstanceRec<double> own;
+            int32_t base = peel_ops(o.a, own);
             if (rc) return;
-            const GraphObj& bo = g.objs[base];
+            Chain full = outer;
+            if (!append_ops(full, own)) return;
             MediumRec<double> md{};
-            if (bo.kind == GraphObj::SPHERE_K) md.boundary = make_ref(PRIM_SPHERE, emit({PRIM_SPHERE, base, Box3(), 0}));
-            else if (bo.kind == GraphObj::CUBE_K) md.boundary = make_ref(PRIM_BOX, emit({PRIM_BOX, base, Box3(), 0}));
-            else { fail(ERR_UNSUPPORTED, "constant_medium boundary must be a sphere or a cube (optionally translated/rotated)"); return; }
+            std::vector<int32_t> refs;
+            if (!boundary_members(base, refs)) return;
+            if (refs.empty()) { fail(ERR_UNSUPPORTED, "constant_medium with an empty boundary"); return; }
+            md.b_first = int32_t(fs.medium_refs.size());
+            md.b_count = int32_t(refs.size());
+            fs.medium_refs.insert(fs.medium_refs.end(), refs.begin(), refs.end());
             md.inst = -1;
-            if (in.n_ops > 0) { in.root = -1; fs.insts.push_back(in); md.inst = int32_t(fs.insts.size() - 1); }
+            md.n_outer = outer.n;
+            if (full.n > 0) {
+                InstanceRec<double> in;
+                chain_to_inst(full, in);
+                in.root = -1;
+                fs.insts.push_back(in);
+                md.inst = int32_t(fs.insts.size() - 1);
+            }
             md.mat = mat_index[o.b];
             md.neg_inv_density = -1. / o.v[0]; // hittable.rs:733
             // media keep their creation order (= RNG slot, DESIGN.md "RNG")
-            if (size_t(o.c) >= fs.media.size()) fs.media.resize(size_t(o.c) + 1, MediumRec<double>{make_ref(PRIM_NONE, 0), -1, 0, 0, 0.0});
+            if (size_t(o.c) >= fs.media.size()) fs.media.resize(size_t(o.c) + 1, MediumRec<double>{-1, 0, -1, 0, 0, 0, 0.0});
             fs.media[o.c] = md;
             break;
         }
@@ -574,11 +620,11 @@ struct Lowering {
         if (g.world < 0 || g.objs[g.world].kind != GraphObj::LIST_K) return fail(-2, "commit: world not set");
         lower_textures_materials();
         std::vector<Item> top;
-        uint32_t inst_depth = 0;
-        collect(g.world, top, false, inst_depth);
+        top_items = &top;
+        collect(g.world, top, Chain{});
         if (rc) return rc;
         for (const auto& md : fs.media)
-            if (ref_kind(md.boundary) == PRIM_NONE) return fail(ERR_UNSUPPORTED, "a constant_medium was created but is not in the world list");
+            if (md.b_first < 0) return fail(ERR_UNSUPPORTED, "a constant_medium was created but is not in the world list");
         uint32_t top_depth = 0;
         Box3 wb;
         fs.top_root2 = build_root(top, top_depth, wb);
@@ -611,14 +657,15 @@ struct Lowering {
 static bool fits_lds_form(const FlatScene& f) {
     return lds_form_bytes(uint32_t(f.nodes4.size()), f.stack_depth, 1024) <= 160 * 1024;
 }
-int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder) {
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder, double time0, double time1) {
     const bool small = g.objs.size() <= 8192 && builder == nullptr;
     const char* forced = getenv("RTTNW_MAX_LEAF"); // experiments: force the leaf size of the host SAH build (1, 2 or 4)
     for (size_t max_leaf : {size_t(1), size_t(2), size_t(4)}) {
         if (forced && *forced && size_t(atoi(forced)) != max_leaf && max_leaf != 4) continue;
         if (!small && max_leaf != 4) continue;
         out = FlatScene();
-        Lowering lw{g, out, err, {}, {}, 0, builder, max_leaf};
+        out.time0 = time0; out.time1 = time1;
+        Lowering lw{g, out, err, {}, {}, 0, builder, max_leaf, time0, time1};
         const int rc = lw.run();
         if (rc != 0 || max_leaf == 4 || fits_lds_form(out)) return rc;
     }

@@ -49,6 +49,8 @@ struct FlatScene {
     std::vector<BoxRec<double>> boxes;
     std::vector<InstanceRec<double>> insts;
     std::vector<MediumRec<double>> media;
+    std::vector<int32_t> medium_refs; // boundary primitives of the media (MediumRec::b_first / b_count)
+    double time0 = 0.0, time1 = 1.0;  // shutter interval the moving spheres' boxes were built for (BvhTree::from_time, hittable.rs:261)
     std::vector<MaterialRec<double>> mats;
     std::vector<TextureRec<double>> texs;
     std::vector<ImageRec> images;
@@ -62,7 +64,8 @@ struct FlatScene {
 
 // Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.  `builder` (optional)
 // replaces the host binned-SAH build for every tree of two or more leaves (bvh_build.hpp).
-int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder = nullptr);
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder = nullptr, double time0 = 0.0,
+                double time1 = 1.0);
 
 // Camera::new — camera.rs:32-61 (computed once on the host, in f64)
 void make_camera(const double lookfrom[3], const double lookat[3], const double view_up[3], double vfov_deg,

@@ -6,6 +6,7 @@
 #include "../../rttnw_amd/csrc/rt_core.hpp"
 #include "../../rttnw_amd/csrc/scene_handle.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <thread>
@@ -84,14 +85,14 @@ template <typename R> struct HostScene {
             }
             insts.push_back(o);
         }
-        for (auto& m : f.media) media.push_back({m.boundary, m.inst, m.mat, 0, R(m.neg_inv_density)});
+        for (auto& m : f.media) media.push_back({m.b_first, m.b_count, m.inst, m.n_outer, m.mat, 0, R(m.neg_inv_density)});
         for (auto& m : f.mats) mats.push_back({m.type, m.tex, {R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2])}, R(m.param)});
         for (auto& t : f.texs) texs.push_back({t.type, t.a, t.b, 0, {R(t.color[0]), R(t.color[1]), R(t.color[2])}, R(t.scale)});
         for (double v : f.perlin_vec) perlin_vec.push_back(R(v));
         view.nodes = f.nodes4.data();
         view.spheres = spheres.data(); view.sphere_mat = f.sphere_mat.data(); view.sphere_seq = f.sphere_seq.data();
         view.moving = moving.data(); view.rects = rects.data(); view.boxes = boxes.data();
-        view.insts = insts.data(); view.media = media.data(); view.mats = mats.data(); view.texs = texs.data();
+        view.insts = insts.data(); view.media = media.data(); view.medium_refs = f.medium_refs.data(); view.mats = mats.data(); view.texs = texs.data();
         view.images = f.images.data(); view.texels = f.texels.data();
         view.perlin_vec = perlin_vec.data(); view.perlin_perm = f.perlin_perm.data();
         view.top_root = f.top_root; view.n_media = int32_t(media.size());
@@ -255,6 +256,12 @@ void hostsim_walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const 
 int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
                    rttnw_stats* stats, int n_threads) {
     if (!s || !s->committed || !cam || !p || !out_linear) return RTTNW_ERR_INVALID;
+    if (!s->flat.moving.empty() && (cam->open_time < s->flat.time0 || cam->close_time > s->flat.time1)) { // as render.hip validate()
+        std::string err;
+        FlatScene wider;
+        if (int rc = lower_scene(s->graph, wider, err, nullptr, std::min(s->flat.time0, cam->open_time), std::max(s->flat.time1, cam->close_time))) return rc;
+        s->flat = std::move(wider);
+    }
     return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
                                      : render_t<double>(s, cam, p, out_linear, stats, n_threads);
 }

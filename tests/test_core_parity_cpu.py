@@ -89,9 +89,10 @@ def test_unsupported_graphs_are_rejected(hostsim):
     from rttnw_amd import scene as S
     sc = S.Scene(hostsim)
     m = sc.lambertian((0.5, 0.5, 0.5))
-    inner = sc.translate(sc.sphere((0, 0, 0), 1.0, m), (1, 0, 0))
-    outer = sc.rotate_y(sc.list([inner]), 10.0)                                  # transform nested in a transformed group
-    sc.set_world(sc.list([outer]))
+    x = sc.sphere((0, 0, 0), 1.0, m)
+    for k in range(9):                                                           # nine wrappers around one object (limit: 8)
+        x = sc.translate(x, (0.1, 0, 0))
+    sc.set_world(sc.list([x]))
     with pytest.raises(abi.RttnwError, match="UNSUPPORTED"):
         sc.commit()
     sc2 = S.Scene(hostsim)
@@ -103,6 +104,19 @@ def test_unsupported_graphs_are_rejected(hostsim):
     sc3 = S.Scene(hostsim)
     with pytest.raises(abi.RttnwError):
         sc3.commit()                                                             # world not set
+
+
+@pytest.mark.parametrize("shape", sorted(__import__("graph_shapes").SHAPES))
+def test_graph_shapes_the_trait_objects_allow(hostsim, oracle, shape):
+    """Any Hittable can be wrapped, nested and used as a medium boundary in the reference (hittable.rs:51-65,731): the
+    lowering takes those graphs too (tests/graph_shapes.py) and the host build of the core agrees with the oracle."""
+    import graph_shapes
+    sh, cam, p = graph_shapes.build(hostsim, shape)
+    so, _, _ = graph_shapes.build(oracle, shape)
+    lin, _ = util.hostsim_render(hostsim, sh, cam, p)
+    lo, _, _ = rto.render(so, cam, p)
+    assert np.abs(lin - lo).max() <= 1e-11 * max(1.0, lo.max()), shape
+    assert lo.std() > 0.01                                                        # the scene is really in view
 
 
 def test_sample_ranges_compose(hostsim, oracle, scenes_lib):

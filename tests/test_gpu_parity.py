@@ -427,3 +427,26 @@ def test_render_multi_equals_single_render(gpu, scenes_lib, earth, precision):
         assert sum(x.samples for x in st) == 104 * 72 * 6 and all(x.kernel_ms > 0 for x in st)
     with pytest.raises(abi.RttnwError):
         render.render_multi(sc, cam, p, [gpu.device_count()])                      # no such device
+
+
+@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH], ids=["sah", "lbvh"])
+@pytest.mark.parametrize("shape", sorted(__import__("graph_shapes").SHAPES))
+def test_graph_shapes_the_trait_objects_allow(gpu, oracle, shape, bvh):
+    """Instances inside instances, five wrappers on one object, a medium inside a transformed group, List / BvhTree medium
+    boundaries, a shutter wider than [0, 1] (hittable.rs:51-65,261,731): the device agrees with the oracle in f64 and
+    statistically in f32."""
+    import graph_shapes
+    from rttnw_amd import scene as S
+    sg = S.Scene(gpu, 7)
+    sg.set_bvh_builder(bvh)
+    sg.set_world(graph_shapes.SHAPES[shape](sg))
+    sg.commit()
+    so, cam, p = graph_shapes.build(oracle, shape)
+    lin, rgba, _ = gpu_render(gpu, sg, cam, p)
+    lo, ro, _ = rto.render(so, cam, p)
+    assert (np.abs(lin - lo).max(axis=2) <= T1_ABS).mean() >= 0.999, (shape, np.abs(lin - lo).max())
+    assert (rgba == ro).all(axis=2).mean() >= 0.999
+    _, cam32, p32 = graph_shapes.build(oracle, shape, spp=64, precision=abi.F32)
+    lin32, _, _ = gpu_render(gpu, sg, cam32, p32)
+    lo64, _, _ = rto.render(so, cam32, graph_shapes.build(oracle, shape, spp=64)[2])
+    assert abs(lin32.mean() - lo64.mean()) / lo64.mean() < 0.01

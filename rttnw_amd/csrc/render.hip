@@ -96,8 +96,8 @@ template <uint32_t STRIDE> struct LdsStackNodes : LdsStack<STRIDE> {
     }
 };
 
-template <bool COUNT> struct CounterSel { using type = NoCounters; };
-template <> struct CounterSel<true> { using type = LaneCounters; };
+template <bool COUNT, bool GENERAL> struct CounterSel { using type = NoCountersT<GENERAL>; };
+template <bool GENERAL> struct CounterSel<true, GENERAL> { using type = LaneCountersT<GENERAL>; };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -174,14 +174,14 @@ template <typename T> __device__ __forceinline__ T kernarg_reload(uint32_t offse
 template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; };
 static_assert(alignof(SceneView<float>) <= 8 && alignof(CameraRec<double>) <= 8 && alignof(RenderConsts) <= 8, "kernarg_reload assumes naturally aligned arguments");
 
-template <typename R, bool COUNT>
+template <typename R, bool COUNT, bool GENERAL>
 __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,
                                                             uint32_t* __restrict__ pool_u, uint32_t n_slots, int32_t* __restrict__ spill) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    typename CounterSel<COUNT>::type cnt;
+    typename CounterSel<COUNT, GENERAL>::type cnt;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
     unsigned char* wbase = lds_raw + wave_in_block * wave_lds_bytes<R>(rc.stack_depth);
     R* const rq_f = reinterpret_cast<R*>(wbase);            // ray queue [7][QCAP]: o.xyz, d.xyz, time
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, Cam
 // bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
 // bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
 // decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
-template <typename R, bool COUNT, int BLOCK, bool LDSN>
+template <typename R, bool COUNT, int BLOCK, bool LDSN, bool GENERAL>
 __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, Cam
     } else {
         stack.base = (LdsIntPtr)(lds_stack + threadIdx.x);
     }
-    typename CounterSel<COUNT>::type cnt;
+    typename CounterSel<COUNT, GENERAL>::type cnt;
 
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long n_jobs = rc.n_jobs;
@@ -751,7 +751,7 @@ template <typename R> struct DeviceScene {
             in.push_back(o);
         }
         std::vector<MediumRec<R>> md;
-        for (auto& m : f.media) md.push_back({m.b_first, m.b_count, m.inst, m.n_outer, m.mat, 0, R(m.neg_inv_density)});
+        for (auto& m : f.media) md.push_back({m.b_first, m.b_count, m.inst, m.n_outer, m.mat, m.ref0, R(m.neg_inv_density)});
         std::vector<MaterialRec<R>> mt;
         for (auto& m : f.mats) mt.push_back({m.type, m.tex, {R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2])}, R(m.param)});
         std::vector<TextureRec<R>> tx;
@@ -1001,8 +1001,12 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) <= 160 * 1024;
             rc.lds_nodes = want_lds ? n4 : 0u;
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
-            const void* kernel = want_lds ? (count ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true>)
-                                          : (count ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false>);
+            const bool gen = s->flat.needs_general; // rare graph shapes: the instantiation that carries their code
+            const void* kernel =
+                want_lds ? (count ? (gen ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, false>)
+                                  : (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false>))
+                         : (count ? (gen ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, false>)
+                                  : (gen ? (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false, false>));
             const size_t lds_bytes = lds_form_bytes(want_lds ? n4 : 0u, rc.stack_depth, uint32_t(block));
             if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
             HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
@@ -1023,7 +1027,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                 HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
             }
         } else {
-            auto kernel = count ? trace_kernel<R, true> : trace_kernel<R, false>;
+            const bool gen = s->flat.needs_general;
+            auto kernel = count ? (gen ? trace_kernel<R, true, true> : trace_kernel<R, true, false>) : (gen ? trace_kernel<R, false, true> : trace_kernel<R, false, false>);
             const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
             size_t grid = 1;
             if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;

@@ -160,19 +160,26 @@ template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bo
 }
 
 // ---------------------------------------------------------------- counters (instrumentation)
-struct NoCounters {
+// Counter policies.  Their template flag GENERAL also selects, at compile time, whether the code for the rare graph shapes
+// (more than FAST_INSTANCE_OPS wrappers around an object, List / BvhTree medium boundaries, media inside transformed groups;
+// FlatScene::needs_general) is compiled into a kernel at all: it costs the common kernels registers even when it never runs.
+template <bool G> struct NoCountersT {
+    static constexpr bool GENERAL = G;
     RT_HD void ray() {}
     RT_HD void node() {}
     RT_HD void prim() {}
     RT_HD void texel() {}
 };
-struct LaneCounters {
+template <bool G> struct LaneCountersT {
+    static constexpr bool GENERAL = G;
     uint32_t rays = 0, nodes = 0, prims = 0, texels = 0;
     RT_HD void ray() { ++rays; }
     RT_HD void node() { ++nodes; }
     RT_HD void prim() { ++prims; }
     RT_HD void texel() { ++texels; }
 };
+using NoCounters = NoCountersT<true>;     // host build, probes: every shape
+using LaneCounters = LaneCountersT<true>;
 
 // ---------------------------------------------------------------- camera (camera.rs:63-84)
 template <typename R>
@@ -367,58 +374,123 @@ RT_HD bool box_t(const BoxRec<R>& bx, const Ray<R>& ray, R t_min, R t_max, R& t_
     return any;
 }
 
-template <typename R> RT_HD void face_normal(V3<R> dir, V3<R> outward, V3<R>& normal, bool& front);
-// Ray -> object space through the first `n` ops of an instance (Translate::hit :600-604, YRotate::hit :687-697).  The record
-// is read through a reference, op by op: chains are short (two ops in the reference's scenes) and entered rarely.
-template <typename R> RT_HD Ray<R> to_object_n(const InstanceRec<R>& in, Ray<R> ray, int n) {
-    for (int i = 0; i < n; ++i) {
-        const int32_t type = in.ops[i].type;
-        const R v0 = in.ops[i].v[0], v1 = in.ops[i].v[1], v2 = in.ops[i].v[2];
-        if (type == OP_TRANSLATE) {
-            ray.o = ray.o - V3<R>(v0, v1, v2);
-        } else {
-            const R s = v0, c = v1;
-            const R ox = c * ray.o.x - s * ray.o.z, oz = s * ray.o.x + c * ray.o.z;
-            const R dx = c * ray.d.x - s * ray.d.z, dz = s * ray.d.x + c * ray.d.z;
-            ray.o.x = ox; ray.o.z = oz; ray.d.x = dx; ray.d.z = dz;
+template <typename R> RT_HD const InstanceHead<R>& head_of(const InstanceRec<R>& in) { return reinterpret_cast<const InstanceHead<R>&>(in); }
+
+// Ray -> object space through the ops of an instance (Translate::hit :600-604, YRotate::hit :687-697): a chain of up to
+// FAST_INSTANCE_OPS wrappers (copied by value, unrolled) ...
+template <typename R> RT_HD Ray<R> to_object_fast(const InstanceHead<R>& in, Ray<R> ray, int n) {
+#pragma unroll
+    for (int i = 0; i < FAST_INSTANCE_OPS; ++i) {
+        if (i < n) {
+            if (in.ops[i].type == OP_TRANSLATE) {
+                ray.o = ray.o - V3<R>(in.ops[i].v);
+            } else {
+                R s = in.ops[i].v[0], c = in.ops[i].v[1];
+                R ox = c * ray.o.x - s * ray.o.z, oz = s * ray.o.x + c * ray.o.z;
+                R dx = c * ray.d.x - s * ray.d.z, dz = s * ray.d.x + c * ray.d.z;
+                ray.o.x = ox; ray.o.z = oz; ray.d.x = dx; ray.d.z = dz;
+            }
         }
     }
     return ray;
 }
-template <typename R> RT_HD Ray<R> to_object(const InstanceRec<R>& in, Ray<R> ray) { return to_object_n(in, ray, in.n_ops); }
-// The ray DIRECTION after ops[0..upto] (what level `upto`'s face_normal sees: Translate's `moved_ray` :607, YRotate's rotated ray :706).
-template <typename R> RT_HD V3<R> dir_after(const InstanceRec<R>& in, V3<R> d, int upto) {
-    for (int i = 0; i <= upto; ++i)
-        if (in.ops[i].type == OP_ROTATE_Y) {
-            const R s = in.ops[i].v[0], c = in.ops[i].v[1];
-            const R dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
-            d.x = dx; d.z = dz;
+// ... and any longer one, op by op through the record in memory.
+template <typename R> RT_HD void to_object_general(const InstanceRec<R>* in, Ray<R>* ray, int n) {
+    Ray<R> r = *ray;
+    for (int i = 0; i < n; ++i) {
+        const int32_t type = in->ops[i].type;
+        const R v0 = in->ops[i].v[0], v1 = in->ops[i].v[1], v2 = in->ops[i].v[2];
+        if (type == OP_TRANSLATE) {
+            r.o = r.o - V3<R>(v0, v1, v2);
+        } else {
+            const R s = v0, c = v1;
+            const R ox = c * r.o.x - s * r.o.z, oz = s * r.o.x + c * r.o.z;
+            const R dx = c * r.d.x - s * r.d.z, dz = s * r.d.x + c * r.d.z;
+            r.o.x = ox; r.o.z = oz; r.d.x = dx; r.d.z = dz;
         }
-    return d;
-}
-// Unwind a hit record (p, normal, front_face) through ops[n-1] .. ops[0], innermost first, with the reference's
-// face_normal call at every level and — under quirk Q1 — its overwritten-x back-rotation (hittable.rs:700-706, :607-611).
-template <typename R>
-RT_HD void unwind_record(const InstanceRec<R>& in, int n, V3<R> world_dir, uint32_t quirks, V3<R>& p, V3<R>& normal, bool& front_face) {
-    for (int i = n - 1; i >= 0; --i) {
-        if (in.ops[i].type == OP_ROTATE_Y) { // hittable.rs:700-706
-            const R s = in.ops[i].v[0], c = in.ops[i].v[1];
-            const R px = c * p.x + s * p.z;
-            const R nx = c * normal.x + s * normal.z;
-            // Q1: the reference's z line reads the x it has just overwritten
-            const R pxz = (quirks & 1u) ? px : p.x;
-            const R nxz = (quirks & 1u) ? nx : normal.x;
-            const R pz = -s * pxz + c * p.z;
-            const R nz = -s * nxz + c * normal.z;
-            p.x = px; p.z = pz;
-            normal.x = nx; normal.z = nz;
-        } else { // hittable.rs:607-611
-            p = p + V3<R>(in.ops[i].v[0], in.ops[i].v[1], in.ops[i].v[2]);
-        }
-        V3<R> nn; bool ff;
-        face_normal(dir_after(in, world_dir, i), normal, nn, ff);
-        normal = nn; front_face = ff;
     }
+    *ray = r;
+}
+template <bool G, typename R> RT_HD Ray<R> to_object_n(const InstanceRec<R>& in, Ray<R> ray, int n) {
+    if (!G || n <= FAST_INSTANCE_OPS) { // !G: the host selected this kernel because no chain of the scene is longer
+        const InstanceHead<R> h = head_of(in);
+        return to_object_fast(h, ray, n);
+    }
+    if constexpr (G) to_object_general(&in, &ray, n);
+    return ray;
+}
+template <bool G, typename R> RT_HD Ray<R> to_object(const InstanceRec<R>& in, Ray<R> ray) { return to_object_n<G>(in, ray, head_of(in).n_ops); }
+
+template <typename R> RT_HD void face_normal(V3<R> dir, V3<R> outward, V3<R>& normal, bool& front);
+// Unwind a hit record (p, normal, front_face) through ops[n-1] .. ops[0], innermost first, with the reference's face_normal
+// call at every level — level i sees the ray direction after ops[0..i] (Translate's `moved_ray` :607, YRotate's rotated
+// ray :706) — and, under quirk Q1, its overwritten-x back-rotation (hittable.rs:700-706, :607-611).
+template <typename R> RT_HD void unwind_op(int32_t type, R v0, R v1, R v2, V3<R> dir, uint32_t quirks, V3<R>& p, V3<R>& normal, bool& front_face) {
+    if (type == OP_ROTATE_Y) { // hittable.rs:700-706
+        const R s = v0, c = v1;
+        const R px = c * p.x + s * p.z;
+        const R nx = c * normal.x + s * normal.z;
+        // Q1: the reference's z line reads the x it has just overwritten
+        const R pxz = (quirks & 1u) ? px : p.x;
+        const R nxz = (quirks & 1u) ? nx : normal.x;
+        const R pz = -s * pxz + c * p.z;
+        const R nz = -s * nxz + c * normal.z;
+        p.x = px; p.z = pz;
+        normal.x = nx; normal.z = nz;
+    } else { // hittable.rs:607-611
+        p = p + V3<R>(v0, v1, v2);
+    }
+    V3<R> nn; bool ff;
+    face_normal(dir, normal, nn, ff);
+    normal = nn; front_face = ff;
+}
+template <typename R> RT_HD void unwind_fast(const InstanceHead<R>& in, int n, V3<R> world_dir, uint32_t quirks, V3<R>& p, V3<R>& normal, bool& front_face) {
+    V3<R> dirs[FAST_INSTANCE_OPS];
+    {
+        V3<R> d = world_dir;
+#pragma unroll
+        for (int i = 0; i < FAST_INSTANCE_OPS; ++i) {
+            if (i < n && in.ops[i].type == OP_ROTATE_Y) {
+                R s = in.ops[i].v[0], c = in.ops[i].v[1];
+                R dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
+                d.x = dx; d.z = dz;
+            }
+            dirs[i] = d;
+        }
+    }
+#pragma unroll
+    for (int i = FAST_INSTANCE_OPS - 1; i >= 0; --i)
+        if (i < n) unwind_op(in.ops[i].type, in.ops[i].v[0], in.ops[i].v[1], in.ops[i].v[2], dirs[i], quirks, p, normal, front_face);
+}
+template <typename R> RT_HD void unwind_general(const InstanceRec<R>* in, int n, V3<R> world_dir, uint32_t quirks, V3<R>* p_io, V3<R>* n_io, bool* ff_io) {
+    V3<R> p = *p_io, normal = *n_io;
+    bool ff = *ff_io;
+    for (int i = n - 1; i >= 0; --i) {
+        V3<R> d = world_dir; // the direction after ops[0..i]
+        for (int k = 0; k <= i; ++k)
+            if (in->ops[k].type == OP_ROTATE_Y) {
+                const R s = in->ops[k].v[0], c = in->ops[k].v[1];
+                const R dx = c * d.x - s * d.z, dz = s * d.x + c * d.z;
+                d.x = dx; d.z = dz;
+            }
+        unwind_op(in->ops[i].type, in->ops[i].v[0], in->ops[i].v[1], in->ops[i].v[2], d, quirks, p, normal, ff);
+    }
+    *p_io = p; *n_io = normal; *ff_io = ff;
+}
+template <bool G, typename R>
+RT_HD void unwind_record(const InstanceRec<R>& in, int n, V3<R> world_dir, uint32_t quirks, V3<R>& p, V3<R>& normal, bool& front_face) {
+    if (!G || n <= FAST_INSTANCE_OPS) {
+        const InstanceHead<R> h = head_of(in);
+        unwind_fast(h, n, world_dir, quirks, p, normal, front_face);
+    } else {
+        if constexpr (G) unwind_general(&in, n, world_dir, quirks, &p, &normal, &front_face);
+    }
+}
+// The ray DIRECTION after ops[0..upto] (a medium inside a transformed group measures its free flight along that ray).
+template <bool G, typename R> RT_HD V3<R> dir_after(const InstanceRec<R>& in, V3<R> d, int upto) {
+    Ray<R> r;
+    r.o = V3<R>(); r.d = d; r.time = R(0);
+    return to_object_n<G>(in, r, upto + 1).d;
 }
 
 // Rectangle hit coordinates at parameter t, no range checks (used to rebuild the winner's record).
@@ -597,23 +669,29 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     const uint32_t kind = leaf_kind(tr.node), count = leaf_count(tr.node), first = leaf_first(tr.node);
     if (kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
         cnt.prim();
-        const InstanceRec<R>& in = sc.insts[first];
-        if (in.single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk
+        const InstanceRec<R>& in_rec = sc.insts[first];
+        const InstanceHead<R> head = head_of(in_rec); // one by-value copy serves the transform below
+        const int32_t single_leaf = head.single_leaf, inst_root = head.root;
+        auto object_ray = [&]() -> Ray<R> {
+            if (!Cnt::GENERAL || head.n_ops <= FAST_INSTANCE_OPS) return to_object_fast(head, wray, head.n_ops);
+            return to_object<Cnt::GENERAL>(in_rec, wray);
+        };
+        if (single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk
             const Ray<R> outer = tr.ray;
             const int32_t outer_inst = tr.cur_inst;
-            tr.ray = to_object(in, wray);
+            tr.ray = object_ray();
             tr.cur_inst = int32_t(first);
             cnt.prim();
-            trav_test_record(tr, sc, leaf_kind(in.single_leaf), leaf_first(in.single_leaf), t_min);
+            trav_test_record(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min);
             tr.ray = outer;
             tr.cur_inst = outer_inst;
             trav_pop(tr, wray, stack);
             return;
         }
         stack.set(tr.sp++, STACK_SENTINEL);
-        trav_set_ray(tr, to_object(in, wray), stack);
+        trav_set_ray(tr, object_ray(), stack);
         tr.cur_inst = int32_t(first);
-        tr.node = in.root;
+        tr.node = inst_root;
         return;
     }
     if constexpr (WHOLE_LEAF) {
@@ -676,11 +754,11 @@ template <typename R> RT_HD bool uv_is_read(const SceneView<R>& sc, int32_t mat)
     return tex >= 0 && (sc.texs[tex].type == TEX_IMAGE || sc.texs[tex].type == TEX_CHECKER);
 }
 
-template <typename R>
+template <bool G, typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim), idx = ref_index(ref.prim);
     Ray<R> ray = wray;
-    if (ref.inst >= 0) ray = to_object(sc.insts[ref.inst], wray);
+    if (ref.inst >= 0) ray = to_object<G>(sc.insts[ref.inst], wray);
     rec.t = t;
     V3<R> outward;
     if (kind == PRIM_SPHERE) { // hittable.rs:109-113
@@ -729,7 +807,7 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
 
     if (ref.inst >= 0) {
         const InstanceRec<R>& in = sc.insts[ref.inst];
-        unwind_record(in, in.n_ops, wray.d, quirks, rec.p, rec.normal, rec.front_face);
+        unwind_record<G>(in, head_of(in).n_ops, wray.d, quirks, rec.p, rec.normal, rec.front_face);
     }
 }
 
@@ -751,11 +829,11 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
     for (int32_t m = 0; m < sc.n_media; ++m) {
         const MediumRec<R> md = sc.media[m];
         Ray<R> bray = ray;
-        if (md.inst >= 0) bray = to_object(sc.insts[md.inst], ray);
-        const int32_t ref0 = sc.medium_refs[md.b_first];
+        if (md.inst >= 0) bray = to_object<Cnt::GENERAL>(sc.insts[md.inst], ray);
+        const int32_t ref0 = md.ref0;
         R t1, t2;
         cnt.prim(); // first boundary query; the second is counted once the first has hit, as the reference would call it
-        if (md.b_count == 1 && ref_kind(ref0) == PRIM_SPHERE) {
+        if ((!Cnt::GENERAL || md.b_count == 1) && ref_kind(ref0) == PRIM_SPHERE) {
             // boundary.hit(ray, -inf, +inf) then boundary.hit(ray, t1 + 0.0001, +inf) (hittable.rs:745-751) are two
             // evaluations of ONE quadratic: same discriminant, near root first, far root if the near one is out of
             // range.  Evaluated once here, with Sphere::hit's range tests kept literally (NaN behaviour included).
@@ -778,6 +856,11 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
                 t2 = far_root;
                 if (t2 < lo2 || Lim<R>::inf() < t2) continue;
             }
+        } else if constexpr (!Cnt::GENERAL) { // one cube (smoke_cornell_box): the two queries of hittable.rs:745-751
+            int aux;
+            if (!prim_t(sc, ref_kind(ref0), ref_index(ref0), bray, -Lim<R>::inf(), Lim<R>::inf(), t1, aux)) continue;
+            cnt.prim();
+            if (!prim_t(sc, ref_kind(ref0), ref_index(ref0), bray, t1 + medium_sep(t1), Lim<R>::inf(), t2, aux)) continue;
         } else {
             // any boundary: a cube, or a List / BvhTree of spheres and cubes (ConstantMedium takes any Hittable and treats it
             // as convex, hittable.rs:731,739): List::hit over the members with a shrinking t_max (hittable.rs:153-163), twice
@@ -808,7 +891,9 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         if (t1 >= t2) continue; // before any draw
         t1 = rt_max(t1, R(0));
         // the ray as the medium itself sees it: inside a transformed group, the group's object-space ray
-        const V3<R> mdir = md.n_outer > 0 ? dir_after(sc.insts[md.inst], ray.d, md.n_outer - 1) : ray.d;
+        V3<R> mdir = ray.d;
+        if constexpr (Cnt::GENERAL)
+            if (md.n_outer > 0) mdir = dir_after<true>(sc.insts[md.inst], ray.d, md.n_outer - 1);
         R ray_length = magnitude(mdir);
         R distance_inside = (t2 - t1) * ray_length;
         R hit_distance = md.neg_inv_density * rt_log(uniform01_log<R>(key, rng_ctr(bounce + 1, SLOT_MEDIUM + uint32_t(m))));
@@ -825,15 +910,15 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         rec.front_face = true;
         rec.u = R(0); rec.v = R(0);
         rec.mat = md.mat;
-        if (md.n_outer > 0) { // a medium inside a transformed group: its record goes through the group's wrappers like any other
-            const InstanceRec<R>& in = sc.insts[md.inst];
-            rec.p = to_object_n(in, ray, md.n_outer).at(closest);
-            unwind_record(in, md.n_outer, ray.d, quirks, rec.p, rec.normal, rec.front_face);
-        } else {
-            rec.p = ray.at(closest);
-        }
+        rec.p = ray.at(closest);
+        if constexpr (Cnt::GENERAL)
+            if (md.n_outer > 0) { // a medium inside a transformed group: its record goes through the group's wrappers like any other
+                const InstanceRec<R>& in = sc.insts[md.inst];
+                rec.p = to_object_n<true>(in, ray, md.n_outer).at(closest);
+                unwind_record<true>(in, md.n_outer, ray.d, quirks, rec.p, rec.normal, rec.front_face);
+            }
     } else {
-        make_record(sc, ray, best, closest, quirks, rec);
+        make_record<Cnt::GENERAL>(sc, ray, best, closest, quirks, rec);
     }
     return true;
 }

@@ -101,6 +101,14 @@ template <typename R> struct alignas(16) InstanceRec {
     struct Op { int32_t type; int32_t pad; R v[3]; } ops[MAX_INSTANCE_OPS]; // translate: offset; rotate: {sin, cos, -}
 };
 
+// The head of an instance record: what a chain of up to FAST_INSTANCE_OPS wrappers (every scene of the reference: two) needs.
+// The kernels copy it by value and run unrolled code; longer chains take the general, out-of-line path over the full record.
+constexpr int FAST_INSTANCE_OPS = 3;
+template <typename R> struct alignas(16) InstanceHead {
+    int32_t n_ops, root, single_leaf, pad0;
+    typename InstanceRec<R>::Op ops[FAST_INSTANCE_OPS];
+};
+
 template <typename R> struct MediumRec {
     int32_t b_first;  // boundary = medium_refs[b_first .. b_first + b_count): make_ref(kind, index) of spheres / boxes; more than
     int32_t b_count;  //   one = a List / BvhTree boundary (ConstantMedium takes any Hittable, hittable.rs:731)
@@ -108,7 +116,7 @@ template <typename R> struct MediumRec {
     int32_t n_outer;  // how many of those ops (the leading ones) wrap the MEDIUM itself (a medium inside a transformed
                       //   group): its hit record is unwound through them like any other record of the group
     int32_t mat;      // Isotropic material
-    int32_t pad;
+    int32_t ref0;     // medium_refs[b_first], inline: the common one-primitive boundary needs no second lookup
     R neg_inv_density;
 };
 

@@ -483,6 +483,7 @@ struct Lowering {
             if (refs.empty()) { fail(ERR_UNSUPPORTED, "constant_medium with an empty boundary"); return; }
             md.b_first = int32_t(fs.medium_refs.size());
             md.b_count = int32_t(refs.size());
+            md.ref0 = refs[0];
             fs.medium_refs.insert(fs.medium_refs.end(), refs.begin(), refs.end());
             md.inst = -1;
             md.n_outer = outer.n;
@@ -496,7 +497,7 @@ struct Lowering {
             md.mat = mat_index[o.b];
             md.neg_inv_density = -1. / o.v[0]; // hittable.rs:733
             // media keep their creation order (= RNG slot, DESIGN.md "RNG")
-            if (size_t(o.c) >= fs.media.size()) fs.media.resize(size_t(o.c) + 1, MediumRec<double>{-1, 0, -1, 0, 0, 0, 0.0});
+            if (size_t(o.c) >= fs.media.size()) fs.media.resize(size_t(o.c) + 1, MediumRec<double>{-1, 0, -1, 0, 0, make_ref(PRIM_NONE, 0), 0.0});
             fs.media[o.c] = md;
             break;
         }
@@ -643,6 +644,8 @@ struct Lowering {
         // Entries a lane's stack can hold at once: the pending children of the top tree and, while inside an instance,
         // one sentinel plus the pending children of the instance's tree.  +1 spare.
         fs.stack_depth = top_need + (any_tree ? 1u + inst_need : 0u) + 1u;
+        for (const auto& in : fs.insts) fs.needs_general = fs.needs_general || in.n_ops > FAST_INSTANCE_OPS;
+        for (const auto& md : fs.media) fs.needs_general = fs.needs_general || md.b_count > 1 || md.n_outer > 0;
         return 0;
     }
 };

@@ -57,6 +57,8 @@ struct FlatScene {
     std::vector<uint32_t> texels;
     std::vector<double> perlin_vec;   // [n][256][3]
     std::vector<uint8_t> perlin_perm; // [n][3][256]
+    bool needs_general = false;       // a chain of more than FAST_INSTANCE_OPS wrappers, a multi-member medium boundary or a medium
+                                      //   inside a transformed group: rendered by the GENERAL instantiation of the kernels
     int32_t top_root = 0;
     uint32_t stack_depth = 4;         // entries a lane's traversal stack can need (exact bound for the 4-wide trees)
     uint32_t n_prims_in_bvh = 0;

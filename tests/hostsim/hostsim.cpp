@@ -85,7 +85,7 @@ template <typename R> struct HostScene {
             }
             insts.push_back(o);
         }
-        for (auto& m : f.media) media.push_back({m.b_first, m.b_count, m.inst, m.n_outer, m.mat, 0, R(m.neg_inv_density)});
+        for (auto& m : f.media) media.push_back({m.b_first, m.b_count, m.inst, m.n_outer, m.mat, m.ref0, R(m.neg_inv_density)});
         for (auto& m : f.mats) mats.push_back({m.type, m.tex, {R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2])}, R(m.param)});
         for (auto& t : f.texs) texs.push_back({t.type, t.a, t.b, 0, {R(t.color[0]), R(t.color[1]), R(t.color[2])}, R(t.scale)});
         for (double v : f.perlin_vec) perlin_vec.push_back(R(v));

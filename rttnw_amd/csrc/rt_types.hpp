@@ -217,7 +217,7 @@ struct RenderConsts {
 // Schedule and passes are functions of the WHOLE image (image_tile_pixels = n_tiles * 64) and of spp only — never of the
 // number of ranks or of which tiles a rank owns: the per-pixel fold, hence the image, is bit-identical for any
 // tile_world (each rank's share of the budget below is 1/tile_world of it).
-constexpr uint64_t CHUNK_SUM_BUDGET = 8ull << 30; // bytes of chunk sums alive at once, all ranks together
+constexpr uint64_t CHUNK_SUM_BUDGET = 16ull << 30; // bytes of chunk sums alive at once, all ranks together (one GPU alone: 16 of its 288 GB)
 // RTTNW_CHUNK_SUM_BUDGET=<bytes> overrides it (tests: makes the budget bind on small images; changes how a pixel's
 // sum is grouped, i.e. rounding only).
 inline uint64_t chunk_sum_budget() {

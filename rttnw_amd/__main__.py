@@ -28,7 +28,7 @@ def main(argv=None):
     ap.add_argument("scene", type=int)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64"], help="f64 = the reference's arithmetic (default); f32 = throughput")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="image.png")
     ap.add_argument("--passes", type=int, default=1, help="render in this many passes over disjoint sample ranges, "

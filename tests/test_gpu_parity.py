@@ -450,3 +450,19 @@ def test_graph_shapes_the_trait_objects_allow(gpu, oracle, shape, bvh):
     lin32, _, _ = gpu_render(gpu, sg, cam32, p32)
     lo64, _, _ = rto.render(so, cam32, graph_shapes.build(oracle, shape, spp=64)[2])
     assert abs(lin32.mean() - lo64.mean()) / lo64.mean() < 0.01
+
+
+def test_cli_writes_the_reference_image(gpu, oracle, scenes_lib, tmp_path):
+    """`python -m rttnw_amd 7` = `cargo run --release -- 7` (main.rs:236-258): scene number -> the reference's camera and
+    size table, image.png in RGBA8, top row first; here at a reduced size / spp and checked against the oracle."""
+    from PIL import Image
+    from rttnw_amd import __main__ as cli
+    out = tmp_path / "image.png"
+    assert cli.main(["7", "--width", "48", "--spp", "6", "--out", str(out)]) == 0
+    got = np.asarray(Image.open(out))
+    assert got.shape == (48, 48, 4) and (got[..., 3] == 255).all()
+    so, setup = util.build(oracle, scenes_lib, "cornell_box")
+    cam, p = util.params_for(setup, 48, 48, 6)
+    _, ro, _ = rto.render(so, cam, p)
+    assert (got == ro).all(axis=2).mean() >= 0.999
+    assert cli.main(["12"]) == 1                                                # "There is no scene 12", main.rs:179-182

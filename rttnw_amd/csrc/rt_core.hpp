@@ -223,17 +223,19 @@ template <typename R> struct SlabRay { // what a ray contributes to every slab t
 // passes: images and hits are those of f64 slab tests, a node step costs about a third (f64 runs at half rate and
 // selects move register pairs).
 template <> struct SlabRay<double> {
-    float o[3], inv[3], slack[3];
+    float o[3], inv[3];
+    float slack; // the largest of the three axes' slacks: one widening of the box's entry / exit serves all planes (below)
 };
 template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     SlabRay<R> sr;
     if constexpr (sizeof(R) == 8) {
         const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+        sr.slack = 0.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             sr.o[a] = float(oo[a]);
             sr.inv[a] = float(1.0 / dd[a]);
-            sr.slack[a] = rt_fabs(sr.o[a] * sr.inv[a]) * 1.2e-7f;
+            sr.slack = rt_max(sr.slack, rt_fabs(sr.o[a] * sr.inv[a]) * 1.2e-7f); // maxNum: an inf * 0 axis drops out
         }
     } else {
         sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -252,29 +254,48 @@ template <typename R> RT_HD uint32_t near_piece(int a, const SlabRay<R>& sr) {
     if constexpr (sizeof(R) == 8) return uint32_t(a) + (sr.inv[a] < 0.f ? 3u : 0u);
     else return uint32_t(a) + ((a == 0 ? sr.inv.x : (a == 1 ? sr.inv.y : sr.inv.z)) < R(0) ? 3u : 0u);
 }
-// Child c of the record: `e` = the entry distance as a float >= tmin (ordering key only).
-RT_HD bool slab_hit4(const Planes4& nd, int c, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float& e) {
+// The four children's entry / exit distances against their boxes alone (no [t_min, closest] yet): tn[c] = the largest
+// near-plane distance, tf[c] = the smallest far-plane distance.  (As 24 PACKED f32 operations — v_pk_add_f32 / v_pk_mul_f32
+// with the ray's component splat by op_sel, which the by-axis layout makes natural — it measured SLOWER: final_scene f32
+// 1389 against 1452, spheres_1m 340 against 397: on wave64 a packed operation issues no faster than its two halves.)
+RT_HD void slab4_planes(const Planes4& nd, const float o[3], const float inv[3], float tn[4], float tf[4]) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float n = (nd.nr[a][c] - sr.o[a]) * sr.inv[a], f = (nd.fr[a][c] - sr.o[a]) * sr.inv[a];
-        n = __builtin_fmaf(-rt_fabs(n), 2.4e-7f, n) - sr.slack[a];
-        f = __builtin_fmaf(rt_fabs(f), 2.4e-7f, f) + sr.slack[a];
-        lo_t = rt_max(n, lo_t); // maxNum / minNum: a NaN plane (0 * inf) drops out
-        hi_t = rt_min(f, hi_t);
+    for (int c = 0; c < 4; ++c) {
+        const float nx = (nd.nr[0][c] - o[0]) * inv[0], fx = (nd.fr[0][c] - o[0]) * inv[0];
+        const float ny = (nd.nr[1][c] - o[1]) * inv[1], fy = (nd.fr[1][c] - o[1]) * inv[1];
+        const float nz = (nd.nr[2][c] - o[2]) * inv[2], fz = (nd.fr[2][c] - o[2]) * inv[2];
+        tn[c] = rt_max(nz, rt_max(ny, nx));
+        tf[c] = rt_min(fz, rt_min(fy, fx));
     }
-    e = lo_t;
-    return !(hi_t < lo_t);
 }
-RT_HD bool slab_hit4(const Planes4& nd, int c, V3<float> o, const SlabRay<float>& sr, float tmin, float tmax, float& e) {
-    const V3<float> inv = sr.inv;
-    const float nx = (nd.nr[0][c] - o.x) * inv.x, fx = (nd.fr[0][c] - o.x) * inv.x;
-    const float ny = (nd.nr[1][c] - o.y) * inv.y, fy = (nd.fr[1][c] - o.y) * inv.y;
-    const float nz = (nd.nr[2][c] - o.z) * inv.z, fz = (nd.fr[2][c] - o.z) * inv.z;
-    tmin = rt_max(nz, rt_max(ny, rt_max(nx, tmin)));
-    tmax = rt_min(fz, rt_min(fy, rt_min(fx, tmax)));
-    e = tmin;
-    // f32: absorb the rounding of (bound - o) * inv and of the 1-2 ulp reciprocal (boxes are already padded)
-    return !((tmax > 0.f ? tmax * 1.0000005f : tmax) < tmin);
+// Hit test of the four children against [lo_t, hi_t]; e[c] = the entry distance (>= lo_t: the ordering key).
+// f64 kernels: the conservative form.  With k the plane that sets tn, the true entry is >= t_k >= n_k - (2.4e-7 |n_k| +
+// slack_k), so tn - 2.4e-7 |tn| - slack (slack = the largest axis slack) is a lower bound of the true entry, and likewise
+// an upper bound of the true exit: ONE widening per box instead of one per plane (round 1), a box the exact f64 test
+// would pass still always passes.  NaN / inf (axis-parallel rays) never cull.
+RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float e[4], bool h[4]) {
+    float tn[4], tf[4];
+    slab4_planes(nd, sr.o, sr.inv, tn, tf);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float n = __builtin_fmaf(-rt_fabs(tn[c]), 2.4e-7f, tn[c]) - sr.slack;
+        const float f = __builtin_fmaf(rt_fabs(tf[c]), 2.4e-7f, tf[c]) + sr.slack;
+        const float lo = rt_max(n, lo_t), hi = rt_min(f, hi_t); // maxNum / minNum: a NaN drops out
+        e[c] = lo;
+        h[c] = !(hi < lo);
+    }
+}
+RT_HD void slab_hit4(const Planes4& nd, V3<float> o, const SlabRay<float>& sr, float tmin, float tmax, float e[4], bool h[4]) {
+    const float oo[3] = {o.x, o.y, o.z}, inv[3] = {sr.inv.x, sr.inv.y, sr.inv.z};
+    float tn[4], tf[4];
+    slab4_planes(nd, oo, inv, tn, tf);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float lo = rt_max(tn[c], tmin), hi = rt_min(tf[c], tmax);
+        e[c] = lo;
+        // f32: absorb the rounding of (bound - o) * inv and of the 1-2 ulp reciprocal (boxes are already padded)
+        h[c] = !((hi > 0.f ? hi * 1.0000005f : hi) < lo);
+    }
 }
 // the walk's [t_min, closest] as the floats the slab tests compare against (f64: rounded outward once per node)
 RT_HD void slab_range(double tmin, double tmax, float& lo_t, float& hi_t) {
@@ -616,12 +637,13 @@ RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     constexpr uint32_t MISS = 0xFFFFFFFFu;
     uint32_t k[4];
     int32_t ch[4];
+    float e[4];
+    bool h[4];
+    slab_hit4(nd, tr.ray.o, tr.sr, lo_t, hi_t, e, h);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float e;
         ch[c] = nd.child[c];
-        const bool h = slab_hit4(nd, c, tr.ray.o, tr.sr, lo_t, hi_t, e) && ch[c] != CHILD_EMPTY;
-        k[c] = h ? float_bits(e) : MISS; // entry distances are positive: their bit patterns order like the values
+        k[c] = (h[c] && ch[c] != CHILD_EMPTY) ? float_bits(e[c]) : MISS; // entry distances are positive: their bit patterns order like the values
     }
     pair_swap(k[0], ch[0], k[1], ch[1]); pair_swap(k[2], ch[2], k[3], ch[3]); pair_swap(k[0], ch[0], k[2], ch[2]);
     pair_swap(k[1], ch[1], k[3], ch[3]); pair_swap(k[1], ch[1], k[2], ch[2]);

@@ -214,11 +214,13 @@ template <typename R> struct SlabRay { // what a ray contributes to every slab t
     V3<R> inv; // 1 / d
 };
 // f64: the boxes are f32 and only cull, so the f64 kernels test them in f32 too — CONSERVATIVELY, which the f32
-// kernels need not be: origin and 1/d are rounded to f32 once per walk, and every plane distance is widened by a
-// bound on what that rounding can have done to it.  With o32 = o(1+e), inv32 = inv(1+e'), |e|,|e'| <= 2^-24:
-//   t32 = fl(fl(b - o32) inv32) = t (1+E) - (o32 - o) inv (1+E),  |E| <= 3 * 2^-24 + ...  ~ 1.8e-7
-//   |t32 - t| <= 1.8e-7 |t| + 6.0e-8 |o inv|      (t = (b - o) inv exactly, b a float)
-// so near planes move down and far planes up by 2.4e-7 |t32| + slack, slack = 1.2e-7 |o32 inv32|, the range's ends
+// kernels need not be: origin and 1/d are rounded to f32 once per walk (1/d as v_rcp_f32 of the rounded d: 1 ulp — three
+// f64 divisions per walk start, instance entry and instance exit were 5 % of the f64 kernel's instructions), and every
+// plane distance is widened by a bound on what that rounding can have done to it.  With o32 = o(1+e), |e| <= 2^-24,
+// inv32 = inv(1+e'), |e'| <= 2^-24 + 2^-23:
+//   t32 = fl(fl(b - o32) inv32) = t (1+E) - (o32 - o) inv (1+E),  |E| <= 2 * 2^-24 + |e'| + ...  ~ 3.0e-7
+//   |t32 - t| <= 3.0e-7 |t| + 6.0e-8 |o inv|      (t = (b - o) inv exactly, b a float)
+// so near planes move down and far planes up by 3.6e-7 |t32| + slack, slack = 1.2e-7 |o32 inv32|, the range's ends
 // are rounded outward, and NaN / inf (axis-parallel rays) never cull.  A box the exact test would pass always
 // passes: images and hits are those of f64 slab tests, a node step costs about a third (f64 runs at half rate and
 // selects move register pairs).
@@ -234,7 +236,7 @@ template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             sr.o[a] = float(oo[a]);
-            sr.inv[a] = float(1.0 / dd[a]);
+            sr.inv[a] = rt_rcp(float(dd[a]));
             sr.slack = rt_max(sr.slack, rt_fabs(sr.o[a] * sr.inv[a]) * 1.2e-7f); // maxNum: an inf * 0 axis drops out
         }
     } else {
@@ -269,8 +271,8 @@ RT_HD void slab4_planes(const Planes4& nd, const float o[3], const float inv[3],
     }
 }
 // Hit test of the four children against [lo_t, hi_t]; e[c] = the entry distance (>= lo_t: the ordering key).
-// f64 kernels: the conservative form.  With k the plane that sets tn, the true entry is >= t_k >= n_k - (2.4e-7 |n_k| +
-// slack_k), so tn - 2.4e-7 |tn| - slack (slack = the largest axis slack) is a lower bound of the true entry, and likewise
+// f64 kernels: the conservative form.  With k the plane that sets tn, the true entry is >= t_k >= n_k - (3.6e-7 |n_k| +
+// slack_k), so tn - 3.6e-7 |tn| - slack (slack = the largest axis slack) is a lower bound of the true entry, and likewise
 // an upper bound of the true exit: ONE widening per box instead of one per plane (round 1), a box the exact f64 test
 // would pass still always passes.  NaN / inf (axis-parallel rays) never cull.
 RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float e[4], bool h[4]) {
@@ -278,8 +280,8 @@ RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, f
     slab4_planes(nd, sr.o, sr.inv, tn, tf);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float n = __builtin_fmaf(-rt_fabs(tn[c]), 2.4e-7f, tn[c]) - sr.slack;
-        const float f = __builtin_fmaf(rt_fabs(tf[c]), 2.4e-7f, tf[c]) + sr.slack;
+        const float n = __builtin_fmaf(-rt_fabs(tn[c]), 3.6e-7f, tn[c]) - sr.slack;
+        const float f = __builtin_fmaf(rt_fabs(tf[c]), 3.6e-7f, tf[c]) + sr.slack;
         const float lo = rt_max(n, lo_t), hi = rt_min(f, hi_t); // maxNum / minNum: a NaN drops out
         e[c] = lo;
         h[c] = !(hi < lo);
@@ -300,8 +302,8 @@ RT_HD void slab_hit4(const Planes4& nd, V3<float> o, const SlabRay<float>& sr, f
 // the walk's [t_min, closest] as the floats the slab tests compare against (f64: rounded outward once per node)
 RT_HD void slab_range(double tmin, double tmax, float& lo_t, float& hi_t) {
     lo_t = float(tmin); hi_t = float(tmax);
-    lo_t = __builtin_fmaf(-rt_fabs(lo_t), 2.4e-7f, lo_t); // outward: float() rounds to nearest
-    hi_t = __builtin_fmaf(rt_fabs(hi_t), 2.4e-7f, hi_t);
+    lo_t = __builtin_fmaf(-rt_fabs(lo_t), 3.6e-7f, lo_t); // outward: float() rounds to nearest
+    hi_t = __builtin_fmaf(rt_fabs(hi_t), 3.6e-7f, hi_t);
 }
 RT_HD void slab_range(float tmin, float tmax, float& lo_t, float& hi_t) { lo_t = tmin; hi_t = tmax; }
 RT_HD uint32_t float_bits(float f) {
@@ -848,6 +850,7 @@ template <typename R, typename Cnt>
 RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_t key, uint32_t bounce, uint32_t quirks,
                             bool found, R closest, HitRef best, HitRecord<R>& rec, Cnt& cnt) {
     int32_t medium = -1;
+    const R world_length = sc.n_media > 0 ? magnitude(ray.d) : R(0); // |direction|: once for all media (hittable.rs:760)
     for (int32_t m = 0; m < sc.n_media; ++m) {
         const MediumRec<R> md = sc.media[m];
         Ray<R> bray = ray;
@@ -913,10 +916,9 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         if (t1 >= t2) continue; // before any draw
         t1 = rt_max(t1, R(0));
         // the ray as the medium itself sees it: inside a transformed group, the group's object-space ray
-        V3<R> mdir = ray.d;
+        R ray_length = world_length;
         if constexpr (Cnt::GENERAL)
-            if (md.n_outer > 0) mdir = dir_after<true>(sc.insts[md.inst], ray.d, md.n_outer - 1);
-        R ray_length = magnitude(mdir);
+            if (md.n_outer > 0) ray_length = magnitude(dir_after<true>(sc.insts[md.inst], ray.d, md.n_outer - 1));
         R distance_inside = (t2 - t1) * ray_length;
         R hit_distance = md.neg_inv_density * rt_log(uniform01_log<R>(key, rng_ctr(bounce + 1, SLOT_MEDIUM + uint32_t(m))));
         if (hit_distance > distance_inside) continue;
@@ -1052,8 +1054,14 @@ RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, 
         emitted = colour;
         return false;
     }
+    // The unit-ball draw of Lambertian / Isotropic / Metal (the same keyed draws whichever asks) and the unit direction of
+    // Metal / Dielectric, each in ONE place: three inlined rejection loops in three divergent branches ran one after the
+    // other, each to the iteration count of its unluckiest lane.
+    V3<R> ball, ud;
+    if (m.type == MAT_LAMBERTIAN || m.type == MAT_ISOTROPIC || m.type == MAT_METAL) ball = random_in_unit_space<R>(key, bounce);
+    if (m.type == MAT_METAL || m.type == MAT_DIELECTRIC) ud = unit(ray.d);
     if (m.type == MAT_LAMBERTIAN) { // material.rs:89-100
-        V3<R> target = rec.p + rec.normal + random_in_unit_space<R>(key, bounce);
+        V3<R> target = rec.p + rec.normal + ball;
         ray.d = target - rec.p;
         ray.o = rec.p;
         att = colour;
@@ -1061,21 +1069,20 @@ RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, 
     }
     if (m.type == MAT_ISOTROPIC) { // material.rs:256-265
         ray.o = rec.p;
-        ray.d = random_in_unit_space<R>(key, bounce);
+        ray.d = ball;
         att = colour;
         return true;
     }
     if (m.type == MAT_METAL) { // material.rs:134-149
-        V3<R> reflected = reflect(unit(ray.d), rec.normal);
+        V3<R> reflected = reflect(ud, rec.normal);
         ray.o = rec.p;
-        ray.d = reflected + m.param * random_in_unit_space<R>(key, bounce);
+        ray.d = reflected + m.param * ball;
         att = V3<R>(m.albedo);
         return dot(ray.d, rec.normal) > R(0);
     }
     // MAT_DIELECTRIC — material.rs:179-203
     att = V3<R>(R(1), R(1), R(1));
     R ratio = rec.front_face ? rt_rcp(m.param) : m.param;
-    V3<R> ud = unit(ray.d);
     R cos_theta = rt_min(dot(-ud, rec.normal), R(1));
     R sin_theta = rt_sqrt(R(1) - cos_theta * cos_theta);
     bool cannot_refract = ratio * sin_theta > R(1);

@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTTNW_ABI_VERSION: c_int = 1;
+pub const RTTNW_ABI_VERSION: c_int = 2;
 
 /// Opaque scene handle.
 #[repr(C)]

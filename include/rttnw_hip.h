@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTTNW_ABI_VERSION 1
+#define RTTNW_ABI_VERSION 2 /* 2: 4-wide node records (n_nodes, debug_scene_nodes4), rttnw_render_multi */
 
 typedef struct rttnw_scene rttnw_scene; /* opaque */
 typedef int32_t rttnw_id;

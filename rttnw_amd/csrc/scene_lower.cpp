@@ -626,6 +626,7 @@ struct Lowering {
         if (rc) return rc;
         for (const auto& md : fs.media)
             if (md.b_first < 0) return fail(ERR_UNSUPPORTED, "a constant_medium was created but is not in the world list");
+        if (fs.media.size() > 16) return fail(ERR_UNSUPPORTED, "more than 16 constant media (the free-flight draw of medium m uses RNG slot m < 16)");
         uint32_t top_depth = 0;
         Box3 wb;
         fs.top_root2 = build_root(top, top_depth, wb);

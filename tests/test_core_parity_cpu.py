@@ -104,6 +104,13 @@ def test_unsupported_graphs_are_rejected(hostsim):
     sc3 = S.Scene(hostsim)
     with pytest.raises(abi.RttnwError):
         sc3.commit()                                                             # world not set
+    sc4 = S.Scene(hostsim)
+    w4 = sc4.list()
+    for k in range(17):                                                          # 17 media: one RNG slot too many
+        sc4.push(w4, sc4.constant_medium(sc4.sphere((3.0 * k, 0, 0), 1.0, sc4.dielectric(1.5)), 0.1, (1, 1, 1)))
+    sc4.set_world(w4)
+    with pytest.raises(abi.RttnwError, match="UNSUPPORTED"):
+        sc4.commit()
 
 
 @pytest.mark.parametrize("shape", sorted(__import__("graph_shapes").SHAPES))

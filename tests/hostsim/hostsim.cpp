@@ -225,14 +225,24 @@ static void walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const r
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth; rc.quirks = p->quirks; rc.seed = p->seed;
     V3<float> background(float(p->background[0]), float(p->background[1]), float(p->background[2]));
     HostStack stack; LaneCounters cnt;
+    const int mode = node_steps / 100; // experiment: 1 = test the previous hit's primitive first when it was inside an instance
+    node_steps %= 100;
     for (uint32_t row = 0; row < rc.height; ++row)
         for (uint32_t px = 0; px < rc.width; ++px)
             for (uint32_t si = 0; si < rc.spp; ++si) {
                 PathState<float> ps;
                 path_begin(ps, camr, rc, px, row, si);
+                HitRef prev; prev.prim = make_ref(PRIM_NONE, 0); prev.inst = -1; prev.aux = 0;
                 for (;;) {
                     Trav<float> tr;
                     trav_begin(tr, hs.view, ps.ray, stack);
+                    if (mode == 1 && prev.inst >= 0 && ref_kind(prev.prim) != PRIM_NONE) {
+                        const Ray<float> saved = tr.ray;
+                        tr.ray = to_object<true>(hs.view.insts[prev.inst], ps.ray);
+                        tr.cur_inst = prev.inst;
+                        trav_test_record(tr, hs.view, ref_kind(prev.prim), ref_index(prev.prim), float(p->t_min));
+                        tr.ray = saved; tr.cur_inst = -1;
+                    }
                     uint32_t trips = 0;
                     while (tr.node != TRAV_DONE) {
                         ++trips;
@@ -242,6 +252,8 @@ static void walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const r
                     }
                     hist[trips < 63 ? trips : 63]++;
                     out2[0]++;
+                    if (tr.found && tr.best.inst >= 0) { out2[3] += trips; out2[4]++; }
+                    prev = tr.best; if (!tr.found) prev.inst = -1;
                     if (!path_shade(ps, hs.view, rc, background, float(p->t_min), tr.found, tr.closest, tr.best, cnt)) break;
                 }
             }

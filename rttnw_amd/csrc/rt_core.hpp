@@ -56,6 +56,24 @@ RT_HD float rt_div(float a, float b) {
 #endif
 }
 RT_HD double rt_div(double a, double b) { return a / b; }
+// Two quotients with ONE divisor: n1 / d and n2 / d.  f32 and the host: two divisions.  f64 on the device: the compiler's
+// IEEE division is an 11-instruction sequence around a quarter-rate v_rcp_f64, per quotient; here the reciprocal (v_rcp_f64
+// + two Newton steps) is shared and each quotient is q = n r corrected once by its residual (q + (n - d q) r, Markstein's
+// form: the correctly rounded quotient unless r is 1 ulp off the rounded reciprocal AND the quotient sits within that of a
+// rounding boundary; d = 0 gives NaN where IEEE gives inf — no hit either way in the one caller, box_t).
+RT_HD void rt_div2(float n1, float n2, float d, float& q1, float& q2) { q1 = rt_div(n1, d); q2 = rt_div(n2, d); }
+RT_HD void rt_div2(double n1, double n2, double d, double& q1, double& q2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double a1 = n1 * r, a2 = n2 * r;
+    q1 = __builtin_fma(__builtin_fma(-d, a1, n1), r, a1);
+    q2 = __builtin_fma(__builtin_fma(-d, a2, n2), r, a2);
+#else
+    q1 = n1 / d; q2 = n2 / d;
+#endif
+}
 
 template <typename R> struct Lim;
 template <> struct Lim<float> {
@@ -380,12 +398,17 @@ RT_HD bool box_t(const BoxRec<R>& bx, const Ray<R>& ray, R t_min, R t_max, R& t_
     R closest = t_max;
     int fc = 0;
     const R o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    R tf[6]; // (k - origin) / direction of the six faces (Rectangle::hit, hittable.rs:503-513): the two faces of an axis share the divisor
+#pragma unroll
+    for (int plane = 0; plane < 3; ++plane) {
+        const int ik = plane == 0 ? 2 : (plane == 1 ? 1 : 0);
+        rt_div2(bx.mn[ik] - o[ik], bx.mx[ik] - o[ik], d[ik], tf[2 * plane], tf[2 * plane + 1]);
+    }
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
         const int plane = f >> 1;                            // 0 XY, 1 XZ, 2 YZ
-        const int ia = plane == 2 ? 1 : 0, ib = plane == 0 ? 1 : 2, ik = plane == 0 ? 2 : (plane == 1 ? 1 : 0);
-        const R k = (f & 1) ? bx.mx[ik] : bx.mn[ik];
-        const R t = rt_div(k - o[ik], d[ik]);                // Rectangle::hit, hittable.rs:503-513
+        const int ia = plane == 2 ? 1 : 0, ib = plane == 0 ? 1 : 2;
+        const R t = tf[f];
         const R a = o[ia] + t * d[ia], b = o[ib] + t * d[ib];
         const bool hit = !(t < t_min) & !(t > closest) & (bx.mn[ia] <= a) & (a < bx.mx[ia]) & (bx.mn[ib] <= b) & (b < bx.mx[ib]);
         closest = hit ? t : closest;
@@ -773,10 +796,7 @@ template <typename R> RT_HD void sphere_uv(V3<R> p, R& u, R& v) { // hittable.rs
 
 // The reference computes (u, v) for every hit (Sphere::uv's acos + atan2, the rectangles' two divisions; Q11), but only
 // an image texture — possibly under a checker — ever reads them: they are computed only then.  Same results.
-template <typename R> RT_HD bool uv_is_read(const SceneView<R>& sc, int32_t mat) {
-    const int32_t tex = sc.mats[mat].tex;
-    return tex >= 0 && (sc.texs[tex].type == TEX_IMAGE || sc.texs[tex].type == TEX_CHECKER);
-}
+RT_HD bool uv_is_read(int32_t mat_ref) { return (mat_ref & MAT_UV_FLAG) != 0; } // decided by the lowering, see MAT_UV_FLAG
 
 template <bool G, typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
@@ -790,19 +810,20 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         V3<R> c(s.cx, s.cy, s.cz);
         rec.p = ray.at(t);
         outward = (rec.p - c) / s.r;
-        rec.mat = sc.sphere_mat[idx];
+        const int32_t mref = sc.sphere_mat[idx];
+        rec.mat = mref & MAT_INDEX_MASK;
         rec.u = R(0); rec.v = R(0);
-        if (uv_is_read(sc, rec.mat)) sphere_uv(outward, rec.u, rec.v);
+        if (uv_is_read(mref)) sphere_uv(outward, rec.u, rec.v);
     } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
         const MovingSphereRec<R> m = sc.moving[idx];
         rec.p = ray.at(t);
         outward = (rec.p - moving_center(m, ray.time)) / m.r;
         rec.u = R(0); rec.v = R(0);
-        rec.mat = m.mat;
+        rec.mat = m.mat & MAT_INDEX_MASK;
     } else if (kind == PRIM_RECT) { // hittable.rs:515-519
         const RectRec<R> r = sc.rects[idx];
         rec.u = R(0); rec.v = R(0);
-        if (uv_is_read(sc, r.mat)) {
+        if (uv_is_read(r.mat)) {
             R a, b;
             rect_ab(r.plane, ray, t, a, b);
             rec.u = (a - r.a0) / (r.a1 - r.a0);
@@ -810,12 +831,12 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         }
         outward = V3<R>(r.plane == 2 ? R(1) : R(0), r.plane == 1 ? R(1) : R(0), r.plane == 0 ? R(1) : R(0));
         rec.p = ray.at(t);
-        rec.mat = r.mat;
+        rec.mat = r.mat & MAT_INDEX_MASK;
     } else { // PRIM_BOX: the winning face's rectangle record
         const BoxRec<R> bx = sc.boxes[idx];
         const int plane = ref.aux >> 1;
         rec.u = R(0); rec.v = R(0);
-        if (uv_is_read(sc, bx.mat)) {
+        if (uv_is_read(bx.mat)) {
             R a, b;
             rect_ab(plane, ray, t, a, b);
             R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
@@ -825,7 +846,7 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         }
         outward = V3<R>(plane == 2 ? R(1) : R(0), plane == 1 ? R(1) : R(0), plane == 0 ? R(1) : R(0));
         rec.p = ray.at(t);
-        rec.mat = bx.mat;
+        rec.mat = bx.mat & MAT_INDEX_MASK;
     }
     face_normal(ray.d, outward, rec.normal, rec.front_face);
 

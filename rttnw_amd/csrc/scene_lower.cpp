@@ -494,7 +494,7 @@ struct Lowering {
                 fs.insts.push_back(in);
                 md.inst = int32_t(fs.insts.size() - 1);
             }
-            md.mat = mat_index[o.b];
+            md.mat = mat_index[o.b] & MAT_INDEX_MASK;
             md.neg_inv_density = -1. / o.v[0]; // hittable.rs:733
             // media keep their creation order (= RNG slot, DESIGN.md "RNG")
             if (size_t(o.c) >= fs.media.size()) fs.media.resize(size_t(o.c) + 1, MediumRec<double>{-1, 0, -1, 0, 0, make_ref(PRIM_NONE, 0), 0.0});
@@ -560,6 +560,7 @@ struct Lowering {
                 else m.tex = tex_index[o.a];
             }
             mat_index[id] = int32_t(fs.mats.size());
+            if (m.tex >= 0 && (fs.texs[m.tex].type == TEX_IMAGE || fs.texs[m.tex].type == TEX_CHECKER)) mat_index[id] |= MAT_UV_FLAG;
             fs.mats.push_back(m);
         }
     }

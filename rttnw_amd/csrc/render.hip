@@ -175,7 +175,9 @@ template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; 
 static_assert(alignof(SceneView<float>) <= 8 && alignof(CameraRec<double>) <= 8 && alignof(RenderConsts) <= 8, "kernarg_reload assumes naturally aligned arguments");
 
 template <typename R, bool COUNT, bool GENERAL>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+// (at least 3 waves/SIMD: 170 VGPRs — the f32 code needs 164; the f64 code, allowed 256, ran at 2 waves/SIMD and waited on
+// the fabric: spheres_1m f64 167 -> 264 Msamples/s with 140 registers spilled; 4 waves/SIMD: 205)
+__global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,

@@ -391,7 +391,9 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 // bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
 // decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
 template <typename R, bool COUNT, int BLOCK, bool LDSN, bool GENERAL>
-__global__ __launch_bounds__(BLOCK) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+// (the 256-thread form — nodes in global memory — asks for at least 3 waves/SIMD like the decoupled kernel: its f64 code,
+// allowed 256 VGPRs, ran at 2: a 20 000-sphere scene 29.9 -> 13.7 ms per 67 Msamples)
+__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters, int32_t* __restrict__ spill) {

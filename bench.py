@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--counter-spp", type=int, default=8)
     ap.add_argument("--counter-level", type=int, default=1, help="collect_counters of the untimed counting pass (2, 3: more RTTNW_DEBUG_SCHED statistics)")
     ap.add_argument("--no-other", action="store_true", help="skip the timing of the other precision's kernels")
+    ap.add_argument("--spp-chunk", type=int, default=0, help="samples per work item (0 = the library's tapered schedule)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder at commit: host binned SAH (default) or device LBVH")
     args = ap.parse_args()
 
@@ -163,7 +164,7 @@ def main():
     def timed(prec, steps, warmup):
         """`steps` timed steps after `warmup` untimed ones: (ms_per_step over the barrier-bracketed region, mean device
         time of the trace kernel(s) per step from the library's HIP events on the launch stream)."""
-        cam_t, p = util.params_for(setup, W, H, spp, precision=prec, tile_rank=rank, tile_world=world, seed=1)
+        cam_t, p = util.params_for(setup, W, H, spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, spp_chunk=args.spp_chunk)
         r = render.DeviceRenderer(sc, cam_t, p)
         for _ in range(warmup):
             r.step()

@@ -31,6 +31,9 @@
 #include <string>
 #include <vector>
 
+#ifndef RT_F32_STREAM_BLOCK
+#define RT_F32_STREAM_BLOCK 1024
+#endif
 #ifndef RT_F64_BLOCK
 #define RT_F64_BLOCK 768 // threads per block of the LDS-resident f64 kernel: 3 waves/SIMD at 168 VGPRs (512 / 768 / 1024: 718 / 885 / 874 Msamples/s on final_scene, 1004 / 1344 / 1166 on cornell_box; the spills at 768 are kernel-invariant values reloaded in shade)
 #endif
@@ -134,8 +137,9 @@ constexpr uint32_t SLOTS_PER_WAVE = 128; // paths owned by one wave64: 64 being 
 constexpr uint32_t QCAP = 128;           // capacity of a wave's ray queue and hit queue (entries)
 
 // Path state of a slot, in global memory (L2-resident), struct-of-arrays over all slots of the launch.
-enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_LX, PR_LY, PR_LZ, PR_AX, PR_AY, PR_AZ, PR_COUNT };
-enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
+// (PR_HT, PU_HPRIM, PU_HINST: the slot's finished walk — only trace_kernel_stream keeps it here, when its LDS has no room for it)
+enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_LX, PR_LY, PR_LZ, PR_AX, PR_AY, PR_AZ, PR_HT, PR_COUNT };
+enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_HPRIM, PU_HINST, PU_COUNT };
 // bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
 template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
     return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (LDS_STACK_ENTRIES + 1u) * 64u * 4u; // stack: + the spare slot
@@ -370,6 +374,305 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                 has_ray = false;
             }
             hit_n += uint32_t(__popcll(fm));
+        }
+    }
+
+    if constexpr (COUNT) {
+        uint32_t r = wave_sum(cnt.rays), nn = wave_sum(cnt.nodes), p = wave_sum(cnt.prims), t = wave_sum(cnt.texels);
+        if (lane == 0) {
+            atomicAdd(&counters->rays, (unsigned long long)r);
+            atomicAdd(&counters->nodes, (unsigned long long)nn);
+            atomicAdd(&counters->prims, (unsigned long long)p);
+            atomicAdd(&counters->texels, (unsigned long long)t);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) atomicAdd(&counters->dbg[k], (unsigned long long)dbg[k]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The STREAM form: the decoupled loop for scenes whose node records fit in LDS (one large block per CU, like
+// trace_kernel_plain), with the rays kept in REGISTERS.  A wave owns 128 path slots (state in global memory, as above);
+// a lane holds the ray it is walking and, most of the time, the NEXT one: the moment its walk ends it writes the hit to
+// the slot (three stores, nothing waits for them), puts the slot number on the wave's hit queue and goes on with its
+// next ray in the same trip — no lane waits for the longest walk of the wave, and no ray is read back from memory.
+// (HITS_LDS: the hits wait in LDS instead of the slot when the block's LDS has the room.)
+// When 64 hits are queued the whole wave shades them (one wait for the 64 slots' state) and hands the 64 continuation
+// rays to the lanes by ds_bpermute: first to the lanes that have none, then as "next" rays.  128 slots = 64 + 64 register
+// places + what is queued, so every ray finds a place.  Same per-path steps, same keyed draws, same job sums as the
+// other forms: the images are bit-identical (tests/test_gpu_parity.py::test_kernel_forms_agree).
+#ifndef RT_F32_STREAM_BLOCK
+#define RT_F32_STREAM_BLOCK 1024
+#endif
+// per wave: [hit queue's t, primitive, instance when HITS_LDS] + its slot | FRESH | face << 8 entries + the hand-over's lane table
+inline constexpr uint32_t stream_wave_bytes(uint32_t real_bytes, bool hits_lds) { return (hits_lds ? QCAP * (real_bytes + 8u) : 0u) + QCAP * 2u + 64u * 2u; }
+inline size_t stream_form_bytes(uint32_t n_nodes4, uint32_t stack_depth, uint32_t block, uint32_t real_bytes, bool hits_lds) {
+    return lds_form_bytes(n_nodes4, stack_depth, block) + size_t(block / 64u) * stream_wave_bytes(real_bytes, hits_lds);
+}
+// (path state is read and written with ordinary accesses: non-temporal ones, and agent-scope ones that bypass the vector
+// cache, were both slower: final_scene f32 1187 and 1271 against 1329 Msamples/s)
+template <typename T> __device__ __forceinline__ T pool_ld(const T* p) { return *p; }
+template <typename T> __device__ __forceinline__ void pool_st(T* p, T v) { *p = v; }
+__device__ __forceinline__ float lane_pull(float v, uint32_t src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(int(src_lane << 2), __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t lane_pull(uint32_t v, uint32_t src_lane) {
+    return uint32_t(__builtin_amdgcn_ds_bpermute(int(src_lane << 2), int(v)));
+}
+__device__ __forceinline__ double lane_pull(double v, uint32_t src_lane) {
+    const int lo = __builtin_amdgcn_ds_bpermute(int(src_lane << 2), __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(int(src_lane << 2), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <typename R> __device__ __forceinline__ Ray<R> lane_pull(const Ray<R>& r, uint32_t src_lane) {
+    Ray<R> g;
+    g.o = V3<R>(lane_pull(r.o.x, src_lane), lane_pull(r.o.y, src_lane), lane_pull(r.o.z, src_lane));
+    g.d = V3<R>(lane_pull(r.d.x, src_lane), lane_pull(r.d.y, src_lane), lane_pull(r.d.z, src_lane));
+    g.time = lane_pull(r.time, src_lane);
+    return g;
+}
+
+template <typename R, bool COUNT, int BLOCK, bool GENERAL, bool HITS_LDS>
+__global__ __launch_bounds__(BLOCK, 1) void trace_kernel_stream(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g, R bg_b, R t_min,
+                                                                R* __restrict__ partial, unsigned long long* __restrict__ job_counter,
+                                                                DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,
+                                                                uint32_t* __restrict__ pool_u, uint32_t n_slots, int32_t* __restrict__ spill) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    typename CounterSel<COUNT, GENERAL>::type cnt;
+    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    constexpr int NODE_STEPS = sizeof(R) == 8 ? RT_NODE_STEPS + 1 : RT_NODE_STEPS; // the trips of closest_solid()
+    LdsStackNodes<BLOCK> stack;
+    stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * BLOCK + threadIdx.x));
+    stack.spill_stride = gridDim.x * BLOCK;
+    uint16_t *hq, *tbl;
+    R* hq_t = nullptr;
+    int32_t *hq_prim = nullptr, *hq_inst = nullptr;
+    { // [node pieces][stacks of the block][per wave: hit queue, lane table]
+        const uint32_t n = rc.lds_nodes;
+        const int4* src = reinterpret_cast<const int4*>(sc.nodes);
+        int4* dst = reinterpret_cast<int4*>(lds_raw);
+        for (uint32_t i = threadIdx.x; i < n * 8u; i += BLOCK)
+            if ((i & 7u) < BVH4_USED_SIXTEENTHS) dst[(i & 7u) * n + (i >> 3)] = src[i];
+        int32_t* const stacks = reinterpret_cast<int32_t*>(lds_raw) + n * (4u * BVH4_USED_SIXTEENTHS);
+        stack.base = (LdsIntPtr)(stacks + threadIdx.x);
+        stack.piece = dst;
+        stack.n_nodes = n;
+        unsigned char* wbase = reinterpret_cast<unsigned char*>(stacks + (LDS_STACK_ENTRIES + 1u) * BLOCK) + wave_in_block * stream_wave_bytes(sizeof(R), HITS_LDS);
+        if constexpr (HITS_LDS) {
+            hq_t = reinterpret_cast<R*>(wbase);
+            hq_prim = reinterpret_cast<int32_t*>(hq_t + QCAP);
+            hq_inst = hq_prim + QCAP;
+            wbase = reinterpret_cast<unsigned char*>(hq_inst + QCAP);
+        }
+        hq = reinterpret_cast<uint16_t*>(wbase);
+        tbl = hq + QCAP;
+    }
+    const uint32_t wave_global = blockIdx.x * (BLOCK / 64) + wave_in_block;
+    const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;
+    const unsigned long long n_jobs = rc.n_jobs;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const V3<R> background(bg_r, bg_g, bg_b);
+
+    hq[lane] = uint16_t(lane | HIT_FRESH); // every slot starts out needing its first job
+    hq[lane + 64u] = uint16_t((lane + 64u) | HIT_FRESH);
+    __syncthreads(); // the node records are in place
+    uint32_t hit_n = SLOTS_PER_WAVE;                  // wave-uniform fill level of the hit queue
+    unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
+    uint32_t dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    bool has_ray = false, has_next = false;
+    uint32_t slot = 0, nslot = 0;
+    Ray<R> wray, nray; // the ray being walked and the one after it, in world space
+    Trav<R> tr;
+
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        if (hit_n >= 64u || __ballot(has_ray) == 0ull) {
+            if (hit_n == 0u) break; // nothing walking, nothing queued: this wave is done
+            // ================================================================== SHADE (up to 64 queued hits)
+            const uint32_t m = hit_n < 64u ? hit_n : 64u;
+            if constexpr (COUNT) { dbg[9] += 1; dbg[10] += m; }
+            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+            if constexpr (COUNT) c1 = c0 = clock64();
+            const bool on = lane < m;
+            const uint32_t e = hit_n - 1u - (on ? lane : 0u);
+            hit_n -= m;
+            const uint32_t meta = on ? uint32_t(hq[e]) : HIT_FRESH;
+            const uint32_t hslot = meta & 0x7Fu;
+            const bool fresh = (meta & HIT_FRESH) != 0u;
+            const size_t g = gbase + hslot;
+            R* const pr = pool_r + g;
+            uint32_t* const pu = pool_u + g;
+
+            PathState<R> ps;
+            bool emit = false, need_sample = false, slot_done = false;
+            uint32_t pxrow = 0, smp = 0, smp_end = 0;
+            unsigned long long job = ~0ull;
+            V3<R> acc;
+            if (on && !fresh) {
+                ps.ray.o = V3<R>(pool_ld(&pr[size_t(PR_OX) * n_slots]), pool_ld(&pr[size_t(PR_OY) * n_slots]), pool_ld(&pr[size_t(PR_OZ) * n_slots]));
+                ps.ray.d = V3<R>(pool_ld(&pr[size_t(PR_DX) * n_slots]), pool_ld(&pr[size_t(PR_DY) * n_slots]), pool_ld(&pr[size_t(PR_DZ) * n_slots]));
+                ps.ray.time = pool_ld(&pr[size_t(PR_TIME) * n_slots]);
+                ps.throughput = V3<R>(pool_ld(&pr[size_t(PR_TX) * n_slots]), pool_ld(&pr[size_t(PR_TY) * n_slots]), pool_ld(&pr[size_t(PR_TZ) * n_slots]));
+                ps.radiance = V3<R>(pool_ld(&pr[size_t(PR_LX) * n_slots]), pool_ld(&pr[size_t(PR_LY) * n_slots]), pool_ld(&pr[size_t(PR_LZ) * n_slots]));
+                ps.key = (unsigned long long)pool_ld(&pu[size_t(PU_KEY_LO) * n_slots]) | ((unsigned long long)pool_ld(&pu[size_t(PU_KEY_HI) * n_slots]) << 32);
+                ps.bounce = pool_ld(&pu[size_t(PU_BOUNCE) * n_slots]);
+                HitRef best;
+                R hit_t;
+                if constexpr (HITS_LDS) {
+                    hit_t = hq_t[e]; best.prim = hq_prim[e]; best.inst = hq_inst[e];
+                } else {
+                    hit_t = pool_ld(&pr[size_t(PR_HT) * n_slots]);
+                    best.prim = int32_t(pool_ld(&pu[size_t(PU_HPRIM) * n_slots]));
+                    best.inst = int32_t(pool_ld(&pu[size_t(PU_HINST) * n_slots]));
+                }
+                best.aux = int32_t((meta >> 8) & 7u);
+                const bool found = ref_kind(best.prim) != PRIM_NONE;
+                if constexpr (COUNT) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = clock64(); }
+                if (path_shade(ps, kernarg_reload<SceneView<R>>(offsetof(TraceArgsHead<R>, sc)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), background, t_min,
+                               found, hit_t, best, cnt)) {
+                    emit = true; // next world.hit of the same path
+                } else {         // main.rs:216: acc + color(...)
+                    pxrow = pool_ld(&pu[size_t(PU_PXROW) * n_slots]);
+                    smp = pool_ld(&pu[size_t(PU_S) * n_slots]);
+                    smp_end = pool_ld(&pu[size_t(PU_SEND) * n_slots]);
+                    job = (unsigned long long)pool_ld(&pu[size_t(PU_JOB_LO) * n_slots]) | ((unsigned long long)pool_ld(&pu[size_t(PU_JOB_HI) * n_slots]) << 32);
+                    acc = V3<R>(pool_ld(&pr[size_t(PR_AX) * n_slots]), pool_ld(&pr[size_t(PR_AY) * n_slots]), pool_ld(&pr[size_t(PR_AZ) * n_slots])) + ps.radiance;
+                    ++smp;
+                    need_sample = true;
+                }
+            } else if (on) {
+                need_sample = true; // fresh slot: smp == smp_end == 0, no job yet
+            }
+            if constexpr (COUNT) c2 = clock64();
+            // job hand-out for the slots whose job is finished: wave-aggregated (an empty job — a tile pixel outside the
+            // image — is finished at once, hence the loop)
+            for (;;) {
+                const bool need_job = need_sample && !slot_done && smp >= smp_end;
+                const unsigned long long jm = __ballot(need_job);
+                if (jm == 0ull) break;
+                if (need_job && job != ~0ull) { // retire the finished job: its sequential sum
+                    R* dst = partial + job * 3ull;
+                    dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
+                }
+                const unsigned long long mine = wave_take_jobs(jm, lane, batch_next, batch_end, job_counter);
+                if (need_job) {
+                    job = mine;
+                    if (job >= n_jobs) {
+                        slot_done = true; // no jobs left: this slot retires
+                    } else {
+                        const RenderConsts rj = kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)); // cold: keep it out of the SGPRs
+                        const JobInfo ji = job_decode(rj, uint32_t(job));
+                        pxrow = ji.px | (ji.row << 16);
+                        smp = ji.s; smp_end = ji.s_end;
+                        job = ji.real ? (unsigned long long)ji.sum_index : ~0ull; // from here on: where the job's sum goes (none for padding)
+                        acc = V3<R>();
+                    }
+                }
+            }
+            if (need_sample && !slot_done) { // main.rs:212-215: the job's next sample
+                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), pxrow & 0xFFFFu, pxrow >> 16, smp);
+                pool_st(&pu[size_t(PU_KEY_LO) * n_slots], uint32_t(ps.key));
+                pool_st(&pu[size_t(PU_KEY_HI) * n_slots], uint32_t(ps.key >> 32));
+                pool_st(&pu[size_t(PU_PXROW) * n_slots], pxrow);
+                pool_st(&pu[size_t(PU_S) * n_slots], smp);
+                pool_st(&pu[size_t(PU_SEND) * n_slots], smp_end);
+                pool_st(&pu[size_t(PU_JOB_LO) * n_slots], uint32_t(job));
+                pool_st(&pu[size_t(PU_JOB_HI) * n_slots], uint32_t(job >> 32));
+                pool_st(&pr[size_t(PR_AX) * n_slots], acc.x); pool_st(&pr[size_t(PR_AY) * n_slots], acc.y); pool_st(&pr[size_t(PR_AZ) * n_slots], acc.z);
+                emit = true;
+            }
+            if constexpr (COUNT) c3 = clock64();
+            const unsigned long long em = __ballot(emit);
+            if (emit) { // the slot's next ray: path state back to memory, this lane into the hand-over's table
+                pool_st(&pr[size_t(PR_OX) * n_slots], ps.ray.o.x); pool_st(&pr[size_t(PR_OY) * n_slots], ps.ray.o.y); pool_st(&pr[size_t(PR_OZ) * n_slots], ps.ray.o.z);
+                pool_st(&pr[size_t(PR_DX) * n_slots], ps.ray.d.x); pool_st(&pr[size_t(PR_DY) * n_slots], ps.ray.d.y); pool_st(&pr[size_t(PR_DZ) * n_slots], ps.ray.d.z);
+                pool_st(&pr[size_t(PR_TIME) * n_slots], ps.ray.time);
+                pool_st(&pr[size_t(PR_TX) * n_slots], ps.throughput.x); pool_st(&pr[size_t(PR_TY) * n_slots], ps.throughput.y); pool_st(&pr[size_t(PR_TZ) * n_slots], ps.throughput.z);
+                pool_st(&pr[size_t(PR_LX) * n_slots], ps.radiance.x); pool_st(&pr[size_t(PR_LY) * n_slots], ps.radiance.y); pool_st(&pr[size_t(PR_LZ) * n_slots], ps.radiance.z);
+                pool_st(&pu[size_t(PU_BOUNCE) * n_slots], ps.bounce);
+                tbl[__popcll(em & lanes_below)] = uint16_t(lane);
+            }
+            const uint32_t n_emit = uint32_t(__popcll(em));
+            if (n_emit != 0u) {
+                __builtin_amdgcn_wave_barrier();
+                uint32_t given = 0;
+                { // first the lanes that have no ray: they start its walk here
+                    const bool want = !has_ray;
+                    const unsigned long long wm = __ballot(want);
+                    const uint32_t r = uint32_t(__popcll(wm & lanes_below));
+                    const bool take = want && r < n_emit;
+                    const uint32_t src = take ? uint32_t(tbl[r]) : lane;
+                    const Ray<R> got = lane_pull(ps.ray, src);
+                    const uint32_t got_slot = lane_pull(hslot, src);
+                    if (take) {
+                        wray = got; slot = got_slot; has_ray = true;
+                        cnt.ray();
+                        trav_begin(tr, sc, wray, stack);
+                    }
+                    const uint32_t wn = uint32_t(__popcll(wm));
+                    given = wn < n_emit ? wn : n_emit;
+                    if constexpr (COUNT) { dbg[11] += 1; dbg[12] += given; }
+                }
+                if (given < n_emit) { // the others become "next" rays
+                    const bool want = !has_next;
+                    const unsigned long long wm = __ballot(want);
+                    const uint32_t r = given + uint32_t(__popcll(wm & lanes_below));
+                    const bool take = want && r < n_emit;
+                    const uint32_t src = take ? uint32_t(tbl[r]) : lane;
+                    const Ray<R> got = lane_pull(ps.ray, src);
+                    const uint32_t got_slot = lane_pull(hslot, src);
+                    if (take) { nray = got; nslot = got_slot; has_next = true; }
+                }
+            }
+            if constexpr (COUNT) {
+                c4 = clock64();
+                if (lane == 0) { dbg[0] += uint32_t((c1 - c0) >> 4); dbg[1] += uint32_t((c2 - c1) >> 4); dbg[2] += uint32_t((c3 - c2) >> 4); dbg[3] += uint32_t((c4 - c3) >> 4); }
+            }
+            continue;
+        }
+
+        // ====================================================================== WALK until 64 hits are queued
+        if constexpr (COUNT) dbg[8] += 1;
+        long long w0 = 0;
+        if constexpr (COUNT) w0 = clock64();
+        for (;;) {
+            if (__ballot(has_ray) == 0ull) break;
+            if constexpr (COUNT) { dbg[13] += 1; dbg[14] += uint32_t(__popcll(__ballot(has_ray))); }
+            if (has_ray) {
+#pragma unroll
+                for (int k = 0; k < NODE_STEPS; ++k)
+                    if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
+                if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
+            }
+            const bool fin = has_ray && tr.node == TRAV_DONE;
+            const unsigned long long fm = __ballot(fin);
+            if (fm != 0ull) {
+                if (fin) { // the hit goes to the slot, the slot onto the queue, the lane on to its next ray
+                    const uint32_t idx = hit_n + uint32_t(__popcll(fm & lanes_below));
+                    const int32_t hprim = tr.found ? tr.best.prim : make_ref(PRIM_NONE, 0);
+                    if constexpr (HITS_LDS) {
+                        hq_t[idx] = tr.closest; hq_prim[idx] = hprim; hq_inst[idx] = tr.best.inst;
+                    } else {
+                        const size_t g = gbase + slot;
+                        pool_r[size_t(PR_HT) * n_slots + g] = tr.closest;
+                        pool_u[size_t(PU_HPRIM) * n_slots + g] = uint32_t(hprim);
+                        pool_u[size_t(PU_HINST) * n_slots + g] = uint32_t(tr.best.inst);
+                    }
+                    hq[idx] = uint16_t(slot | (uint32_t(tr.best.aux) << 8));
+                    has_ray = has_next;
+                    if (has_next) {
+                        wray = nray; slot = nslot; has_next = false;
+                        cnt.ray();
+                        trav_begin(tr, sc, wray, stack);
+                    }
+                }
+                hit_n += uint32_t(__popcll(fm));
+                if (hit_n >= 64u) break;
+            }
+        }
+        if constexpr (COUNT) {
+            if (lane == 0) dbg[4] += uint32_t((clock64() - w0) >> 4);
         }
     }
 
@@ -976,6 +1279,13 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     bool plain = s->flat.nodes4.size() < 32768; // (about 65536 nodes of the binary tree)
     if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
+    // RTTNW_KERNEL=stream: the LDS-node form of the decoupled loop (trace_kernel_stream; experiments: it reaches 0.41-0.44
+    // lane utilisation but is slower than the lane-owns-path form on every scene measured, profiles/r02/README.md)
+    constexpr int STREAM_BLOCK = sizeof(R) == 4 ? RT_F32_STREAM_BLOCK : RT_F64_BLOCK;
+    const uint32_t n4_all = uint32_t(s->flat.nodes4.size());
+    const bool stream_hits_lds = stream_form_bytes(n4_all, s->flat.stack_depth, STREAM_BLOCK, sizeof(R), true) <= 160 * 1024;
+    const bool streamf = kv && std::strcmp(kv, "stream") == 0 && stream_form_bytes(n4_all, s->flat.stack_depth, STREAM_BLOCK, sizeof(R), stream_hits_lds) <= 160 * 1024;
+    if (streamf) plain = false;
     HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
     DeviceCounters* dc = reinterpret_cast<DeviceCounters*>(d->job_counter + 1);
     auto persistent_grid = [&](const void* kernel, size_t lds_bytes, size_t waves_needed, size_t& grid) -> int {
@@ -1029,6 +1339,32 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                 int32_t* sp = (int32_t*)d->spill;
                 void* args[] = {&view, &camv, &rc, &bg0, &bg1, &bg2, &tmin, &part, &jc, &dc, &sp};
                 HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
+            }
+        } else if (streamf) {
+            const bool gen = s->flat.needs_general;
+            rc.lds_nodes = n4_all;
+            const int sel = (count ? 4 : 0) | (gen ? 2 : 0) | (stream_hits_lds ? 1 : 0);
+            typedef void (*StreamKernel)(SceneView<R>, CameraRec<R>, RenderConsts, R, R, R, R, R*, unsigned long long*, DeviceCounters*, R*, uint32_t*, uint32_t, int32_t*);
+            static const StreamKernel kernels[8] = {
+                trace_kernel_stream<R, false, STREAM_BLOCK, false, false>, trace_kernel_stream<R, false, STREAM_BLOCK, false, true>,
+                trace_kernel_stream<R, false, STREAM_BLOCK, true, false>,  trace_kernel_stream<R, false, STREAM_BLOCK, true, true>,
+                trace_kernel_stream<R, true, STREAM_BLOCK, false, false>,  trace_kernel_stream<R, true, STREAM_BLOCK, false, true>,
+                trace_kernel_stream<R, true, STREAM_BLOCK, true, false>,   trace_kernel_stream<R, true, STREAM_BLOCK, true, true>};
+            const StreamKernel kernel = kernels[sel];
+            const size_t lds_bytes = stream_form_bytes(n4_all, rc.stack_depth, STREAM_BLOCK, sizeof(R), stream_hits_lds);
+            HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+            constexpr size_t waves_per_block = STREAM_BLOCK / 64;
+            const size_t waves_needed = (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
+            const size_t grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus), (waves_needed + waves_per_block - 1) / waves_per_block));
+            const size_t n_slots = grid * waves_per_block * SLOTS_PER_WAVE;
+            if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
+            if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
+            if (int g = grow_spill(grid * size_t(STREAM_BLOCK))) return g;
+            if (n_jobs > 0) {
+                hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(STREAM_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
+                                   R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
+                                   (uint32_t*)d->pool_u, uint32_t(n_slots), (int32_t*)d->spill);
+                HIP_TRY(hipGetLastError());
             }
         } else {
             const bool gen = s->flat.needs_general;
@@ -1117,6 +1453,13 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                 const double w64 = double(stats->samples) / 64.0;
                 fprintf(stderr, "[decoupled] bursts/64smp %.1f  shades/64smp %.2f (lanes %.1f)  refills/64smp %.1f (lanes %.1f)\n", hc.dbg[8] / w64, hc.dbg[9] / w64,
                         hc.dbg[9] ? double(hc.dbg[10]) / hc.dbg[9] : 0.0, hc.dbg[11] / w64, hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
+                if (hc.dbg[13]) { // the stream form: its walk trips and the wave clock of its phases
+                    const double tot = double(hc.dbg[0] + hc.dbg[1] + hc.dbg[2] + hc.dbg[3] + hc.dbg[4]);
+                    fprintf(stderr, "[stream] trips/64smp %.1f, lanes walking per trip %.1f\n", hc.dbg[13] / w64, double(hc.dbg[14]) / hc.dbg[13]);
+                    fprintf(stderr, "[stream] wave clock: state load %.1f%%  path_shade %.1f%%  jobs + new paths %.1f%%  store + hand-over %.1f%%  walk %.1f%%;  per shade batch (clocks): %.0f %.0f %.0f %.0f, per trip %.0f\n",
+                            100 * hc.dbg[0] / tot, 100 * hc.dbg[1] / tot, 100 * hc.dbg[2] / tot, 100 * hc.dbg[3] / tot, 100 * hc.dbg[4] / tot, 16.0 * hc.dbg[0] / hc.dbg[9], 16.0 * hc.dbg[1] / hc.dbg[9],
+                            16.0 * hc.dbg[2] / hc.dbg[9], 16.0 * hc.dbg[3] / hc.dbg[9], 16.0 * hc.dbg[4] / hc.dbg[13]);
+                }
             }
         }
         stats->n_nodes = uint32_t(s->flat.nodes4.size());

@@ -74,6 +74,33 @@ RT_HD void rt_div2(double n1, double n2, double d, double& q1, double& q2) {
     q1 = n1 / d; q2 = n2 / d;
 #endif
 }
+// A divisor used more than once: its reciprocal kept beside it.  f32: v_rcp_f32, a quotient is one multiply (what rt_div
+// does).  f64 on the device: the refined reciprocal of rt_div2 and Markstein's corrected quotient, 3 FMA-rate
+// instructions per quotient instead of the 11-instruction IEEE sequence with its quarter-rate v_rcp_f64; the host build
+// divides.  A zero divisor gives NaN quotients where IEEE gives infinities: callers reject with tests NaN fails.
+template <typename R> struct Recip;
+template <> struct Recip<float> { float r; };
+template <> struct Recip<double> { double d, r; };
+RT_HD Recip<float> recip_of(float d) { return {rt_rcp(d)}; }
+RT_HD Recip<double> recip_of(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return {d, r};
+#else
+    return {d, 0.0};
+#endif
+}
+RT_HD float div_by(float n, const Recip<float>& k) { return n * k.r; }
+RT_HD double div_by(double n, const Recip<double>& k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double q = n * k.r;
+    return __builtin_fma(__builtin_fma(-k.d, q, n), k.r, q);
+#else
+    return n / k.d;
+#endif
+}
 
 template <typename R> struct Lim;
 template <> struct Lim<float> {
@@ -99,14 +126,18 @@ template <typename R> RT_HD V3<R> operator*(V3<R> a, V3<R> b) { return {a.x * b.
 template <typename R> RT_HD V3<R> operator*(V3<R> a, R k) { return {a.x * k, a.y * k, a.z * k}; }
 template <typename R> RT_HD V3<R> operator*(R k, V3<R> a) { return {a.x * k, a.y * k, a.z * k}; }
 template <typename R> RT_HD V3<R> operator/(V3<R> a, R k) {
-    if constexpr (sizeof(R) == 4) { const R inv = rt_rcp(k); return {a.x * inv, a.y * inv, a.z * inv}; }
-    else return {a.x / k, a.y / k, a.z / k};
+    const Recip<R> rk = recip_of(k); // (f32: three multiplies by v_rcp_f32(k), as before)
+    return {div_by(a.x, rk), div_by(a.y, rk), div_by(a.z, rk)};
 }
 template <typename R> RT_HD V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
 template <typename R> RT_HD R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // vec3.rs:77
 template <typename R> RT_HD R squared_length(V3<R> a) { return a.x * a.x + a.y * a.y + a.z * a.z; } // vec3.rs:93
 template <typename R> RT_HD R magnitude(V3<R> a) { return rt_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); } // vec3.rs:90
-template <typename R> RT_HD V3<R> unit(V3<R> a) { R k = R(1) / magnitude(a); return a * k; }          // vec3.rs:97
+template <typename R> RT_HD V3<R> unit(V3<R> a) {
+    R k;
+    if constexpr (sizeof(R) == 4) k = R(1) / magnitude(a); else k = rt_rcp(magnitude(a));
+    return a * k;
+}          // vec3.rs:97
 template <typename R> RT_HD V3<R> reflect(V3<R> v, V3<R> n) { return v - R(2) * dot(v, n) * n; }      // vec3.rs:112
 template <typename R> RT_HD V3<R> refract(V3<R> v, V3<R> n, R eta) {                                  // vec3.rs:116-121
     R cos_theta = rt_min(dot(-v, n), R(1));
@@ -352,22 +383,26 @@ template <typename R> RT_HD R sphere_discriminant(V3<R> oc, V3<R> d, R a, R half
 template <typename R>
 RT_HD bool sphere_t(V3<R> center, R radius, const Ray<R>& ray, R t_min, R t_max, R& t_out) {
     V3<R> oc = ray.o - center;
-    R a = dot(ray.d, ray.d);
+    // (the two roots share |d|^2's reciprocal.  Keeping it with the walk's ray instead — it is the same for every sphere the
+    // ray meets — cost the f64 kernels more in registers than the v_rcp_f64 it saved: final_scene f64 970 against 1002)
+    const R a = dot(ray.d, ray.d);
+    const Recip<R> inv_a = recip_of(a);
     R half_b = dot(oc, ray.d);
     R disc = sphere_discriminant(oc, ray.d, a, half_b, radius);
     if (disc < R(0)) return false;
     R sqrtd = rt_sqrt(disc);
-    R root = rt_div(-half_b - sqrtd, a);
-    if (root < t_min || t_max < root) {
-        root = rt_div(-half_b + sqrtd, a);
-        if (root < t_min || t_max < root) return false;
+    // (range tests written so that NaN — a zero direction — is out of range, like the infinities IEEE division gives there)
+    R root = div_by(-half_b - sqrtd, inv_a);
+    if (!(root >= t_min && t_max >= root)) {
+        root = div_by(-half_b + sqrtd, inv_a);
+        if (!(root >= t_min && t_max >= root)) return false;
     }
     t_out = root;
     return true;
 }
 // MovingSphere::center — hittable.rs:187-191
 template <typename R> RT_HD V3<R> moving_center(const MovingSphereRec<R>& m, R time) {
-    return V3<R>(m.c0) + ((time - m.t0) / (m.t1 - m.t0)) * (V3<R>(m.c1) - V3<R>(m.c0));
+    return V3<R>(m.c0) + rt_div(time - m.t0, m.t1 - m.t0) * (V3<R>(m.c1) - V3<R>(m.c0));
 }
 // Rectangle::hit — hittable.rs:503-513 (half-open extents, Q9).  plane: 0 XY, 1 XZ, 2 YZ.
 template <typename R>
@@ -792,8 +827,8 @@ template <typename R> RT_HD void sphere_uv(V3<R> p, R& u, R& v) { // hittable.rs
     const R pi = R(3.14159265358979323846264338327950288);
     R theta = rt_acos(-p.y);
     R phi = rt_atan2(-p.z, p.x) + pi;
-    u = phi / (R(2) * pi);
-    v = theta / pi;
+    u = div_by(phi, recip_of(R(2) * pi)); // (constant divisors: their reciprocals fold)
+    v = div_by(theta, recip_of(pi));
 }
 
 // The reference computes (u, v) for every hit (Sphere::uv's acos + atan2, the rectangles' two divisions; Q11), but only
@@ -828,8 +863,8 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         if (uv_is_read(r.mat)) {
             R a, b;
             rect_ab(r.plane, ray, t, a, b);
-            rec.u = (a - r.a0) / (r.a1 - r.a0);
-            rec.v = (b - r.b0) / (r.b1 - r.b0);
+            rec.u = rt_div(a - r.a0, r.a1 - r.a0);
+            rec.v = rt_div(b - r.b0, r.b1 - r.b0);
         }
         outward = V3<R>(r.plane == 2 ? R(1) : R(0), r.plane == 1 ? R(1) : R(0), r.plane == 0 ? R(1) : R(0));
         rec.p = ray.at(t);
@@ -843,8 +878,8 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
             rect_ab(plane, ray, t, a, b);
             R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
             R b0 = plane == 0 ? bx.mn[1] : bx.mn[2], b1 = plane == 0 ? bx.mx[1] : bx.mx[2];
-            rec.u = (a - a0) / (a1 - a0);
-            rec.v = (b - b0) / (b1 - b0);
+            rec.u = rt_div(a - a0, a1 - a0);
+            rec.v = rt_div(b - b0, b1 - b0);
         }
         outward = V3<R>(plane == 2 ? R(1) : R(0), plane == 1 ? R(1) : R(0), plane == 0 ? R(1) : R(0));
         rec.p = ray.at(t);
@@ -891,7 +926,8 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
             const R disc = sphere_discriminant(oc, bray.d, a, half_b, sp.r);
             if (disc < R(0)) continue;
             const R sqrtd = rt_sqrt(disc);
-            const R near_root = rt_div(-half_b - sqrtd, a), far_root = rt_div(-half_b + sqrtd, a);
+            R near_root, far_root;
+            rt_div2(-half_b - sqrtd, -half_b + sqrtd, a, near_root, far_root);
             t1 = near_root;
             if (t1 < -Lim<R>::inf() || Lim<R>::inf() < t1) {
                 t1 = far_root;
@@ -1058,7 +1094,7 @@ RT_HD V3<R> material_color(const SceneView<R>& sc, const MaterialRec<R>& m, cons
 RT_HD float schlick_pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
 RT_HD double schlick_pow5(double x) { double x2 = x * x; return x2 * x2 * x; }
 template <typename R> RT_HD R schlick(R cosine, R ri) { // material.rs:173-176
-    R r0 = (R(1) - ri) / (R(1) + ri);
+    R r0 = rt_div(R(1) - ri, R(1) + ri);
     r0 = r0 * r0;
     return r0 + (R(1) - r0) * schlick_pow5(R(1) - cosine);
 }
@@ -1131,8 +1167,8 @@ RT_HD void path_begin(PathState<R>& ps, const CameraRec<R>& cam, const RenderCon
     const uint64_t pixel = uint64_t(row) * rc.width + px;
     ps.key = sample_key(rc.seed, pixel, uint64_t(s) + rc.sample_begin);
     const uint32_t j = rc.height - 1 - row;
-    R u = (R(px) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_U))) / R(rc.width);
-    R v = (R(j) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_V))) / R(rc.height);
+    R u = rt_div(R(px) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_U)), R(rc.width));
+    R v = rt_div(R(j) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_V)), R(rc.height));
     ps.ray = camera_ray(cam, u, v, ps.key);
     ps.throughput = V3<R>(R(1), R(1), R(1));
     ps.radiance = V3<R>();

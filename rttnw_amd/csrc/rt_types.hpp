@@ -69,7 +69,10 @@ static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 constexpr uint32_t BVH4_USED_SIXTEENTHS = 7; // 16-byte pieces of a record that carry data (the LDS copy leaves the pad out)
 // Traversal stack: the first LDS_STACK_ENTRIES entries of a lane live in LDS, deeper ones (a 4-wide walk can have three
 // pending children per level, but rarely has) in a per-lane strip of global memory.
-constexpr uint32_t LDS_STACK_ENTRIES = 16;
+#ifndef RT_LDS_STACK_ENTRIES // (12 / 10 / 8 entries: final_scene f32 -0.4 / -1.5 / -2.5 %)
+#define RT_LDS_STACK_ENTRIES 16
+#endif
+constexpr uint32_t LDS_STACK_ENTRIES = RT_LDS_STACK_ENTRIES;
 // LDS bytes of the lane-owns-path kernel's resident form: node records (without their pad) + the lanes' stacks.
 inline size_t lds_form_bytes(uint32_t n_nodes4, uint32_t stack_depth, uint32_t block) {
     (void)stack_depth; // the LDS part of a stack has a fixed size (+ 1: the spare slot of the branch-free pushes)

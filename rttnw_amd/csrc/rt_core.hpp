@@ -55,6 +55,8 @@ RT_HD float rt_div(float a, float b) {
     return a / b;
 #endif
 }
+// (f64 single divisions stay IEEE: a v_rcp_f64 + Newton + Markstein form of ONE quotient was slower — final_scene f64 990
+// against 1000 Msamples/s, spheres_1m f64 239 against 254; the forms below pay where a divisor is shared)
 RT_HD double rt_div(double a, double b) { return a / b; }
 // Two quotients with ONE divisor: n1 / d and n2 / d.  f32 and the host: two divisions.  f64 on the device: the compiler's
 // IEEE division is an 11-instruction sequence around a quarter-rate v_rcp_f64, per quotient; here the reciprocal (v_rcp_f64

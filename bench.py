@@ -70,13 +70,21 @@ def committed_traffic(scene_name, precision_name):
     vals, sha = {}, None
     for line in open(pmc):
         f = line.split()
-        if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+        if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"):
             vals[f[0]] = float(f[1])
         if len(f) >= 2 and f[0] == "kernel_source_sha":
             sha = f[1]
-    if len(vals) != 2 or sha != kernel_source_sha():
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals or sha != kernel_source_sha():
         return None, None
+    global _committed_valu
+    if "SQ_INSTS_VALU" in vals and vals.get("SQ_ACTIVE_INST_VALU"):
+        _committed_valu[(scene_name, precision_name)] = {
+            "wave_instructions_per_launch": vals["SQ_INSTS_VALU"],
+            "lane_utilisation": round(vals.get("SQ_THREAD_CYCLES_VALU", 0.0) / (vals["SQ_ACTIVE_INST_VALU"] * 64.0), 3)}
     return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), "profiles/%s/%s" % (PROFILE_ROUND, os.path.basename(pmc))
+
+
+_committed_valu = {}   # (scene, precision) -> VALU counters of the same committed summary (filled by committed_traffic)
 
 
 def main():
@@ -199,8 +207,13 @@ def main():
         achieved = b_alg * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         pname = "f32" if prec == abi.F32 else "f64"
         traffic, traffic_src = (committed_traffic(scene_name, pname) if world == 1 and not args.spp and not args.size else (None, None))
+        valu = _committed_valu.get((scene_name, pname))
+        if valu is not None:   # the secondary bound of the LDS-resident scenes: what the vector ALUs did, from the same PMC summary
+            valu = dict(valu, wave_instructions_per_sample=round(valu["wave_instructions_per_launch"] / samples_rank, 1),
+                        note="SQ_INSTS_VALU of one launch and SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU): the kernel is bound by "
+                             "vector-instruction issue at this lane utilisation, not by memory")
         return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu": valu,
                 "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if form == 0 else "", "float" if prec == abi.F32 else "double"),
                 "kernel_ms": round(kernel_ms, 3), "alg_bytes_per_sample": round(b_alg, 2),
                 "alg_bytes_per_launch": round(b_alg * samples_rank),

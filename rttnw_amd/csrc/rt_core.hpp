@@ -839,7 +839,12 @@ RT_HD bool uv_is_read(int32_t mat_ref) { return (mat_ref & MAT_UV_FLAG) != 0; } 
 
 template <bool G, typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
-    const uint32_t kind = ref_kind(ref.prim), idx = ref_index(ref.prim);
+    const uint32_t kind = ref_kind(ref.prim);
+    uint32_t idx = ref_index(ref.prim);
+    if (kind == PRIM_SPHERE && ref.inst < 0) { // the world-space copy of a transformed group's sphere: its record is made in
+        const int32_t home = sc.sphere_mat[idx]; // object space through the group's chain, like the reference's (scene_lower.cpp)
+        if (home & MAT_HOME_FLAG) { idx = uint32_t(home) & MAT_HOME_SPHERE_MASK; ref.inst = (home >> MAT_HOME_INST_SHIFT) & MAT_HOME_INST_MAX; }
+    }
     Ray<R> ray = wray;
     if (ref.inst >= 0) ray = to_object<G>(sc.insts[ref.inst], wray);
     rec.t = t;

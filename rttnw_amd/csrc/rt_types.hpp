@@ -128,6 +128,11 @@ template <typename R> struct MediumRec {
 // (material, texture) just to find that out were 4 % of the f64 kernel.
 constexpr int32_t MAT_UV_FLAG = 1 << 30;
 constexpr int32_t MAT_INDEX_MASK = MAT_UV_FLAG - 1;
+// SceneView::sphere_mat only: MAT_HOME_FLAG marks the world-space copy of a sphere of a transformed group (scene_lower.cpp);
+// the entry then holds, instead of a material, the object-space sphere record and the transform chain its hit record is made from.
+constexpr int32_t MAT_HOME_FLAG = 1 << 29;
+constexpr int32_t MAT_HOME_INST_SHIFT = 20, MAT_HOME_INST_MAX = 511;
+constexpr uint32_t MAT_HOME_SPHERE_MASK = (1u << MAT_HOME_INST_SHIFT) - 1u, MAT_HOME_SPHERE_MAX = MAT_HOME_SPHERE_MASK;
 enum : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
 template <typename R> struct MaterialRec {
     int32_t type;

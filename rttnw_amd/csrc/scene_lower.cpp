@@ -104,7 +104,10 @@ struct Item {
     int32_t obj;    // graph object id (instances: index into FlatScene::insts)
     Box3 box;
     int32_t seq = 0; // position in the reference's depth-first traversal of the world List
+    int32_t world_copy = -1; // spheres only: index into Lowering::world_spheres (the record to emit is that world-space copy)
 };
+// A sphere of a rigidly transformed group, in world space (collect(), "spheres of transformed groups")
+struct WorldSphere { double c[3], r; int32_t home, inst; };
 
 struct Lowering {
     const SceneGraph& g;
@@ -157,8 +160,14 @@ struct Lowering {
         const GraphObj& o = g.objs[it.obj];
         switch (it.kind) {
         case PRIM_SPHERE: {
-            fs.spheres.push_back({o.v[0], o.v[1], o.v[2], o.v[3]});
-            fs.sphere_mat.push_back(mat_index[o.a]);
+            if (it.world_copy >= 0) {
+                const WorldSphere& w = world_spheres[it.world_copy];
+                fs.spheres.push_back({w.c[0], w.c[1], w.c[2], w.r});
+                fs.sphere_mat.push_back(MAT_HOME_FLAG | (w.inst << MAT_HOME_INST_SHIFT) | w.home); // not a material: where its record is made
+            } else {
+                fs.spheres.push_back({o.v[0], o.v[1], o.v[2], o.v[3]});
+                fs.sphere_mat.push_back(mat_index[o.a]);
+            }
             fs.sphere_seq.push_back(it.seq);
             return uint32_t(fs.spheres.size() - 1);
         }
@@ -391,6 +400,8 @@ struct Lowering {
     int nesting = 0; // recursion guard: a list that (transitively) contains itself
     std::vector<Item>* top_items = nullptr;
     uint32_t inst_need_dummy = 0;
+    std::vector<WorldSphere> world_spheres;
+    bool move_spheres = true;         // RTTNW_WORLD_SPHERES=0 keeps them in their groups' trees (experiments)
 
     bool append_ops(Chain& c, const InstanceRec<double>& in) {
         for (int i = 0; i < in.n_ops; ++i) {
@@ -446,7 +457,39 @@ struct Lowering {
             std::vector<Item> sub;
             collect(inner, sub, full);
             if (rc) return;
-            if (sub.empty()) break; // nothing but nested instances / media inside: they went to the top level themselves
+            // Spheres of transformed groups: Translate and YRotate are rigid (the forward half of YRotate::hit is a proper
+            // rotation, hittable.rs:687-694; quirk Q1 sits in the way BACK), so a sphere under them is a sphere in world space:
+            // centre carried through the chain, same radius, same t along the same ray.  The walk tests that world-space
+            // copy in the TOP tree — no ray transform, no second tree, one SAH build over everything (final_scene's 1000-sphere
+            // cluster) — and the hit record is still made the reference's way, in object space through the chain
+            // (make_record: SceneView::sphere_home leads from the copy to the object-space record and the chain).
+            const int32_t inst_index = int32_t(fs.insts.size()); // of the record pushed below
+            bool moved = false;
+            if (move_spheres) {
+                std::vector<Item> keep;
+                for (const Item& it : sub) {
+                    // (the copy's material slot holds where its record is made: 20 bits of sphere index, 9 of chain index)
+                    if (it.kind != PRIM_SPHERE || inst_index > MAT_HOME_INST_MAX || fs.spheres.size() >= MAT_HOME_SPHERE_MAX) { keep.push_back(it); continue; }
+                    const GraphObj& so = g.objs[it.obj];
+                    WorldSphere w{{so.v[0], so.v[1], so.v[2]}, so.v[3], int32_t(emit(it)), inst_index};
+                    to_world(in, w.c);
+                    Box3 wb;
+                    for (int k = 0; k < 3; ++k) { // (+ the rounding of the carried centre)
+                        const double pad = std::fabs(w.r) + 1e-9 * std::max(1.0, std::fabs(w.c[k]) + std::fabs(w.r));
+                        wb.lo[k] = w.c[k] - pad; wb.hi[k] = w.c[k] + pad;
+                    }
+                    world_spheres.push_back(w);
+                    Item copy{PRIM_SPHERE, it.obj, wb, it.seq};
+                    copy.world_copy = int32_t(world_spheres.size() - 1);
+                    top_items->push_back(copy);
+                    moved = true;
+                }
+                sub.swap(keep);
+            }
+            if (sub.empty()) {
+                if (moved) { in.root = -1; in.single_leaf = 0; fs.insts.push_back(in); } // the chain alone: the moved spheres' records go through it
+                break; // (else: nothing but nested instances / media inside: they went to the top level themselves)
+            }
             uint32_t depth = 0;
             Box3 ob;
             in.root = build_root(sub, depth, ob);
@@ -621,6 +664,7 @@ struct Lowering {
     int run() {
         if (g.world < 0 || g.objs[g.world].kind != GraphObj::LIST_K) return fail(-2, "commit: world not set");
         lower_textures_materials();
+        if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
         std::vector<Item> top;
         top_items = &top;
         collect(g.world, top, Chain{});

@@ -15,8 +15,15 @@ from oracle import rto
 from rttnw_amd import abi
 
 
+@pytest.mark.parametrize("world_spheres", [0, 1], ids=["spheres_in_groups", "spheres_in_world_space"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_core_f64_equals_golden(hostsim, scenes_lib, earth, case):
+def test_core_f64_equals_golden(hostsim, scenes_lib, earth, case, world_spheres, monkeypatch):
+    """The host build of the tracing core against the oracle's golden images.  With the spheres of transformed groups left
+    in their groups' trees (RTTNW_WORLD_SPHERES=0) the core does the oracle's arithmetic: equal to rounding.  By default
+    the lowering tests those spheres in world space (scene_lower.cpp): t is the root of the same quadratic written in
+    another frame, a last-place difference that a few bounces off small spheres amplify — the T1 bar of the device tests
+    (1e-9 on >= 99.9 % of the pixels) applies."""
+    monkeypatch.setenv("RTTNW_WORLD_SPHERES", str(world_spheres))
     key, name, w, h, spp, chunk, param = case
     sc, setup = util.build(hostsim, scenes_lib, name, earth, param)
     cam, p = util.params_for(setup, w, h, spp, spp_chunk=chunk, precision=abi.F64)
@@ -28,8 +35,10 @@ def test_core_f64_equals_golden(hostsim, scenes_lib, earth, case):
     assert hostsim.lib.hostsim_max_stack() <= dims[7], (key, dims[7])
     g = load()[key + "_linear"]
     d = np.abs(lin - g)
-    # recursion (oracle) vs throughput loop (core) differ by rounding only
-    assert d.max() <= 1e-12 * max(1.0, g.max()), (key, d.max())
+    if world_spheres:
+        assert (d.max(axis=2) <= 1e-9).mean() >= 0.999, (key, d.max())
+    else:  # recursion (oracle) vs throughput loop (core) differ by rounding only
+        assert d.max() <= 1e-12 * max(1.0, g.max()), (key, d.max())
 
 
 def test_core_counts_match_oracle_rays(hostsim, oracle, scenes_lib, earth):
@@ -78,7 +87,9 @@ def test_lowering_shapes(hostsim, scenes_lib, earth):
     sc, _ = util.build(hostsim, scenes_lib, "final_scene", earth)
     hostsim.lib.hostsim_scene_dims(sc.handle, dims)
     nodes, sph, mov, rect, box, inst, media, stack = list(dims)
-    assert (sph, mov, rect, box, inst, media) == (1007, 1, 1, 400, 1, 2)        # 1000 + 5 free + 2 boundaries
+    # 1000 cluster spheres + their 1000 world-space copies (what the walk tests) + 5 free + 2 boundaries; the cluster's
+    # chain stays as an instance record without a tree
+    assert (sph, mov, rect, box, inst, media) == (2007, 1, 1, 400, 1, 2)
     assert nodes < 1500 and stack <= 40
     sc, _ = util.build(hostsim, scenes_lib, "smoke_cornell_box")
     hostsim.lib.hostsim_scene_dims(sc.handle, dims)

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(BLOCK, 1) void trace_kernel_stream(SceneView<R> sc,
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typename CounterSel<COUNT, GENERAL>::type cnt;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    constexpr int NODE_STEPS = sizeof(R) == 8 ? RT_NODE_STEPS + 1 : RT_NODE_STEPS; // the trips of closest_solid()
+    constexpr int NODE_STEPS = RT_NODE_STEPS; // the trips of closest_solid()
     LdsStackNodes<BLOCK> stack;
     stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * BLOCK + threadIdx.x));
     stack.spill_stride = gridDim.x * BLOCK;

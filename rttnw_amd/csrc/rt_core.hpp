@@ -801,8 +801,9 @@ RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R&
         // step halves the trips of node-heavy walks and with them the executions of the (wide, poorly filled) leaf
         // code.  Measured, node steps per trip 1 / 2 / 3 / 4: final_scene 1288 / 1368 / 1357 / 1356 Msamples/s,
         // cornell_box 1707 / 1718 / 1665 / 1691.
-        // (f64: three node steps per trip — its leaf step, f64 primitive tests, is the dearer one: 968 -> 976 Msamples/s)
-        constexpr int node_steps = sizeof(R) == 8 ? RT_NODE_STEPS + 1 : RT_NODE_STEPS;
+        // (re-measured with the spheres of transformed groups in the top tree, node steps per trip 1 / 2 / 3: final_scene f32
+        // 1605 / 1632 / 1562, f64 - / 1058 / 1037; cornell_box f32 1893 / 2040 / 2066, f64 - / 1359 / 1370)
+        constexpr int node_steps = RT_NODE_STEPS;
 #pragma unroll
         for (int k = 0; k < node_steps; ++k)
             if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);

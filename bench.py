@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the timing of the other precision's kernels")
     ap.add_argument("--spp-chunk", type=int, default=0, help="samples per work item (0 = the library's tapered schedule)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder at commit: host binned SAH (default) or device LBVH")
+    ap.add_argument("--share", default=None, metavar="R/W",
+                    help="trace ONE rank's share (rank R of a W-way partition) of the N = W workload on this GPU, no gather: "
+                         "what each GPU of a W-GPU run does (not a bench line for the driver)")
     args = ap.parse_args()
 
     import numpy as np
@@ -114,12 +117,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    share = None
+    if args.share:
+        share = tuple(int(x) for x in args.share.split("/"))
+        rank, world = share
+    elif world != args.gpus:
         log("bench: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     # RTTNW_BENCH_FORCE_DIST=1: take the torch.distributed code path with a single rank too (checks the launch plumbing
     # on a 1-GPU box; the numbers are the same)
-    use_dist = world > 1 or os.environ.get("RTTNW_BENCH_FORCE_DIST") == "1"
+    use_dist = (world > 1 or os.environ.get("RTTNW_BENCH_FORCE_DIST") == "1") and share is None
     if use_dist:
         import torch.distributed as dist
         # RCCL prints its version banner on stdout when NCCL_DEBUG=VERSION is set (it is, on the GPU boxes): keep stdout
@@ -175,7 +182,7 @@ def main():
         cam_t, p = util.params_for(setup, W, H, spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, spp_chunk=args.spp_chunk)
         r = render.DeviceRenderer(sc, cam_t, p)
         for _ in range(warmup):
-            r.step()
+            r.trace() if share is not None else r.step()
         st = abi.Stats()
         kms = []
         if use_dist:
@@ -185,7 +192,8 @@ def main():
         for _ in range(steps):
             r.trace(st)             # rttnw_stats.kernel_ms: hipEvents around the trace kernel launch(es) on their own stream
             kms.append(st.kernel_ms)
-            r.collect()
+            if share is None:
+                r.collect()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -201,6 +209,8 @@ def main():
 
     samples_total = float(W) * H * spp          # all ranks together
     samples_rank = samples_total / world
+    if share is not None:
+        samples_total = samples_rank            # --share: this rank's rate
 
     def roofline(prec, kernel_ms):
         b_alg, per, form = counted(prec)
@@ -255,15 +265,16 @@ def main():
                "sample": "%s %dx%d spp=%d (%.1f s), f64 CPU oracle (reference-shaped: list scan + reference BVH builder)"
                          % (scene_name, W, H, cspp, dt)}
 
-    if rank == 0:
+    if rank == 0 or share is not None:
         out = {
             "metric": "Msamples/sec on final_scene 800x800 spp=1000; achieved HBM GB/s vs peak",
-            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": 1 if share is not None else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s %dx%d spp=%d%s" % (scene_name, W, H, spp, " (spp = %d x %d GPUs)" % (spp1, world) if world > 1 else ""),
                        "max_depth": 50, "scene_seed": "0x5eed0001", "render_seed": 1, "quirks": "reference",
-                       "partition": "8x8 tiles interleaved over %d rank(s), RCCL gather to rank 0" % world,
+                       "partition": ("8x8 tiles interleaved over %d rank(s), RCCL gather to rank 0" % world) if share is None else
+                                    ("--share: rank %d of %d only, on one GPU, no gather; value = this rank's rate" % (rank, world)),
                        "scene_nodes": info.n_nodes, "scene_prims": info.n_prims, "scene_bytes_f32": info.scene_bytes,
                        "scene_build_s": round(build_s, 3), "bvh_builder": args.bvh, "bvh_lower_ms": round(binfo.lower_ms, 2),
                        "bvh_device_ms": round(binfo.device_ms, 3), "stack_depth": binfo.stack_depth},

@@ -28,8 +28,13 @@ def nested_transforms(sc):
     deep = sc.cube((-15, 0, -15), (15, 50, 15), sc.lambertian((0.2, 0.7, 0.3)))
     for k in range(5):                                                                              # five wrappers
         deep = sc.rotate_y(deep, 8.0 + k) if k % 2 else sc.translate(deep, (25.0, 2.0 * k, -12.0))
+    # ... and a sphere under five wrappers: the lowering tests it in world space and makes its record through the whole chain
+    deep_ball = sc.sphere((5, 25, -8), 22.0, sc.metal((0.7, 0.6, 0.5), 0.0))
+    for k in range(5):
+        deep_ball = sc.rotate_y(deep_ball, -11.0 - 3 * k) if k % 2 == 0 else sc.translate(deep_ball, (-18.0, 3.0 * k, 14.0))
     sc.push(world, group)
     sc.push(world, deep)
+    sc.push(world, deep_ball)
     return world
 
 

@@ -401,18 +401,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 // rays to the lanes by ds_bpermute: first to the lanes that have none, then as "next" rays.  128 slots = 64 + 64 register
 // places + what is queued, so every ray finds a place.  Same per-path steps, same keyed draws, same job sums as the
 // other forms: the images are bit-identical (tests/test_gpu_parity.py::test_kernel_forms_agree).
-#ifndef RT_F32_STREAM_BLOCK
-#define RT_F32_STREAM_BLOCK 1024
-#endif
 // per wave: [hit queue's t, primitive, instance when HITS_LDS] + its slot | FRESH | face << 8 entries + the hand-over's lane table
 inline constexpr uint32_t stream_wave_bytes(uint32_t real_bytes, bool hits_lds) { return (hits_lds ? QCAP * (real_bytes + 8u) : 0u) + QCAP * 2u + 64u * 2u; }
 inline size_t stream_form_bytes(uint32_t n_nodes4, uint32_t stack_depth, uint32_t block, uint32_t real_bytes, bool hits_lds) {
     return lds_form_bytes(n_nodes4, stack_depth, block) + size_t(block / 64u) * stream_wave_bytes(real_bytes, hits_lds);
 }
-// (path state is read and written with ordinary accesses: non-temporal ones, and agent-scope ones that bypass the vector
-// cache, were both slower: final_scene f32 1187 and 1271 against 1329 Msamples/s)
-template <typename T> __device__ __forceinline__ T pool_ld(const T* p) { return *p; }
-template <typename T> __device__ __forceinline__ void pool_st(T* p, T v) { *p = v; }
+// (Path state is read and written with ordinary accesses: non-temporal ones, and agent-scope ones that bypass the vector
+// cache, were both slower: final_scene f32 1187 and 1271 against 1329 Msamples/s.)
 __device__ __forceinline__ float lane_pull(float v, uint32_t src_lane) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(int(src_lane << 2), __float_as_int(v)));
 }
@@ -510,21 +505,21 @@ __global__ __launch_bounds__(BLOCK, 1) void trace_kernel_stream(SceneView<R> sc,
             unsigned long long job = ~0ull;
             V3<R> acc;
             if (on && !fresh) {
-                ps.ray.o = V3<R>(pool_ld(&pr[size_t(PR_OX) * n_slots]), pool_ld(&pr[size_t(PR_OY) * n_slots]), pool_ld(&pr[size_t(PR_OZ) * n_slots]));
-                ps.ray.d = V3<R>(pool_ld(&pr[size_t(PR_DX) * n_slots]), pool_ld(&pr[size_t(PR_DY) * n_slots]), pool_ld(&pr[size_t(PR_DZ) * n_slots]));
-                ps.ray.time = pool_ld(&pr[size_t(PR_TIME) * n_slots]);
-                ps.throughput = V3<R>(pool_ld(&pr[size_t(PR_TX) * n_slots]), pool_ld(&pr[size_t(PR_TY) * n_slots]), pool_ld(&pr[size_t(PR_TZ) * n_slots]));
-                ps.radiance = V3<R>(pool_ld(&pr[size_t(PR_LX) * n_slots]), pool_ld(&pr[size_t(PR_LY) * n_slots]), pool_ld(&pr[size_t(PR_LZ) * n_slots]));
-                ps.key = (unsigned long long)pool_ld(&pu[size_t(PU_KEY_LO) * n_slots]) | ((unsigned long long)pool_ld(&pu[size_t(PU_KEY_HI) * n_slots]) << 32);
-                ps.bounce = pool_ld(&pu[size_t(PU_BOUNCE) * n_slots]);
+                ps.ray.o = V3<R>(pr[size_t(PR_OX) * n_slots], pr[size_t(PR_OY) * n_slots], pr[size_t(PR_OZ) * n_slots]);
+                ps.ray.d = V3<R>(pr[size_t(PR_DX) * n_slots], pr[size_t(PR_DY) * n_slots], pr[size_t(PR_DZ) * n_slots]);
+                ps.ray.time = pr[size_t(PR_TIME) * n_slots];
+                ps.throughput = V3<R>(pr[size_t(PR_TX) * n_slots], pr[size_t(PR_TY) * n_slots], pr[size_t(PR_TZ) * n_slots]);
+                ps.radiance = V3<R>(pr[size_t(PR_LX) * n_slots], pr[size_t(PR_LY) * n_slots], pr[size_t(PR_LZ) * n_slots]);
+                ps.key = (unsigned long long)pu[size_t(PU_KEY_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_KEY_HI) * n_slots] << 32);
+                ps.bounce = pu[size_t(PU_BOUNCE) * n_slots];
                 HitRef best;
                 R hit_t;
                 if constexpr (HITS_LDS) {
                     hit_t = hq_t[e]; best.prim = hq_prim[e]; best.inst = hq_inst[e];
                 } else {
-                    hit_t = pool_ld(&pr[size_t(PR_HT) * n_slots]);
-                    best.prim = int32_t(pool_ld(&pu[size_t(PU_HPRIM) * n_slots]));
-                    best.inst = int32_t(pool_ld(&pu[size_t(PU_HINST) * n_slots]));
+                    hit_t = pr[size_t(PR_HT) * n_slots];
+                    best.prim = int32_t(pu[size_t(PU_HPRIM) * n_slots]);
+                    best.inst = int32_t(pu[size_t(PU_HINST) * n_slots]);
                 }
                 best.aux = int32_t((meta >> 8) & 7u);
                 const bool found = ref_kind(best.prim) != PRIM_NONE;
@@ -533,11 +528,11 @@ __global__ __launch_bounds__(BLOCK, 1) void trace_kernel_stream(SceneView<R> sc,
                                found, hit_t, best, cnt)) {
                     emit = true; // next world.hit of the same path
                 } else {         // main.rs:216: acc + color(...)
-                    pxrow = pool_ld(&pu[size_t(PU_PXROW) * n_slots]);
-                    smp = pool_ld(&pu[size_t(PU_S) * n_slots]);
-                    smp_end = pool_ld(&pu[size_t(PU_SEND) * n_slots]);
-                    job = (unsigned long long)pool_ld(&pu[size_t(PU_JOB_LO) * n_slots]) | ((unsigned long long)pool_ld(&pu[size_t(PU_JOB_HI) * n_slots]) << 32);
-                    acc = V3<R>(pool_ld(&pr[size_t(PR_AX) * n_slots]), pool_ld(&pr[size_t(PR_AY) * n_slots]), pool_ld(&pr[size_t(PR_AZ) * n_slots])) + ps.radiance;
+                    pxrow = pu[size_t(PU_PXROW) * n_slots];
+                    smp = pu[size_t(PU_S) * n_slots];
+                    smp_end = pu[size_t(PU_SEND) * n_slots];
+                    job = (unsigned long long)pu[size_t(PU_JOB_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_JOB_HI) * n_slots] << 32);
+                    acc = V3<R>(pr[size_t(PR_AX) * n_slots], pr[size_t(PR_AY) * n_slots], pr[size_t(PR_AZ) * n_slots]) + ps.radiance;
                     ++smp;
                     need_sample = true;
                 }
@@ -572,25 +567,25 @@ __global__ __launch_bounds__(BLOCK, 1) void trace_kernel_stream(SceneView<R> sc,
             }
             if (need_sample && !slot_done) { // main.rs:212-215: the job's next sample
                 path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), pxrow & 0xFFFFu, pxrow >> 16, smp);
-                pool_st(&pu[size_t(PU_KEY_LO) * n_slots], uint32_t(ps.key));
-                pool_st(&pu[size_t(PU_KEY_HI) * n_slots], uint32_t(ps.key >> 32));
-                pool_st(&pu[size_t(PU_PXROW) * n_slots], pxrow);
-                pool_st(&pu[size_t(PU_S) * n_slots], smp);
-                pool_st(&pu[size_t(PU_SEND) * n_slots], smp_end);
-                pool_st(&pu[size_t(PU_JOB_LO) * n_slots], uint32_t(job));
-                pool_st(&pu[size_t(PU_JOB_HI) * n_slots], uint32_t(job >> 32));
-                pool_st(&pr[size_t(PR_AX) * n_slots], acc.x); pool_st(&pr[size_t(PR_AY) * n_slots], acc.y); pool_st(&pr[size_t(PR_AZ) * n_slots], acc.z);
+                pu[size_t(PU_KEY_LO) * n_slots] = uint32_t(ps.key);
+                pu[size_t(PU_KEY_HI) * n_slots] = uint32_t(ps.key >> 32);
+                pu[size_t(PU_PXROW) * n_slots] = pxrow;
+                pu[size_t(PU_S) * n_slots] = smp;
+                pu[size_t(PU_SEND) * n_slots] = smp_end;
+                pu[size_t(PU_JOB_LO) * n_slots] = uint32_t(job);
+                pu[size_t(PU_JOB_HI) * n_slots] = uint32_t(job >> 32);
+                pr[size_t(PR_AX) * n_slots] = acc.x; pr[size_t(PR_AY) * n_slots] = acc.y; pr[size_t(PR_AZ) * n_slots] = acc.z;
                 emit = true;
             }
             if constexpr (COUNT) c3 = clock64();
             const unsigned long long em = __ballot(emit);
             if (emit) { // the slot's next ray: path state back to memory, this lane into the hand-over's table
-                pool_st(&pr[size_t(PR_OX) * n_slots], ps.ray.o.x); pool_st(&pr[size_t(PR_OY) * n_slots], ps.ray.o.y); pool_st(&pr[size_t(PR_OZ) * n_slots], ps.ray.o.z);
-                pool_st(&pr[size_t(PR_DX) * n_slots], ps.ray.d.x); pool_st(&pr[size_t(PR_DY) * n_slots], ps.ray.d.y); pool_st(&pr[size_t(PR_DZ) * n_slots], ps.ray.d.z);
-                pool_st(&pr[size_t(PR_TIME) * n_slots], ps.ray.time);
-                pool_st(&pr[size_t(PR_TX) * n_slots], ps.throughput.x); pool_st(&pr[size_t(PR_TY) * n_slots], ps.throughput.y); pool_st(&pr[size_t(PR_TZ) * n_slots], ps.throughput.z);
-                pool_st(&pr[size_t(PR_LX) * n_slots], ps.radiance.x); pool_st(&pr[size_t(PR_LY) * n_slots], ps.radiance.y); pool_st(&pr[size_t(PR_LZ) * n_slots], ps.radiance.z);
-                pool_st(&pu[size_t(PU_BOUNCE) * n_slots], ps.bounce);
+                pr[size_t(PR_OX) * n_slots] = ps.ray.o.x; pr[size_t(PR_OY) * n_slots] = ps.ray.o.y; pr[size_t(PR_OZ) * n_slots] = ps.ray.o.z;
+                pr[size_t(PR_DX) * n_slots] = ps.ray.d.x; pr[size_t(PR_DY) * n_slots] = ps.ray.d.y; pr[size_t(PR_DZ) * n_slots] = ps.ray.d.z;
+                pr[size_t(PR_TIME) * n_slots] = ps.ray.time;
+                pr[size_t(PR_TX) * n_slots] = ps.throughput.x; pr[size_t(PR_TY) * n_slots] = ps.throughput.y; pr[size_t(PR_TZ) * n_slots] = ps.throughput.z;
+                pr[size_t(PR_LX) * n_slots] = ps.radiance.x; pr[size_t(PR_LY) * n_slots] = ps.radiance.y; pr[size_t(PR_LZ) * n_slots] = ps.radiance.z;
+                pu[size_t(PU_BOUNCE) * n_slots] = ps.bounce;
                 tbl[__popcll(em & lanes_below)] = uint16_t(lane);
             }
             const uint32_t n_emit = uint32_t(__popcll(em));

@@ -119,6 +119,9 @@ struct Lowering {
     size_t max_leaf = 4; // records per leaf of the host SAH build (lower_scene picks it)
     double time0 = 0.0, time1 = 1.0; // shutter interval the moving spheres' boxes must cover
 
+    Lowering(const SceneGraph& graph, FlatScene& flat, std::string& error, const BvhBuilder* bvh_builder, size_t leaf_records, double t0, double t1)
+        : g(graph), fs(flat), err(error), builder(bvh_builder), max_leaf(leaf_records), time0(t0), time1(t1) {}
+
     int fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return code; }
 
     // ---- bounds of leaf objects (Sphere :125-130, MovingSphere :233-244 over shutter 0..1,
@@ -399,7 +402,6 @@ struct Lowering {
     int32_t next_seq = 0;
     int nesting = 0; // recursion guard: a list that (transitively) contains itself
     std::vector<Item>* top_items = nullptr;
-    uint32_t inst_need_dummy = 0;
     std::vector<WorldSphere> world_spheres;
     bool move_spheres = true;         // RTTNW_WORLD_SPHERES=0 keeps them in their groups' trees (experiments)
 
@@ -714,7 +716,7 @@ int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const Bvh
         if (!small && max_leaf != 4) continue;
         out = FlatScene();
         out.time0 = time0; out.time1 = time1;
-        Lowering lw{g, out, err, {}, {}, 0, builder, max_leaf, time0, time1};
+        Lowering lw(g, out, err, builder, max_leaf, time0, time1);
         const int rc = lw.run();
         if (rc != 0 || max_leaf == 4 || fits_lds_form(out)) return rc;
     }

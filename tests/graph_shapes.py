@@ -70,8 +70,20 @@ def wide_shutter(sc):
     return world
 
 
+def many_moved_spheres(sc):
+    """600 spheres, each under its own rotate_y + translate: more transform chains than the 512 a world-space sphere copy can
+    name (rt_types.hpp MAT_HOME_INST_MAX) — the first 512 are tested in world space, the others stay instances."""
+    world, white = _room(sc)
+    mats = [sc.lambertian((0.8, 0.3, 0.2)), sc.metal((0.7, 0.7, 0.8), 0.1), white]
+    for k in range(600):
+        i, j = k % 30, k // 30
+        ball = sc.sphere((0.0, 0.0, 0.0), 4.5, mats[k % 3])
+        sc.push(world, sc.translate(sc.rotate_y(ball, 7.0 * k), (-145.0 + 10.0 * i, 20.0 + 9.0 * j, -60.0 + 4.0 * ((i + j) % 7))))
+    return world
+
+
 SHAPES = {"nested_transforms": nested_transforms, "medium_in_group": medium_in_group, "list_boundaries": list_boundaries,
-          "wide_shutter": wide_shutter}
+          "wide_shutter": wide_shutter, "many_moved_spheres": many_moved_spheres}
 
 
 def build(binding, shape, w=56, h=40, spp=6, precision=abi.F64, seed=13):

@@ -94,6 +94,11 @@ def test_lowering_shapes(hostsim, scenes_lib, earth):
     sc, _ = util.build(hostsim, scenes_lib, "smoke_cornell_box")
     hostsim.lib.hostsim_scene_dims(sc.handle, dims)
     assert list(dims)[3:7] == [6, 2, 2, 2]                                       # box boundaries under rotate+translate
+    import graph_shapes
+    sc, _, _ = graph_shapes.build(hostsim, "many_moved_spheres")
+    hostsim.lib.hostsim_scene_dims(sc.handle, dims)
+    nodes, sph, mov, rect, box, inst, media, stack = list(dims)
+    assert (sph, inst) == (600 + 512, 600)       # 512 chains can be named by a world-space copy; the other 88 spheres stay instances
 
 
 def test_unsupported_graphs_are_rejected(hostsim):

@@ -242,7 +242,7 @@ struct Lowering {
         const bool can_leaf = same_kind && groupable(items[lo].kind) && n <= max_leaf;
 
         // best binned split
-        constexpr int NB = 16;
+        constexpr int NB = 32; // (16 / 32 / 64 / 256 bins: 38.9 / 37.9 / 38.1 / 38.0 node visits per sample on final_scene; 32: +1 % there)
         double best_cost = std::numeric_limits<double>::infinity();
         int best_axis = -1, best_bin = -1;
         for (int ax = 0; ax < 3; ++ax) {
@@ -631,8 +631,8 @@ struct Lowering {
         while (n < 4) {
             int pick = -1;
             double best = -1.0;
-            for (int i = 0; i < n; ++i)
-                if (slots[i].child >= 0 && slot_area(slots[i]) > best) { best = slot_area(slots[i]); pick = i; }
+            for (int i = 0; i < n; ++i) // (picking by the area the expansion saves instead — area minus the children's — is far worse:
+                if (slots[i].child >= 0 && slot_area(slots[i]) > best) { best = slot_area(slots[i]); pick = i; } // 6.1 trips per walk against 4.2)
             if (pick < 0) break;
             const BvhNode inner = fs.nodes[slots[pick].child];
             for (int i = pick; i + 1 < n; ++i) slots[i] = slots[i + 1]; // keep the order of the others

@@ -216,8 +216,10 @@ def main():
         b_alg, per, form = counted(prec)
         achieved = b_alg * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         pname = "f32" if prec == abi.F32 else "f64"
-        traffic, traffic_src = (committed_traffic(scene_name, pname) if world == 1 and not args.spp and not args.size else (None, None))
-        valu = _committed_valu.get((scene_name, pname))
+        # (the committed PMC summaries are of the default configuration: whole frame on one GPU, host SAH trees, default schedule)
+        default_run = world == 1 and share is None and not args.spp and not args.size and not args.spp_chunk and args.bvh == "sah"
+        traffic, traffic_src = committed_traffic(scene_name, pname) if default_run else (None, None)
+        valu = _committed_valu.get((scene_name, pname)) if default_run else None
         if valu is not None:   # the secondary bound of the LDS-resident scenes: what the vector ALUs did, from the same PMC summary
             valu = dict(valu, wave_instructions_per_sample=round(valu["wave_instructions_per_launch"] / samples_rank, 1),
                         note="SQ_INSTS_VALU of one launch and SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU): the kernel is bound by "

@@ -1271,7 +1271,9 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     // scenes (cornell_box, final_scene: <= ~1k nodes), the decoupled form on deep BVHs where traversal lengths vary
     // most (1M spheres).  RTTNW_KERNEL=plain|wave overrides the choice (experiments only).
     const char* kv = getenv("RTTNW_KERNEL");
-    bool plain = s->flat.nodes4.size() < 32768; // (about 65536 nodes of the binary tree)
+    // (crossover measured on spheres_1m-like scenes of 2e4 - 2.5e5 spheres, 512x512 spp 256: f32 at ~24 k 4-wide nodes — 19.6 k:
+    // 3105 against 2972 Msamples/s, 28.3 k: 2258 against 2452 — f64 at ~50 k — 28.3 k: 2022 against 1740, 50.9 k: 1284 against 1318)
+    bool plain = s->flat.nodes4.size() < (sizeof(R) == 4 ? 24576u : 49152u);
     if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     // RTTNW_KERNEL=stream: the LDS-node form of the decoupled loop (trace_kernel_stream; experiments: it reaches 0.41-0.44

@@ -234,7 +234,8 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
 
 
 def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):
-    """>= 65 536 nodes selects the decoupled kernel by itself; it must agree with the forced lane-owns-path form."""
+    """A scene beyond the measured crossover (24 576 four-wide nodes in f32, 49 152 in f64) selects the decoupled kernel by itself; it
+    must agree with the forced lane-owns-path form."""
     sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=150000)
     cam, p = util.params_for(setup, 64, 64, 4, precision=abi.F32, seed=3)
     lin, rgba, st = gpu_render(gpu, sc, cam, p)

@@ -14,6 +14,9 @@
 // the root is node 0 before and after the re-numbering.
 #include "bvh_build.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <string.h> // rocprim/iterator/texture_cache_iterator.hpp calls memset unqualified
 #include <rocprim/rocprim.hpp>
@@ -169,6 +172,9 @@ int lbvh_build_device(const std::vector<BuildPrim>& prims, std::vector<BvhNode>&
     const size_t n = prims.size();
     if (n < 2 || n >= (size_t(1) << 26)) { err = "lbvh_build: needs 2 .. 2^26-1 leaves"; return -1; }
     int rc = 0;
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto wall_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(); };
+    double t_alloc = 0, t_up = 0, t_kernels = 0;
     // centroid bounds on the host (the leaves come from the host anyway)
     float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (const BuildPrim& p : prims)
@@ -215,7 +221,9 @@ int lbvh_build_device(const std::vector<BuildPrim>& prims, std::vector<BvhNode>&
         LBVH_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
         LBVH_TRY(hipEventCreate(&e0));
         LBVH_TRY(hipEventCreate(&e1));
+        t_alloc = wall_ms();
         LBVH_TRY(hipMemcpy(d_prims, prims.data(), n * sizeof(BuildPrim), hipMemcpyHostToDevice));
+        t_up = wall_ms();
 
         LBVH_TRY(hipEventRecord(e0, 0));
         LBVH_TRY(hipMemsetAsync(d_done, 0, (n - 1) * 4, 0));
@@ -240,12 +248,16 @@ int lbvh_build_device(const std::vector<BuildPrim>& prims, std::vector<BvhNode>&
         float ms = 0;
         LBVH_TRY(hipEventElapsedTime(&ms, e0, e1));
         if (kernel_ms) *kernel_ms += ms;
+        t_kernels = wall_ms();
 
         nodes.resize(size_t(base) + n - 1);
         LBVH_TRY(hipMemcpy(nodes.data() + base, d_out2, (n - 1) * sizeof(BvhNode), hipMemcpyDeviceToHost));
         LBVH_TRY(hipMemcpy(&h_levels, d_levels, 4, hipMemcpyDeviceToHost));
         root = base;
         levels = uint32_t(h_levels);
+        if (getenv("RTTNW_DEBUG_LOWER"))
+            fprintf(stderr, "[lbvh] %zu leaves: centroid bounds + allocations %.1f ms, upload %.1f ms, kernels %.1f ms (device %.2f), download %.1f ms\n", n, t_alloc,
+                    t_up - t_alloc, t_kernels - t_up, ms, wall_ms() - t_kernels);
     }
 done:
     if (rc) nodes.resize(size_t(base));

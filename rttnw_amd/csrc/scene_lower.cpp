@@ -13,6 +13,7 @@
 #include "scene_lower.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -665,6 +666,10 @@ struct Lowering {
 
     int run() {
         if (g.world < 0 || g.objs[g.world].kind != GraphObj::LIST_K) return fail(-2, "commit: world not set");
+        const bool timing = getenv("RTTNW_DEBUG_LOWER") != nullptr; // phase times of the lowering on stderr
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        const auto t_start = now();
         lower_textures_materials();
         if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
         std::vector<Item> top;
@@ -676,8 +681,10 @@ struct Lowering {
         if (fs.media.size() > 16) return fail(ERR_UNSUPPORTED, "more than 16 constant media (the free-flight draw of medium m uses RNG slot m < 16)");
         uint32_t top_depth = 0;
         Box3 wb;
+        const auto t_collected = now();
         fs.top_root2 = build_root(top, top_depth, wb);
         if (rc) return rc;
+        const auto t_built = now();
         // The kernels walk 4-wide records: collapse the top tree and every instance's tree.
         uint32_t top_need = 0, inst_need = 0;
         fs.top_root = collapse4(fs.top_root2, top_need);
@@ -692,6 +699,9 @@ struct Lowering {
         // Entries a lane's stack can hold at once: the pending children of the top tree and, while inside an instance,
         // one sentinel plus the pending children of the instance's tree.  +1 spare.
         fs.stack_depth = top_need + (any_tree ? 1u + inst_need : 0u) + 1u;
+        if (timing)
+            fprintf(stderr, "[lower] collect %.1f ms, top tree (%zu items) %.1f ms, 4-wide collapse (%zu -> %zu records) %.1f ms\n", ms(t_start, t_collected),
+                    top.size(), ms(t_collected, t_built), fs.nodes.size(), fs.nodes4.size(), ms(t_built, now()));
         for (const auto& in : fs.insts) fs.needs_general = fs.needs_general || in.n_ops > FAST_INSTANCE_OPS;
         for (const auto& md : fs.media) fs.needs_general = fs.needs_general || md.b_count > 1 || md.n_outer > 0;
         return 0;

@@ -224,8 +224,11 @@ def main():
             valu = dict(valu, wave_instructions_per_sample=round(valu["wave_instructions_per_launch"] / samples_rank, 1),
                         note="SQ_INSTS_VALU of one launch and SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU): the kernel is bound by "
                              "vector-instruction issue at this lane utilisation, not by memory")
+        # the same time priced at SURVEY 8(d)'s letter — ONE 32-B record per node visit whatever a record holds — for comparison
+        strict = (b_alg - (NODE_VISIT_BYTES - 32.0) * per["nodes"]) * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu": valu,
+                "frac_at_32B_per_node_visit": round(strict / HBM_PEAK_GBPS, 5),
                 "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if form == 0 else "", "float" if prec == abi.F32 else "double"),
                 "kernel_ms": round(kernel_ms, 3), "alg_bytes_per_sample": round(b_alg, 2),
                 "alg_bytes_per_launch": round(b_alg * samples_rank),

@@ -31,7 +31,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
     # name: (scene, width, height, spp per GPU, param)
@@ -110,7 +109,6 @@ def main():
 
     import numpy as np
     import torch
-    import util
     from rttnw_amd import abi, library, render
     from rttnw_amd import scene as S
 
@@ -157,7 +155,7 @@ def main():
     earth = S.load_earth()
 
     t0 = time.time()
-    sc, setup = util.build(gpu, scenes, scene_name, earth, param, bvh=abi.BVH_DEVICE_LBVH if args.bvh == "lbvh" else None)
+    sc, setup = S.build(gpu, scenes, scene_name, earth, param, bvh=abi.BVH_DEVICE_LBVH if args.bvh == "lbvh" else None)
     build_s = time.time() - t0
     binfo = sc.build_info()
     info = abi.Stats()
@@ -168,7 +166,7 @@ def main():
         Node records are priced per child box at the rate round 1 used — its 64-byte two-box record counted as ONE 32-B
         accounting record of BASELINE.md, so the 128-byte four-box record the kernels walk now counts as TWO (64 B): half
         the bytes a visit physically reads, in both rounds."""
-        cam_c, pc = util.params_for(setup, W, H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, collect_counters=args.counter_level)
+        cam_c, pc = S.params_for(setup, W, H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, collect_counters=args.counter_level)
         rc_ = render.DeviceRenderer(sc, cam_c, pc)
         st = abi.Stats()
         rc_.trace(st)
@@ -179,7 +177,7 @@ def main():
     def timed(prec, steps, warmup):
         """`steps` timed steps after `warmup` untimed ones: (ms_per_step over the barrier-bracketed region, mean device
         time of the trace kernel(s) per step from the library's HIP events on the launch stream)."""
-        cam_t, p = util.params_for(setup, W, H, spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, spp_chunk=args.spp_chunk)
+        cam_t, p = S.params_for(setup, W, H, spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, spp_chunk=args.spp_chunk)
         r = render.DeviceRenderer(sc, cam_t, p)
         for _ in range(warmup):
             r.trace() if share is not None else r.step()
@@ -255,14 +253,14 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import rto
-        so, _ = util.build(rto.binding(), scenes, scene_name, earth, min(param, 20000) if scene_name == "spheres_1m" else param)
+        so, _ = S.build(rto.binding(), scenes, scene_name, earth, min(param, 20000) if scene_name == "spheres_1m" else param)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        camc, pcal = util.params_for(setup, W, H, 1, seed=1)
+        camc, pcal = S.params_for(setup, W, H, 1, seed=1)
         tc = time.perf_counter()
         rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)      # calibration: 1 spp at full size
         rate = W * H / max(1e-6, time.perf_counter() - tc)
         cspp = int(max(1, min(256, round(rate * args.cpu_seconds / (W * H)))))
-        camc, pcpu = util.params_for(setup, W, H, cspp, seed=1)
+        camc, pcpu = S.params_for(setup, W, H, cspp, seed=1)
         tc = time.perf_counter()
         rto.render(so, camc, pcpu, n_threads=cores, want_rgba8=False)
         dt = time.perf_counter() - tc

@@ -20,6 +20,11 @@
  *     `rttnw_last_error()` returns a thread-local message for the last failure.
  *   - a scene is mutable until `rttnw_scene_commit`, immutable afterwards (the reference shares
  *     `&world` immutably across rayon workers, main.rs:216); one render in flight per scene.
+ *     One exception, inside the library: the trees are built for the shutter interval [0, 1]
+ *     (`BvhTree::from`, hittable.rs:256); the first render whose camera shutter reaches outside
+ *     it rebuilds them for the wider interval (`BvhTree::from_time`, hittable.rs:261) before it
+ *     enqueues anything — under a lock, device copies re-uploaded on use, and
+ *     `rttnw_scene_build_info` reports the rebuilt trees from then on.
  *   - there is NO CPU fallback: every render entry point fails with RTTNW_ERR_HIP when no gfx950
  *     device is usable.
  */

@@ -6,9 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import util  # noqa: E402
 from rttnw_amd import abi, library, render, scene as S  # noqa: E402
 
 gpu, scenes, earth = library.product(), library.scenes(), S.load_earth()
@@ -16,14 +14,14 @@ names = [scenes.scenes_name(n).decode() for n in range(1, 10)] + ["spheres_1m"]
 print("| scene | size | 4-wide nodes | records | kernel form | f64 Msamples/s | f32 Msamples/s | rays / node visits / record tests per sample |")
 print("|---|---|---|---|---|---|---|---|")
 for name in names:
-    sc, setup = util.build(gpu, scenes, name, earth)
+    sc, setup = S.build(gpu, scenes, name, earth)
     w = 800 if name != "spheres_1m" else 1024
     h = int(w / (setup.width / setup.height))
     info = abi.Stats()
     gpu.scene_info(sc.handle, info)
     rates, form, per = {}, None, None
     for prec in (abi.F64, abi.F32):
-        cam, p = util.params_for(setup, w, h, 256, precision=prec, seed=1)
+        cam, p = S.params_for(setup, w, h, 256, precision=prec, seed=1)
         r = render.DeviceRenderer(sc, cam, p)
         st = abi.Stats()
         r.trace(st)                      # warm-up (uploads the scene of this precision)
@@ -31,7 +29,7 @@ for name in names:
         rates[prec] = w * h * 256 / st.kernel_ms / 1e3
         form = "decoupled" if st.reserved else "lane-owns-path"
         if prec == abi.F64:
-            camc, pc = util.params_for(setup, w, h, 8, precision=prec, seed=1, collect_counters=1)
+            camc, pc = S.params_for(setup, w, h, 8, precision=prec, seed=1, collect_counters=1)
             rc = render.DeviceRenderer(sc, camc, pc)
             sc_ = abi.Stats()
             rc.trace(sc_)

@@ -24,6 +24,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <mutex>
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
@@ -1214,26 +1216,36 @@ static int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_
     if (!(cam->open_time <= cam->close_time)) { set_last_error("render: open_time > close_time"); return RTTNW_ERR_INVALID; }
     // The boxes of moving spheres are built for the shutter interval [0, 1] (what BvhTree::from uses, hittable.rs:256).  A
     // camera whose shutter reaches outside it (BvhTree::from_time, hittable.rs:261) makes the library rebuild the trees
-    // for the wider interval, once, and drop the device copies (they are uploaded again on use).
-    if (!s->flat.moving.empty() && (cam->open_time < s->flat.time0 || cam->close_time > s->flat.time1)) {
-        const double t0 = std::min(s->flat.time0, cam->open_time), t1 = std::max(s->flat.time1, cam->close_time);
-        std::string err;
-        BvhBuilder device_builder;
-        const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
-        if (on_device)
-            if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
-        FlatScene wider;
-        if (int rc = lower_scene(s->graph, wider, err, on_device ? &device_builder : nullptr, t0, t1)) { set_last_error(err); return rc; }
-        s->flat = std::move(wider);
-        int prev = -1;
-        (void)hipGetDevice(&prev);
-        std::vector<DeviceState*> all = s->more_devices;
-        all.push_back(s->device);
-        for (DeviceState* d : all) {
-            (void)hipSetDevice(d->device);
-            d->s32.release(); d->s64.release();
+    // for the wider interval, once, and drop the device copies (they are uploaded again on use).  This is the ONE change a
+    // committed scene can undergo (include/rttnw_hip.h says so): it happens under the scene's mutex, before anything of this
+    // call is enqueued, and rttnw_scene_build_info reports the rebuilt trees afterwards.  "One render in flight per scene"
+    // (the header's rule) is what keeps a concurrent render from seeing the swap.
+    {
+        std::lock_guard<std::mutex> lock(s->rebuild_mutex);
+        if (!s->flat.moving.empty() && (cam->open_time < s->flat.time0 || cam->close_time > s->flat.time1)) {
+            const double t0 = std::min(s->flat.time0, cam->open_time), t1 = std::max(s->flat.time1, cam->close_time);
+            std::string err;
+            BvhBuilder device_builder;
+            const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
+            if (on_device)
+                if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
+            FlatScene wider;
+            const auto tb = std::chrono::steady_clock::now();
+            s->build_kernel_ms = 0;
+            if (int rc = lower_scene(s->graph, wider, err, on_device ? &device_builder : nullptr, t0, t1)) { set_last_error(err); return rc; }
+            s->lower_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            std::vector<DeviceState*> all = s->more_devices;
+            all.push_back(s->device);
+            for (DeviceState* d : all) { // nothing of an earlier render may still read the arrays that are about to go
+                (void)hipSetDevice(d->device);
+                (void)hipDeviceSynchronize();
+                d->s32.release(); d->s64.release();
+            }
+            if (prev >= 0) (void)hipSetDevice(prev);
+            s->flat = std::move(wider);
         }
-        if (prev >= 0) (void)hipSetDevice(prev);
     }
     return 0;
 }

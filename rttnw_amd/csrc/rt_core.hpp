@@ -287,8 +287,14 @@ template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             sr.o[a] = float(oo[a]);
-            sr.inv[a] = rt_rcp(float(dd[a]));
-            sr.slack = rt_max(sr.slack, rt_fabs(sr.o[a] * sr.inv[a]) * 1.2e-7f); // maxNum: an inf * 0 axis drops out
+            float inv = rt_rcp(float(dd[a]));
+            // an axis the ray is exactly parallel to (or whose direction component underflows in f32): 1/d = inf would make
+            // the ONE slack below infinite and the whole walk lose its culling.  NaN instead: every plane distance of this
+            // axis is then NaN, which the maxNum / minNum of slab4_planes drop — the axis never culls (conservative: the
+            // exact test could at most cull more) and stays out of the slack.
+            if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
+            sr.inv[a] = inv;
+            sr.slack = rt_max(sr.slack, rt_fabs(sr.o[a] * inv) * 1.2e-7f); // maxNum: a NaN axis drops out
         }
     } else {
         sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -680,9 +686,9 @@ template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray
 }
 
 // One inner node (tr.node >= 0): test the (up to) four child boxes, descend into the nearest hit child, push the others
-// farthest first.  The hit children are ordered by a 4-key sorting network on integers: key = the bits of the (positive)
-// entry distance with the slot number in the two lowest bits (4 ulps of ordering noise, which only ever changes the
-// order of visits, never a result), 0xFFFFFFFF for a miss — five min/max pairs instead of compare-and-select chains.
+// farthest first.  The hit children are ordered by a 5-comparator sorting network on (key, child) pairs: key = the bits
+// of the (positive) entry distance — they order like the values — 0xFFFFFFFF for a miss; equal keys keep slot order
+// (the order of visits never changes a result).
 RT_HD void pair_swap(uint32_t& ka, int32_t& ca, uint32_t& kb, int32_t& cb) { // (key, child) pairs: smaller key first
     const bool sw = kb < ka;
     const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb;

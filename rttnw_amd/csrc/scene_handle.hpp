@@ -3,6 +3,7 @@
 #pragma once
 #include "scene_lower.hpp"
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,4 +28,5 @@ struct rttnw_scene {
     double build_kernel_ms = 0;    // device time of the BVH build kernels (device builder only)
     rt::DeviceState* device = nullptr;              // state on the device that was current at commit
     std::vector<rt::DeviceState*> more_devices;     // states on further devices (rttnw_render_multi), created on first use
+    std::mutex rebuild_mutex;                       // render entry points: the one post-commit change of `flat` (a wider shutter, render.hip validate)
 };

@@ -164,6 +164,24 @@ def make_params(width, height, spp, *, background=(0.0, 0.0, 0.0), seed=1, preci
                   spp_chunk, tile_rank, tile_world, collect_counters, sample_begin, 0)
 
 
+def build(binding, scenes_lib, name, earth=None, param=0, seed=0x5EED0001, bvh=None):
+    """One of the catalogue scenes (host/scenes.cpp, the scenes.rs mirror) built through `binding` and committed:
+    (Scene, SceneSetup).  `bvh`: abi.BVH_HOST_SAH (default) or abi.BVH_DEVICE_LBVH."""
+    sc = Scene(binding, seed, scenes_binding=scenes_lib)
+    if bvh is not None:
+        sc.set_bvh_builder(bvh)
+    setup = sc.build_named(name, earth_rgba=earth, param=param)
+    return sc, setup
+
+
+def params_for(setup, w, h, spp, **kw):
+    """(CameraDesc, Params) of a catalogue scene at another size: the scene's own camera (main.rs:66-183) at aspect w / h."""
+    cam = CameraDesc.from_buffer_copy(setup.camera)
+    cam.aspect_ratio = w / h
+    p = make_params(w, h, spp, background=tuple(setup.background), **kw)
+    return cam, p
+
+
 def load_earth():
     """Decode the earth map fixture (the reference's assets/earth.png, scenes.rs:129,303)."""
     import os

@@ -12,7 +12,8 @@ EXE = os.path.join(ROOT, "rttnw_amd", "host", "rttnw")
 
 @pytest.fixture(scope="module")
 def exe():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "rttnw_amd", "host")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "rttnw_amd", "csrc")], check=True, capture_output=True)   # the program links against it
+    subprocess.run(["make", "-C", os.path.join(ROOT, "rttnw_amd", "host"), "cli"], check=True, capture_output=True)
     return EXE
 
 

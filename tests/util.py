@@ -7,19 +7,7 @@ from rttnw_amd import abi
 from rttnw_amd import scene as S
 
 
-def build(binding, scenes_lib, name, earth=None, param=0, seed=0x5EED0001, bvh=None):
-    sc = S.Scene(binding, seed, scenes_binding=scenes_lib)
-    if bvh is not None:
-        sc.set_bvh_builder(bvh)
-    setup = sc.build_named(name, earth_rgba=earth, param=param)
-    return sc, setup
-
-
-def params_for(setup, w, h, spp, **kw):
-    cam = abi.CameraDesc.from_buffer_copy(setup.camera)
-    cam.aspect_ratio = w / h
-    p = S.make_params(w, h, spp, background=tuple(setup.background), **kw)
-    return cam, p
+build, params_for = S.build, S.params_for  # (live in the package: bench.py and smoke() use them too)
 
 
 def hostsim_render(hostsim, sc, cam, p, n_threads=0):

@@ -18,17 +18,7 @@ from oracle import rto  # noqa: E402
 from rttnw_amd import abi, scene as S  # noqa: E402
 import util  # noqa: E402
 
-CASES = [  # name, scene, w, h, spp, spp_chunk, param
-    ("cornell_64", "cornell_box", 64, 64, 16, 4, 0),
-    ("final_64", "final_scene", 64, 64, 16, 4, 0),
-    ("final_ragged_45x37", "final_scene", 45, 37, 5, 2, 0),
-    ("random_scene_48x27", "random_scene", 48, 27, 8, 8, 0),
-    ("smoke_cornell_40", "smoke_cornell_box", 40, 40, 8, 3, 0),
-    ("simple_light_48x27", "simple_light", 48, 27, 8, 4, 0),
-    ("two_spheres_32x18", "two_spheres", 32, 18, 4, 4, 0),
-    ("earth_32x18", "earth", 32, 18, 4, 4, 0),
-    ("spheres_2k_48", "spheres_1m", 48, 48, 8, 4, 2000),
-]
+from golden_cases import CASES  # noqa: E402  (key, scene, w, h, spp, spp_chunk, param)
 
 if __name__ == "__main__":
     b = rto.binding()

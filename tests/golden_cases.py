@@ -12,6 +12,8 @@ CASES = [  # key, scene, w, h, spp, spp_chunk, param
     ("simple_light_48x27", "simple_light", 48, 27, 8, 4, 0),
     ("two_spheres_32x18", "two_spheres", 32, 18, 4, 4, 0),
     ("earth_32x18", "earth", 32, 18, 4, 4, 0),
+    ("two_perlin_48x27", "two_perlin_spheres", 48, 27, 8, 4, 0),     # Perlin at scale 4 on a radius-1000 sphere (scenes.rs:110-125)
+    ("empty_cornell_40", "empty_cornell_box", 40, 40, 8, 3, 0),      # scenes.rs:157-173
     ("spheres_2k_48", "spheres_1m", 48, 48, 8, 4, 2000),
 ]
 

@@ -11,16 +11,30 @@ resolve + tile gather to rank 0 + un-tile/quantise), with the scene already resi
 Arithmetic: the F64 kernels by default — the reference is f64 end to end (src/math/vec3.rs:12); the F32
 (throughput) kernels are timed beside them and reported under "f32_kernels".
 
-N = 1 (default): BASELINE.json's metric config, final_scene 800x800 spp=1000.
+N = 1 (default): BASELINE.json's metric config, final_scene 800x800 spp=1000, in the top-level fields; the other two
+single-GPU configs of BASELINE.json — cornell_box 800x800 spp=1000 (configs[1]) and spheres_1m 1024x1024 spp=256
+(configs[4]) — are timed in the same run with a few steps each and reported as the sub-records "cornell_box" and
+"spheres_1m" (own steps, ms_per_step, kernel_ms, roofline; --no-sub skips them).
 N > 1: one process per GPU; the 8x8-tile partition of the framebuffer is interleaved over the ranks, every rank
 traces its own tiles (no data-path collective), one RCCL gather brings the packed tiles to rank 0.  The workload
 is BASELINE configs[3]'s frame, final_scene 1600x1600, at spp = 1250 x N: per-GPU work is fixed (weak scaling:
 3200 Msamples per GPU and step) and the N = 8 point IS configs[3] (1600x1600 spp=10000 tile-sharded across 8).
 value = samples of all ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant (trace) kernel against HBM with the counted
-algorithmic bytes of SURVEY.md §8(d); `cpu_baseline` times the CPU oracle (a port of the reference: the
-Rust reference cannot be built here) on the host cores for a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.
+
+`roofline` says what bounds the dominant (trace) kernel:
+  * scenes whose node records live in LDS (final_scene, cornell_box): "bound": "valu" — achieved = full-wave VALU
+    instructions per second (SQ_INSTS_VALU x lane utilisation / kernel time, from the committed rocprofv3 PMC summary of
+    this exact kernel source) against the issue peak of MI355X_MICROARCH.md (1024 SIMDs x 2.4 GHz; 2 cycles per wave64 f32
+    instruction, 4 per f64).  HBM is not what bounds them: counter traffic is ~1 % of peak.
+  * spheres_1m (node records in HBM / Infinity Cache): "bound": "hbm" — achieved = ALGORITHMIC bytes / kernel time with
+    SURVEY 8(d)'s accounting to the letter: 32 B per node visit + 32 B per primitive test + 4 B per texel + 16 B / spp.
+  Every record carries `hbm_algorithmic` (the 8(d) reading at 32 B per visit, and the same time priced at 64 B — 16 B per
+  child box — and at the 128 B a 4-wide record physically is) and `traffic` (HBM bytes per launch from the PMC counters,
+  FETCH_SIZE x 2 + WRITE_SIZE, or null when no summary of this kernel source is committed).
+`cpu_baseline` times the CPU oracle (a port of the reference: the Rust reference cannot be built here) on the host
+cores for a bounded sample of the headline workload.
 """
 import argparse
 import hashlib
@@ -39,9 +53,11 @@ WORKLOADS = {
     "spheres_1m": ("spheres_1m", 1024, 1024, 256, 0),           # configs[4]
     "final_scene_1600": ("final_scene", 1600, 1600, 1250, 0),   # configs[3] when run on 8 GPUs (spp = 1250 x N)
 }
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-NODE_VISIT_BYTES = 64.0  # accounting price of one visit of a 4-wide (128-byte, four-box) node record: 16 B per child box, as in round 1
-PROFILE_ROUND = "r02"
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+N_SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (same table)
+VALU_CYCLES = {"f32": 2.0, "f64": 4.0}   # cycles per wave64 VALU instruction: f32 2 (SIMD-32, per-instruction table), f64 at half rate (78.6 vs 157.3 TFLOP/s)
+NODE_VISIT_BYTES = 32.0  # ONE 32-B accounting record per node visit, whatever a record physically holds
+PROFILE_ROUND = "r03"
 KERNEL_SOURCES = ["rttnw_amd/csrc/render.hip", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp", "rttnw_amd/csrc/Makefile"]
 
 
@@ -58,32 +74,27 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def committed_traffic(scene_name, precision_name):
-    """HBM traffic of one launch of the dominant kernel.  PMC counters can only be collected under rocprofv3, so the
-    figure comes from the committed summary of `profiles/collect_pmc.sh` for this workload and kernel (FETCH_SIZE x 2
-    per the gfx950 correction + WRITE_SIZE, both in KB) — and only while that summary was collected with the kernel
-    sources of THIS tree (its `kernel_source_sha` line); otherwise null."""
+def committed_pmc(scene_name, precision_name):
+    """Counters of one launch of the dominant kernel.  PMC counters can only be collected under rocprofv3, so they come
+    from the committed summary of `profiles/collect_pmc.sh` for this workload and kernel — and only while that summary
+    was collected with the kernel sources of THIS tree (its `kernel_source_sha` line); otherwise None."""
     pmc = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_%s_%s.txt" % (scene_name, precision_name))
     if not os.path.exists(pmc):
-        return None, None
+        return None
     vals, sha = {}, None
     for line in open(pmc):
         f = line.split()
-        if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"):
-            vals[f[0]] = float(f[1])
         if len(f) >= 2 and f[0] == "kernel_source_sha":
             sha = f[1]
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals or sha != kernel_source_sha():
-        return None, None
-    global _committed_valu
-    if "SQ_INSTS_VALU" in vals and vals.get("SQ_ACTIVE_INST_VALU"):
-        _committed_valu[(scene_name, precision_name)] = {
-            "wave_instructions_per_launch": vals["SQ_INSTS_VALU"],
-            "lane_utilisation": round(vals.get("SQ_THREAD_CYCLES_VALU", 0.0) / (vals["SQ_ACTIVE_INST_VALU"] * 64.0), 3)}
-    return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0), "profiles/%s/%s" % (PROFILE_ROUND, os.path.basename(pmc))
-
-
-_committed_valu = {}   # (scene, precision) -> VALU counters of the same committed summary (filled by committed_traffic)
+        elif len(f) >= 2 and f[0].isupper():
+            try:
+                vals[f[0]] = float(f[1])
+            except ValueError:
+                pass
+    if sha != kernel_source_sha():
+        return None
+    vals["source"] = "profiles/%s/%s" % (PROFILE_ROUND, os.path.basename(pmc))
+    return vals
 
 
 def main():
@@ -100,6 +111,8 @@ def main():
     ap.add_argument("--counter-spp", type=int, default=8)
     ap.add_argument("--counter-level", type=int, default=1, help="collect_counters of the untimed counting pass (2, 3: more RTTNW_DEBUG_SCHED statistics)")
     ap.add_argument("--no-other", action="store_true", help="skip the timing of the other precision's kernels")
+    ap.add_argument("--no-sub", action="store_true", help="skip the cornell_box / spheres_1m sub-records of the default run")
+    ap.add_argument("--sub-steps", type=int, default=3, help="timed steps of each sub-record (after one warm-up step)")
     ap.add_argument("--spp-chunk", type=int, default=0, help="samples per work item (0 = the library's tapered schedule)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder at commit: host binned SAH (default) or device LBVH")
     ap.add_argument("--share", default=None, metavar="R/W",
@@ -144,123 +157,187 @@ def main():
     if gpu.device_count() < 1:
         raise RuntimeError("bench: no HIP device (no CPU fallback in the product path)")
     scenes = library.scenes()
-    workload = args.workload or ("final_scene" if world == 1 else "final_scene_1600")
-    scene_name, W, H, spp1, param = WORKLOADS[workload]
-    if args.size:
-        W = H = args.size
-    if args.spp:
-        spp1 = args.spp
-    spp = spp1 * world  # weak scaling: fixed per-GPU work
-    precision = abi.F32 if args.precision == "f32" else abi.F64
     earth = S.load_earth()
 
-    t0 = time.time()
-    sc, setup = S.build(gpu, scenes, scene_name, earth, param, bvh=abi.BVH_DEVICE_LBVH if args.bvh == "lbvh" else None)
-    build_s = time.time() - t0
-    binfo = sc.build_info()
-    info = abi.Stats()
-    gpu.scene_info(sc.handle, info)
+    class Workload:
+        """One named workload resident on the device: scene built and committed, timing and counting helpers."""
 
-    def counted(prec):
-        """Algorithmic bytes per sample, counted by the counting kernel variant on this rank's tiles (untimed).
-        Node records are priced per child box at the rate round 1 used — its 64-byte two-box record counted as ONE 32-B
-        accounting record of BASELINE.md, so the 128-byte four-box record the kernels walk now counts as TWO (64 B): half
-        the bytes a visit physically reads, in both rounds."""
-        cam_c, pc = S.params_for(setup, W, H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, collect_counters=args.counter_level)
-        rc_ = render.DeviceRenderer(sc, cam_c, pc)
-        st = abi.Stats()
-        rc_.trace(st)
-        n = max(1, st.samples)
-        per = dict(rays=st.rays / n, nodes=st.nodes_visited / n, prims=st.prims_tested / n, texels=st.texel_fetches / n)
-        return NODE_VISIT_BYTES * per["nodes"] + 32.0 * per["prims"] + 4.0 * per["texels"] + 16.0 / spp, per, st.reserved
+        def __init__(self, workload, spp_override=0, size_override=0):
+            self.workload = workload
+            self.scene_name, self.W, self.H, spp1, self.param = WORKLOADS[workload]
+            if size_override:
+                self.W = self.H = size_override
+            self.spp1 = spp_override or spp1
+            self.spp = self.spp1 * world  # weak scaling: fixed per-GPU work
+            t0 = time.time()
+            self.sc, self.setup = S.build(gpu, scenes, self.scene_name, earth, self.param,
+                                          bvh=abi.BVH_DEVICE_LBVH if args.bvh == "lbvh" else None)
+            self.build_s = time.time() - t0
+            self.binfo = self.sc.build_info()
+            self.info = abi.Stats()
+            gpu.scene_info(self.sc.handle, self.info)
+            self.samples_total = float(self.W) * self.H * self.spp          # all ranks together
+            self.samples_rank = self.samples_total / world
+            if share is not None:
+                self.samples_total = self.samples_rank                       # --share: this rank's rate
+            # (the committed PMC summaries are of the default configuration: whole frame on one GPU, host SAH trees, default schedule)
+            self.default_run = (world == 1 and share is None and not spp_override and not size_override and not args.spp_chunk
+                                and args.bvh == "sah")
 
-    def timed(prec, steps, warmup):
-        """`steps` timed steps after `warmup` untimed ones: (ms_per_step over the barrier-bracketed region, mean device
-        time of the trace kernel(s) per step from the library's HIP events on the launch stream)."""
-        cam_t, p = S.params_for(setup, W, H, spp, precision=prec, tile_rank=rank, tile_world=world, seed=1, spp_chunk=args.spp_chunk)
-        r = render.DeviceRenderer(sc, cam_t, p)
-        for _ in range(warmup):
-            r.trace() if share is not None else r.step()
-        st = abi.Stats()
-        kms = []
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            r.trace(st)             # rttnw_stats.kernel_ms: hipEvents around the trace kernel launch(es) on their own stream
-            kms.append(st.kernel_ms)
-            if share is None:
-                r.collect()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        ms_per_step = elapsed * 1e3 / max(1, steps)
-        kernel_ms = float(np.mean(kms)) if kms else 0.0
-        if use_dist:
-            t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ms_per_step, kernel_ms = float(t[0]), float(t[1])
-        del r
-        return ms_per_step, kernel_ms
+        def counted(self, prec):
+            """Counted rays / node visits / primitive tests / texels per sample (counted, not modelled), by the
+            counting kernel variant on this rank's tiles (untimed)."""
+            cam_c, pc = S.params_for(self.setup, self.W, self.H, args.counter_spp, precision=prec, tile_rank=rank, tile_world=world,
+                                     seed=1, collect_counters=args.counter_level)
+            rc_ = render.DeviceRenderer(self.sc, cam_c, pc)
+            st = abi.Stats()
+            rc_.trace(st)
+            n = max(1, st.samples)
+            per = dict(rays=st.rays / n, nodes=st.nodes_visited / n, prims=st.prims_tested / n, texels=st.texel_fetches / n)
+            return per, st.reserved
 
-    samples_total = float(W) * H * spp          # all ranks together
-    samples_rank = samples_total / world
-    if share is not None:
-        samples_total = samples_rank            # --share: this rank's rate
+        def timed(self, prec, steps, warmup):
+            """`steps` timed steps after `warmup` untimed ones: (ms_per_step over the barrier-bracketed region, mean device
+            time of the trace kernel(s) per step from the library's HIP events on the launch stream)."""
+            cam_t, p = S.params_for(self.setup, self.W, self.H, self.spp, precision=prec, tile_rank=rank, tile_world=world, seed=1,
+                                    spp_chunk=args.spp_chunk)
+            r = render.DeviceRenderer(self.sc, cam_t, p)
+            for _ in range(warmup):
+                r.trace() if share is not None else r.step()
+            st = abi.Stats()
+            kms = []
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r.trace(st)             # rttnw_stats.kernel_ms: hipEvents around the trace kernel launch(es) on their own stream
+                kms.append(st.kernel_ms)
+                if share is None:
+                    r.collect()
+            torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
+            ms_per_step = elapsed * 1e3 / max(1, steps)
+            kernel_ms = float(np.mean(kms)) if kms else 0.0
+            if use_dist:
+                t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms_per_step, kernel_ms = float(t[0]), float(t[1])
+            del r
+            return ms_per_step, kernel_ms
 
-    def roofline(prec, kernel_ms):
-        b_alg, per, form = counted(prec)
-        achieved = b_alg * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        pname = "f32" if prec == abi.F32 else "f64"
-        # (the committed PMC summaries are of the default configuration: whole frame on one GPU, host SAH trees, default schedule)
-        default_run = world == 1 and share is None and not args.spp and not args.size and not args.spp_chunk and args.bvh == "sah"
-        traffic, traffic_src = committed_traffic(scene_name, pname) if default_run else (None, None)
-        valu = _committed_valu.get((scene_name, pname)) if default_run else None
-        if valu is not None:   # the secondary bound of the LDS-resident scenes (SURVEY 8d): what the vector ALUs did, from the same PMC summary
-            valu = dict(valu, wave_instructions_per_sample=round(valu["wave_instructions_per_launch"] / samples_rank, 1),
-                        note="SQ_INSTS_VALU of one launch and SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU): the kernel is bound by "
-                             "vector-instruction issue at this lane utilisation, not by memory")
-        # the same time priced at SURVEY 8(d)'s letter — ONE 32-B record per node visit whatever a record holds — for comparison
-        strict = (b_alg - (NODE_VISIT_BYTES - 32.0) * per["nodes"]) * samples_rank / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src, "valu": valu,
-                "frac_at_32B_per_node_visit": round(strict / HBM_PEAK_GBPS, 5),
-                "kernel": "rt::trace_kernel%s<%s,false>" % ("_plain" if form == 0 else "", "float" if prec == abi.F32 else "double"),
-                "kernel_ms": round(kernel_ms, 3), "alg_bytes_per_sample": round(b_alg, 2),
-                "alg_bytes_per_launch": round(b_alg * samples_rank),
-                "per_sample": {k: round(v, 3) for k, v in per.items()},
-                "note": "scene is L2/MALL-resident; achieved = counted algorithmic bytes / kernel time; alg bytes = 64 B x node visits "
-                        "(a 128-byte 4-wide record priced at two 32-B accounting records: 16 B per child box, the rate round 1 "
-                        "applied to its 64-byte 2-box records) + 32 B x primitive tests + 4 B x texels + 16 B / spp"}
+        def roofline(self, prec, kernel_ms):
+            per, form = self.counted(prec)
+            pname = "f32" if prec == abi.F32 else "f64"
+            secs = kernel_ms * 1e-3
+
+            # SURVEY 8(d) to the letter: 32 B per node visit + 32 B per primitive test + 4 B per texel + 16 B / spp
+            def alg_bytes(node_bytes):
+                return node_bytes * per["nodes"] + 32.0 * per["prims"] + 4.0 * per["texels"] + 16.0 / self.spp
+
+            def gbps(node_bytes):
+                return alg_bytes(node_bytes) * self.samples_rank / secs / 1e9 if secs > 0 else 0.0
+
+            b_alg = alg_bytes(NODE_VISIT_BYTES)
+            hbm_alg = {"achieved": round(gbps(32.0), 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": round(gbps(32.0) / HBM_PEAK_GBPS, 5),
+                       "alg_bytes_per_sample": round(b_alg, 2), "alg_bytes_per_launch": round(b_alg * self.samples_rank),
+                       "frac_at_64B_per_node_visit": round(gbps(64.0) / HBM_PEAK_GBPS, 5),
+                       "frac_at_128B_per_node_visit": round(gbps(128.0) / HBM_PEAK_GBPS, 5),
+                       "note": "SURVEY 8(d): 32 B x node visits + 32 B x primitive tests + 4 B x texels + 16 B / spp, counts from the "
+                               "counting kernel variant in this run; the 64 B reading prices a 4-wide record per child box (16 B), "
+                               "the 128 B reading at what a visit physically reads"}
+            pmc = committed_pmc(self.scene_name, pname) if self.default_run else None
+            traffic = traffic_src = valu = None
+            if pmc is not None and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # KB -> B; FETCH_SIZE x 2: the gfx950 correction, calibrated on gathers of 128-B records (profiles/r03/README.md)
+                traffic = round((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
+                traffic_src = pmc["source"]
+            if pmc is not None and pmc.get("SQ_INSTS_VALU") and pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU"):
+                lane_util = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
+                peak = N_SIMDS * CLOCK_GHZ / VALU_CYCLES[pname]                           # G wave-instructions / s
+                ach = pmc["SQ_INSTS_VALU"] * lane_util / secs / 1e9 if secs > 0 else 0.0   # full-wave equivalents / s
+                valu = {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": "G full-wave VALU instructions/s",
+                        "frac": round(ach / peak, 5), "lane_utilisation": round(lane_util, 4),
+                        "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
+                        "wave_instructions_per_sample": round(pmc["SQ_INSTS_VALU"] / self.samples_rank, 1),
+                        "issue_cycles_per_instruction": VALU_CYCLES[pname], "source": pmc["source"],
+                        "note": "achieved = SQ_INSTS_VALU x SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) / kernel time: the vector "
+                                "instructions of one launch counted as full 64-lane instructions; peak = 1024 SIMDs x 2.4 GHz / cycles "
+                                "per wave64 instruction of this kernel's arithmetic"}
+            kernel = ("rt::trace_kernel_plain<%s, ...>" if form == 0 else "rt::trace_kernel<%s, ...>") % ("float" if prec == abi.F32 else "double")
+            common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
+                      "per_sample": {k: round(v, 3) for k, v in per.items()}, "hbm_algorithmic": hbm_alg, "valu": valu}
+            if traffic is not None and secs > 0:
+                common["traffic_frac_of_hbm_peak"] = round(traffic / secs / 1e9 / HBM_PEAK_GBPS, 5)
+            # what bounds the kernel: memory when the node records are walked in HBM / Infinity Cache (the decoupled kernel:
+            # counter traffic ~ algorithmic bytes), vector-instruction issue when they are LDS-resident (counter traffic ~1 % of peak)
+            lds_resident = form == 0 and self.info.n_nodes * 112 <= 140 * 1024
+            if lds_resident and valu is not None:
+                out = {"bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]}
+                out["note"] = ("node records are LDS-resident: the kernel is bound by vector-instruction issue at this lane utilisation, "
+                               "not by memory (see traffic); hbm_algorithmic carries SURVEY 8(d)'s byte accounting for the same launch")
+            else:
+                out = {"bound": "hbm", "achieved": hbm_alg["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_alg["frac"]}
+                out["note"] = hbm_alg["note"] + ("" if not lds_resident else
+                                                 "; node records are LDS-resident and the kernel is VALU-issue bound — no PMC summary of "
+                                                 "this kernel source is committed, so only the byte accounting is reported")
+            out.update(common)
+            return out
+
+        def record(self, prec, steps, warmup):
+            ms, kms = self.timed(prec, steps, warmup)
+            return {"workload": "%s %dx%d spp=%d" % (self.scene_name, self.W, self.H, self.spp),
+                    "dtype": "f32" if prec == abi.F32 else "f64",
+                    "value": round(self.samples_total / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3),
+                    "steps": steps, "warmup": warmup, "roofline": self.roofline(prec, kms)}
+
+        def config(self):
+            return {"scene_nodes": self.info.n_nodes, "scene_prims": self.info.n_prims, "scene_bytes_f32": self.info.scene_bytes,
+                    "scene_build_s": round(self.build_s, 3), "bvh_builder": args.bvh, "bvh_lower_ms": round(self.binfo.lower_ms, 2),
+                    "bvh_device_ms": round(self.binfo.device_ms, 3), "stack_depth": self.binfo.stack_depth}
+
+    workload = args.workload or ("final_scene" if world == 1 else "final_scene_1600")
+    wl = Workload(workload, args.spp, args.size)
+    precision = abi.F32 if args.precision == "f32" else abi.F64
 
     # ---- timed region (the reported precision)
-    ms_per_step, kernel_ms = timed(precision, args.steps, args.warmup)
-    value = samples_total / (ms_per_step * 1e-3) / 1e6
-    roof = roofline(precision, kernel_ms)
+    ms_per_step, kernel_ms = wl.timed(precision, args.steps, args.warmup)
+    value = wl.samples_total / (ms_per_step * 1e-3) / 1e6
+    roof = wl.roofline(precision, kernel_ms)
 
     # ---- the same workload through the other precision's kernels, its own multi-step timing
     other = None
     if not args.no_other:
         oprec = abi.F32 if precision == abi.F64 else abi.F64
-        osteps = max(1, min(args.steps, 5))
-        oms, okms = timed(oprec, osteps, 1)
-        other = {"value": round(samples_total / (oms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(oms, 3),
-                 "steps": osteps, "warmup": 1, "roofline": roofline(oprec, okms)}
+        other = wl.record(oprec, max(1, min(args.steps, 5)), 1)
+
+    # ---- the other single-GPU configs of BASELINE.json, timed in the same run (default N = 1 run only)
+    subs = {}
+    if world == 1 and share is None and args.workload is None and not args.no_sub and not args.spp and not args.size:
+        for name in ("cornell_box", "spheres_1m"):
+            w2 = Workload(name)
+            rec = w2.record(abi.F64, args.sub_steps, 1)
+            rec["config"] = w2.config()
+            rec["f32_kernels"] = w2.record(abi.F32, args.sub_steps, 1)
+            subs[name] = rec
+            del w2
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import rto
-        so, _ = S.build(rto.binding(), scenes, scene_name, earth, min(param, 20000) if scene_name == "spheres_1m" else param)
+        scene_name, W, H, param = wl.scene_name, wl.W, wl.H, wl.param
+        so, _ = S.build(rto.binding(), scenes, scene_name, earth, min(param or 20000, 20000) if scene_name == "spheres_1m" else param)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        camc, pcal = S.params_for(setup, W, H, 1, seed=1)
+        camc, pcal = S.params_for(wl.setup, W, H, 1, seed=1)
         tc = time.perf_counter()
         rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)      # calibration: 1 spp at full size
         rate = W * H / max(1e-6, time.perf_counter() - tc)
         cspp = int(max(1, min(256, round(rate * args.cpu_seconds / (W * H)))))
-        camc, pcpu = S.params_for(setup, W, H, cspp, seed=1)
+        camc, pcpu = S.params_for(wl.setup, W, H, cspp, seed=1)
         tc = time.perf_counter()
         rto.render(so, camc, pcpu, n_threads=cores, want_rgba8=False)
         dt = time.perf_counter() - tc
@@ -269,22 +346,22 @@ def main():
                          % (scene_name, W, H, cspp, dt)}
 
     if rank == 0 or share is not None:
+        cfg = {"workload": "%s %dx%d spp=%d%s" % (wl.scene_name, wl.W, wl.H, wl.spp, " (spp = %d x %d GPUs)" % (wl.spp1, world) if world > 1 else ""),
+               "max_depth": 50, "scene_seed": "0x5eed0001", "render_seed": 1, "quirks": "reference",
+               "partition": ("8x8 tiles interleaved over %d rank(s), RCCL gather to rank 0" % world) if share is None else
+                            ("--share: rank %d of %d only, on one GPU, no gather; value = this rank's rate" % (rank, world))}
+        cfg.update(wl.config())
         out = {
             "metric": "Msamples/sec on final_scene 800x800 spp=1000; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": 1 if share is not None else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%s %dx%d spp=%d%s" % (scene_name, W, H, spp, " (spp = %d x %d GPUs)" % (spp1, world) if world > 1 else ""),
-                       "max_depth": 50, "scene_seed": "0x5eed0001", "render_seed": 1, "quirks": "reference",
-                       "partition": ("8x8 tiles interleaved over %d rank(s), RCCL gather to rank 0" % world) if share is None else
-                                    ("--share: rank %d of %d only, on one GPU, no gather; value = this rank's rate" % (rank, world)),
-                       "scene_nodes": info.n_nodes, "scene_prims": info.n_prims, "scene_bytes_f32": info.scene_bytes,
-                       "scene_build_s": round(build_s, 3), "bvh_builder": args.bvh, "bvh_lower_ms": round(binfo.lower_ms, 2),
-                       "bvh_device_ms": round(binfo.device_ms, 3), "stack_depth": binfo.stack_depth},
+            "config": cfg,
             "roofline": roof,
             "cpu_baseline": cpu,
             ("f32_kernels" if precision == abi.F64 else "f64_kernels"): other,
         }
+        out.update(subs)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

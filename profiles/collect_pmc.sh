@@ -7,7 +7,7 @@ mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-other $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $ROOT/$OUT/$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-other --no-sub $BENCH_ARGS > $ROOT/$OUT/$name.log 2>&1
 }
 BENCH_ARGS="$*"
 if [ -n "$PMC_QUICK" ]; then

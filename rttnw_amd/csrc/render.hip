@@ -1251,8 +1251,11 @@ static int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_
 }
 
 template <typename R>
+// prepare_only: upload the scene on first use and grow every workspace buffer this render will need (blocking hipMalloc /
+// hipMemcpy / hipFree calls), launch nothing — rttnw_render_multi does that for ALL its ranks before the first launch, so
+// that no allocation (a device-wide synchronisation) sits between two ranks' kernels.
 int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
-                   rttnw_stats* stats, bool sync_for_stats = true) {
+                   rttnw_stats* stats, bool sync_for_stats = true, bool prepare_only = false) {
     HIP_TRY(hipSetDevice(d->device));
     DeviceScene<R>& ds = scene_of<R>(d);
     if (!ds.ready)
@@ -1295,7 +1298,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     const bool stream_hits_lds = stream_form_bytes(n4_all, s->flat.stack_depth, STREAM_BLOCK, sizeof(R), true) <= 160 * 1024;
     const bool streamf = kv && std::strcmp(kv, "stream") == 0 && stream_form_bytes(n4_all, s->flat.stack_depth, STREAM_BLOCK, sizeof(R), stream_hits_lds) <= 160 * 1024;
     if (streamf) plain = false;
-    HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
+    if (!prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
     DeviceCounters* dc = reinterpret_cast<DeviceCounters*>(d->job_counter + 1);
     auto persistent_grid = [&](const void* kernel, size_t lds_bytes, size_t waves_needed, size_t& grid) -> int {
         if (lds_bytes > 160 * 1024) { set_last_error("render: queues + traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
@@ -1339,7 +1342,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             const size_t waves_per_block = size_t(block) / 64;
             const size_t grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, ((n_jobs + 63) / 64 + waves_per_block - 1) / waves_per_block));
             if (int g = grow_spill(grid * size_t(block))) return g;
-            if (n_jobs > 0) {
+            if (n_jobs > 0 && !prepare_only) {
                 R bg0 = R(p->background[0]), bg1 = R(p->background[1]), bg2 = R(p->background[2]), tmin = R(p->t_min);
                 R* part = (R*)d->partial;
                 unsigned long long* jc = d->job_counter;
@@ -1369,7 +1372,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
             if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
             if (int g = grow_spill(grid * size_t(STREAM_BLOCK))) return g;
-            if (n_jobs > 0) {
+            if (n_jobs > 0 && !prepare_only) {
                 hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(STREAM_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
                                    R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
                                    (uint32_t*)d->pool_u, uint32_t(n_slots), (int32_t*)d->spill);
@@ -1385,7 +1388,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
             if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
             if (int g = grow_spill(grid * size_t(TRACE_BLOCK))) return g;
-            if (n_jobs > 0) {
+            if (n_jobs > 0 && !prepare_only) {
                 hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
                                    R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
                                    (uint32_t*)d->pool_u, uint32_t(n_slots), (int32_t*)d->spill);
@@ -1394,7 +1397,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         }
         return 0;
     };
-    if (stats) HIP_TRY(hipEventRecord(d->ev0, stream));
+    if (stats && !prepare_only) HIP_TRY(hipEventRecord(d->ev0, stream));
     for (uint32_t k = 0; k < n_pass; ++k) {
         const uint32_t s0 = pass_begin(p->spp, n_pass, k), s1 = pass_begin(p->spp, n_pass, k + 1);
         rc.spp = s1 - s0;                          // this pass's samples; the kernels see a render of [sample_begin, +spp)
@@ -1402,14 +1405,16 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         plan_chunks(rc, rc.spp, p->spp_chunk, uint64_t(L.n_tiles) * 64, 3 * sizeof(R)); // whole image: the same schedule on every rank
         if (!plan_jobs(rc)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
         if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(size_t(rc.jobs_per_chunk) * rc.n_chunks, 1) * 3 * sizeof(R))) return g;
-        if (k) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long), stream)); // the job counter only: statistics add up
+        if (k && !prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long), stream)); // the job counter only: statistics add up
         if (int g = trace_pass()) return g;
+        if (prepare_only) continue;
         if (stats && k + 1 == n_pass) HIP_TRY(hipEventRecord(d->ev1, stream));
         hipLaunchKernelGGL(resolve_kernel<R>, dim3((L.pixels_per_rank + 255) / 256), dim3(256), 0, stream, (const R*)d->partial,
                            (R*)d_packed, rc, L.pixels_per_rank, uint32_t(k == 0), uint32_t(k + 1 == n_pass), p->spp);
         HIP_TRY(hipGetLastError());
     }
     rc.spp = p->spp;
+    if (prepare_only) return RTTNW_OK;
 
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -1711,6 +1716,16 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
     if (int g = grow(&root->linear, &root->linear_bytes, npx * 3 * rsz)) return g;
     if (int g = grow((void**)&root->rgba, &root->rgba_bytes, npx * 4)) return g;
 
+    // ---- first use: scene uploads and workspace growth for EVERY rank, before anything is launched (a hipMalloc or a
+    // hipFree between two ranks' launches would synchronise its whole device)
+    for (uint32_t r = 0; r < ngpu; ++r) {
+        rttnw_params pr = p;
+        pr.tile_rank = r;
+        void* dst = (char*)st[r]->multi_packed + chunk * slot[r];
+        int rc = p.precision == RTTNW_F32 ? render_tiles_t<float>(s, st[r], cam, &pr, dst, st[r]->stream, nullptr, false, true)
+                                          : render_tiles_t<double>(s, st[r], cam, &pr, dst, st[r]->stream, nullptr, false, true);
+        if (rc) return rc;
+    }
     // ---- every rank traces its tiles, on its device's stream; ranks that share a device run one after the other
     std::vector<hipEvent_t> ev(size_t(ngpu) * 2, nullptr);
     struct EvFree { std::vector<hipEvent_t>& v; ~EvFree() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } ev_free{ev};
@@ -1729,8 +1744,13 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
         HIP_TRY(hipEventRecord(ev[2 * r + 1], d->stream));
     }
 
-    // ---- gather to the root: a device-to-device copy for ranks on the root's device, RCCL send/recv over xGMI for the others
-    if (distinct.size() > 1) {
+    // ---- gather to the root: a device-to-device copy for ranks on the root's device, RCCL send/recv over xGMI for the others.
+    // RTTNW_MULTI_FORCE_RCCL=1 (tests): the ranks on the root's device travel through RCCL too — a grouped ncclSend / ncclRecv
+    // of the root to itself — so that the dlopen'ed entry points, the communicator set-up, the stream ordering and the
+    // error paths run on a box with ONE GPU as well.
+    const char* force_env = getenv("RTTNW_MULTI_FORCE_RCCL");
+    const bool force_rccl = force_env && force_env[0] == '1';
+    if (distinct.size() > 1 || force_rccl) {
         if (!g_rccl.load(err)) { set_last_error("render_multi: " + err); return RTTNW_ERR_HIP; }
         MultiComms* mc = nullptr;
         for (MultiComms* c : g_comms)
@@ -1741,25 +1761,30 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
             mc->comms.resize(distinct.size());
             ncclResult_t nr = g_rccl.CommInitAll(mc->comms.data(), int(distinct.size()), distinct.data());
             if (nr != ncclSuccess) { set_last_error(std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr)); delete mc; return RTTNW_ERR_HIP; }
-            g_comms.push_back(mc);
+            g_comms.push_back(mc); // kept for the life of the process: communicator set-up costs ~100 ms; freed by the OS at exit
+            if (getenv("RTTNW_DEBUG_MULTI")) fprintf(stderr, "[render_multi] RCCL communicators over %zu device(s)\n", distinct.size());
         }
         ncclResult_t nr = g_rccl.GroupStart();
+        uint32_t n_sent = 0;
         for (uint32_t r = 0; r < ngpu && nr == ncclSuccess; ++r) {
             size_t k = 0;
             while (distinct[k] != device_ids[r]) ++k;
-            if (k == 0) continue; // on the root's device: copied below
+            if (k == 0 && !force_rccl) continue; // on the root's device: copied below
             const void* src = (const char*)st[r]->multi_packed + chunk * slot[r];
             nr = g_rccl.Send(src, chunk, ncclChar, 0, mc->comms[k], st[r]->stream);
             if (nr == ncclSuccess) nr = g_rccl.Recv((char*)root->gathered + chunk * r, chunk, ncclChar, int(k), mc->comms[0], root->stream);
+            ++n_sent;
         }
         ncclResult_t ne = g_rccl.GroupEnd();
         if (nr == ncclSuccess) nr = ne;
         if (nr != ncclSuccess) { set_last_error(std::string("RCCL gather: ") + g_rccl.GetErrorString(nr)); return RTTNW_ERR_HIP; }
+        if (getenv("RTTNW_DEBUG_MULTI")) fprintf(stderr, "[render_multi] %u rank buffer(s) of %zu bytes through ncclSend / ncclRecv\n", n_sent, chunk);
     }
     HIP_TRY(hipSetDevice(root->device));
-    for (uint32_t r = 0; r < ngpu; ++r)
-        if (device_ids[r] == root->device)
-            HIP_TRY(hipMemcpyAsync((char*)root->gathered + chunk * r, (const char*)root->multi_packed + chunk * slot[r], chunk, hipMemcpyDeviceToDevice, root->stream));
+    if (!force_rccl)
+        for (uint32_t r = 0; r < ngpu; ++r)
+            if (device_ids[r] == root->device)
+                HIP_TRY(hipMemcpyAsync((char*)root->gathered + chunk * r, (const char*)root->multi_packed + chunk * slot[r], chunk, hipMemcpyDeviceToDevice, root->stream));
     int rc = rttnw_untile_device(p.width, p.height, ngpu, p.precision, root->gathered, root->linear, root->rgba, root->stream);
     if (rc) return rc;
     for (size_t k = 0; k < distinct.size(); ++k) {

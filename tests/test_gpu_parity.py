@@ -469,3 +469,137 @@ def test_cli_writes_the_reference_image(gpu, oracle, scenes_lib, tmp_path):
     _, ro, _ = rto.render(so, cam, p)
     assert (got == ro).all(axis=2).mean() >= 0.999
     assert cli.main(["12"]) == 1                                                # "There is no scene 12", main.rs:179-182
+
+
+def _plan(hostsim, spp, w, h, rsz):
+    out = (C.c_uint32 * 6)()
+    n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
+    assert hostsim.lib.hostsim_plan(spp, 0, n_tiles, 1, 3 * rsz, out) == 0
+    return {"spp_chunk": out[0], "n_main": out[1], "n_chunks": out[2], "n_jobs": out[3], "n_pass": out[4], "first_pass_spp": out[5]}
+
+
+def test_config2_final_scene_800_at_spp_5000(gpu, oracle, hostsim, scenes_lib, earth):
+    """BASELINE configs[2] at its STATED spp: final_scene 800x800 spp=5000 in the F64 kernels.  At this size the chunk sums
+    of a 4-sample-chunk schedule exceed the library's real workspace budget, so the render runs as several passes over
+    consecutive sample ranges (rt_types.hpp plan_passes) — the path the other tests reach only with a shrunk budget.
+      * the plan (same header, host build) says so: more than one pass;
+      * samples, finiteness, alpha, the saturated light patch;
+      * the one-call render equals the mean of explicit renders of the passes' sample ranges (`sample_begin`) to rounding;
+      * two 64x64 crops — glass + blue-medium spheres, sphere cluster — equal the ORACLE's window render of the same frame to
+        1e-9 on >= 99.9 % of the pixels, RGBA8 identical."""
+    w = h = 800
+    spp = 5000
+    plan = _plan(hostsim, spp, w, h, 8)
+    assert plan["n_pass"] >= 2, plan
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
+    so, _ = util.build(oracle, scenes_lib, "final_scene", earth)
+    cam, p = util.params_for(setup, w, h, spp, precision=abi.F64)
+    lin, rgba, st = gpu_render(gpu, sc, cam, p)
+    assert st.samples == w * h * spp and st.kernel_ms > 0
+    assert np.isfinite(lin).all() and lin.min() >= 0 and (rgba[..., 3] == 255).all()
+    assert (rgba[20:60, 300:400, :3] == 255).all()                              # inside the ceiling light
+    # the passes as explicit renders: pass k covers [k * base + min(k, extra), ...) — rt_types.hpp pass_begin
+    n_pass = plan["n_pass"]
+    begin = lambda k: k * (spp // n_pass) + min(k, spp % n_pass)   # noqa: E731
+    total = np.zeros_like(lin)
+    for k in range(n_pass):
+        n = begin(k + 1) - begin(k)
+        _, pk = util.params_for(setup, w, h, n, precision=abi.F64, sample_begin=begin(k))
+        part, _, _ = gpu_render(gpu, sc, cam, pk)
+        total += part * n
+    assert np.abs(total / spp - lin).max() <= 1e-12 * max(1.0, lin.max())
+    for (x0, y0) in [(250, 550), (500, 280)]:
+        lo, ro, _, _ = rto.render_window(so, cam, p, x0, y0, x0 + 64, y0 + 64)
+        d = np.abs(lin[y0:y0 + 64, x0:x0 + 64] - lo).max(axis=2)
+        assert (d <= T1_ABS).mean() >= 0.999, (x0, y0, d.max())
+        assert (rgba[y0:y0 + 64, x0:x0 + 64] == ro).all(axis=2).mean() >= 0.999
+
+
+def test_config3_final_scene_1600_at_spp_10000_across_eight_ranks(gpu, oracle, hostsim, scenes_lib, earth):
+    """BASELINE configs[3] at its STATED size: final_scene 1600x1600 spp=10000, tile-sharded 8 ways, F64 kernels (ten passes
+    of 1000 spp under the workspace budget).  On one GPU: (i) ONE rank's share through the device-resident entry point —
+    what each of the 8 GPUs does — (ii) all 8 logical ranks through rttnw_render_multi, (iii) the single-rank render.
+    The 8-way image is BIT-identical to the single render, the rank's packed buffer is exactly its tiles of it, and two
+    64x32 crops equal the oracle's window render of the same frame to 1e-9 (RGBA8 identical)."""
+    import torch
+    w = h = 1600
+    spp = 10000
+    assert _plan(hostsim, spp, w, h, 8)["n_pass"] >= 2
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
+    so, _ = util.build(oracle, scenes_lib, "final_scene", earth)
+    cam, p = util.params_for(setup, w, h, spp, precision=abi.F64)
+    one, rgba, st = gpu_render(gpu, sc, cam, p)
+    assert st.samples == w * h * spp and np.isfinite(one).all() and (rgba[..., 3] == 255).all()
+    multi, rgba_m, sts = render.render_multi(sc, cam, p, [0] * 8)
+    assert np.array_equal(multi, one) and np.array_equal(rgba_m, rgba)
+    assert sum(x.samples for x in sts) == w * h * spp and all(x.kernel_ms > 0 for x in sts)
+    cam8, p8 = util.params_for(setup, w, h, spp, precision=abi.F64, tile_rank=5, tile_world=8)
+    dr = render.DeviceRenderer(sc, cam8, p8)
+    st5 = abi.Stats()
+    dr.trace(st5)
+    torch.cuda.synchronize()
+    assert st5.samples == w * h * spp // 8
+    assert np.array_equal(dr.packed.cpu().numpy()[:, :3], tiles.pack_rank(one, 5, 8)[:, :3])
+    for (x0, y0) in [(500, 1100), (1000, 576)]:
+        lo, ro, _, _ = rto.render_window(so, cam, p, x0, y0, x0 + 64, y0 + 32)
+        d = np.abs(one[y0:y0 + 32, x0:x0 + 64] - lo).max(axis=2)
+        assert (d <= T1_ABS).mean() >= 0.999, (x0, y0, d.max())
+        assert (rgba[y0:y0 + 32, x0:x0 + 64] == ro).all(axis=2).mean() >= 0.999
+
+
+_RCCL_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np
+from rttnw_amd import abi, library, render, scene as S
+gpu, scenes = library.product(), library.scenes()
+sc, setup = S.build(gpu, scenes, "final_scene", S.load_earth())
+for prec in (abi.F64, abi.F32):
+    cam, p = S.params_for(setup, 104, 72, 6, precision=prec, spp_chunk=3, seed=8)
+    one, rgba, _ = render.render_host(sc, cam, p)
+    for n in (1, 3, 8):
+        lin, rg, st = render.render_multi(sc, cam, p, [0] * n)
+        assert np.array_equal(lin, one) and np.array_equal(rg, rgba), (prec, n)
+print("RCCL_LEG_OK")
+"""
+
+
+def test_render_multi_gather_through_rccl_on_one_gpu(gpu, tmp_path):
+    """The RCCL leg of rttnw_render_multi on a box with ONE GPU: RTTNW_MULTI_FORCE_RCCL=1 sends the packed tiles of the ranks
+    that live on the root's device through a grouped ncclSend / ncclRecv of the root to itself instead of a device-to-device
+    copy, so the dlopen'ed entry points, ncclCommInitAll, the grouped calls on the ranks' streams and the un-tile behind them
+    run for real; the image must still equal rttnw_render's bit for bit.  In a child process with a time limit: a
+    communicator that hangs must fail the test, not the box."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_leg.py"
+    script.write_text(_RCCL_SCRIPT % {"root": root})
+    env = dict(os.environ, RTTNW_MULTI_FORCE_RCCL="1", RTTNW_DEBUG_MULTI="1", NCCL_DEBUG="VERSION")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_LEG_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "RCCL communicators over 1 device(s)" in r.stderr and "through ncclSend / ncclRecv" in r.stderr, r.stderr[-4000:]
+
+
+def test_bench_line_through_torch_distributed_with_one_rank(gpu):
+    """bench.py as the driver launches it for N > 1 — `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` — with
+    N = 1 and RTTNW_BENCH_FORCE_DIST=1: RCCL process group over one rank, barrier-bracketed timing, max-over-ranks all-reduce,
+    `dist.gather` of the packed tiles, ONE JSON line on stdout.  A fresh child process (the launcher starts the rank before
+    anything touches the GPU in it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTTNW_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0",
+           "--spp", "16", "--no-other"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
+    assert d["config"]["workload"].startswith("final_scene 800x800 spp=16") and d["roofline"]["kernel_ms"] > 0

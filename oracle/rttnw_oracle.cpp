@@ -1012,7 +1012,8 @@ static int render_pixels(rttnw_scene* s, const rttnw_camera_desc* cam, const rtt
     if (n_threads <= 0) n_threads = 1;
     // work unit = 16 consecutive pixels of a row (finer than the reference's rayon row/column split needs, but it
     // keeps hundreds of host threads busy to the end)
-    const uint32_t SEG = 16, segs_per_row = (WW + SEG - 1) / SEG;
+    // (long folds — thousands of samples per pixel on a small window — get shorter units: pixel costs differ several-fold)
+    const uint32_t SEG = spp >= 2048 ? 1 : (spp >= 256 ? 4 : 16), segs_per_row = (WW + SEG - 1) / SEG;
     std::atomic<uint32_t> next_unit{0};
     std::vector<Counters> counters(n_threads);
     const List& world_list = *s->world;

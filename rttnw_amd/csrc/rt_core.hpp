@@ -214,8 +214,12 @@ template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bo
 // Counter policies.  Their template flag GENERAL also selects, at compile time, whether the code for the rare graph shapes
 // (more than FAST_INSTANCE_OPS wrappers around an object, List / BvhTree medium boundaries, media inside transformed groups;
 // FlatScene::needs_general) is compiled into a kernel at all: it costs the common kernels registers even when it never runs.
-template <bool G> struct NoCountersT {
+// EXACT_UV: a sphere's (u, v) are always evaluated with the reference's f64 acos / atan2 at the hit (the per-bounce probes, which
+// report them); otherwise the f64 kernels defer them to the one place that reads them, the image texture's texel choice,
+// and make that choice in f32 wherever f32 is certain of it (texture_value).
+template <bool G, bool XUV = false> struct NoCountersT {
     static constexpr bool GENERAL = G;
+    static constexpr bool EXACT_UV = XUV;
     RT_HD void ray() {}
     RT_HD void node() {}
     RT_HD void prim() {}
@@ -223,13 +227,15 @@ template <bool G> struct NoCountersT {
 };
 template <bool G> struct LaneCountersT {
     static constexpr bool GENERAL = G;
+    static constexpr bool EXACT_UV = false;
     uint32_t rays = 0, nodes = 0, prims = 0, texels = 0;
     RT_HD void ray() { ++rays; }
     RT_HD void node() { ++nodes; }
     RT_HD void prim() { ++prims; }
     RT_HD void texel() { ++texels; }
 };
-using NoCounters = NoCountersT<true>;     // host build, probes: every shape
+using NoCounters = NoCountersT<true>;     // host build: every shape
+using ProbeCounters = NoCountersT<true, true>; // the per-bounce probes: every shape, (u, v) evaluated at every hit that reads them
 using LaneCounters = LaneCountersT<true>;
 
 // ---------------------------------------------------------------- camera (camera.rs:63-84)
@@ -827,6 +833,7 @@ template <typename R> struct HitRecord { // hittable.rs:15-27
     R u, v;
     int32_t mat;
     bool front_face;
+    bool uv_deferred; // a sphere's (u, v) have not been evaluated: `normal` (= +-outward, by front_face) still determines them
 };
 template <typename R> RT_HD void face_normal(V3<R> dir, V3<R> outward, V3<R>& normal, bool& front) { // hittable.rs:30-44
     front = dot(dir, outward) < R(0);
@@ -844,9 +851,10 @@ template <typename R> RT_HD void sphere_uv(V3<R> p, R& u, R& v) { // hittable.rs
 // an image texture — possibly under a checker — ever reads them: they are computed only then.  Same results.
 RT_HD bool uv_is_read(int32_t mat_ref) { return (mat_ref & MAT_UV_FLAG) != 0; } // decided by the lowering, see MAT_UV_FLAG
 
-template <bool G, typename R>
+template <bool G, bool XUV = true, typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim);
+    rec.uv_deferred = false;
     uint32_t idx = ref_index(ref.prim);
     if (kind == PRIM_SPHERE && ref.inst < 0) { // the world-space copy of a transformed group's sphere: its record is made in
         const int32_t home = sc.sphere_mat[idx]; // object space through the group's chain, like the reference's (scene_lower.cpp)
@@ -864,7 +872,17 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         const int32_t mref = sc.sphere_mat[idx];
         rec.mat = mref & MAT_INDEX_MASK;
         rec.u = R(0); rec.v = R(0);
-        if (uv_is_read(mref)) sphere_uv(outward, rec.u, rec.v);
+        if (uv_is_read(mref)) {
+            // f64: Sphere::uv's acos + atan2 (hittable.rs:77-83) are ~250 instructions that the whole wave issues for the few
+            // lanes on an image-textured sphere, and all they feed is a nearest-texel index (texture.rs:78-101).  An untransformed
+            // sphere leaves them to texture_value(): `normal` is +-outward exactly, nothing else is needed.
+            if constexpr (sizeof(R) == 8 && !XUV) {
+                if (ref.inst < 0) rec.uv_deferred = true;
+                else sphere_uv(outward, rec.u, rec.v);
+            } else {
+                sphere_uv(outward, rec.u, rec.v);
+            }
+        }
     } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
         const MovingSphereRec<R> m = sc.moving[idx];
         rec.p = ray.at(t);
@@ -1005,6 +1023,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         rec.t = closest;
         rec.normal = V3<R>(R(1), R(0), R(0));
         rec.front_face = true;
+        rec.uv_deferred = false;
         rec.u = R(0); rec.v = R(0);
         rec.mat = md.mat;
         rec.p = ray.at(closest);
@@ -1015,7 +1034,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
                 unwind_record<true>(in, md.n_outer, ray.d, quirks, rec.p, rec.normal, rec.front_face);
             }
     } else {
-        make_record<Cnt::GENERAL>(sc, ray, best, closest, quirks, rec);
+        make_record<Cnt::GENERAL, Cnt::EXACT_UV>(sc, ray, best, closest, quirks, rec);
     }
     return true;
 }
@@ -1061,8 +1080,49 @@ template <typename R> RT_HD R perlin_turbulence(const R* vec, const uint8_t* per
     return acc;
 }
 
+// The texel an image texture reads at (u, v) — texture.rs:78-101: clamp, flip v, `as u32` (NaN -> 0, saturating), clamp to the last one.
+template <typename R> RT_HD void image_texel(const ImageRec& im, R u, R v, uint32_t& i, uint32_t& j) {
+    if (u < R(0)) u = R(0);
+    if (u > R(1)) u = R(1);
+    if (v < R(0)) v = R(0);
+    if (v > R(1)) v = R(1);
+    v = R(1) - v;
+    R fi = u * R(im.w), fj = v * R(im.h);
+    i = (fi == fi && fi > R(0)) ? uint32_t(fi) : 0u;
+    j = (fj == fj && fj > R(0)) ? uint32_t(fj) : 0u;
+    if (i >= im.w) i = im.w - 1;
+    if (j >= im.h) j = im.h - 1;
+}
+// The same texel for a sphere hit whose (u, v) were deferred (make_record), from the outward unit normal n.  Sphere::uv
+// (hittable.rs:77-83) in f32 first: theta = acos(-n.y), phi = atan2(-n.z, n.x) + pi, texel = (phi / 2 pi * w, (1 - theta / pi) * h).
+// With n rounded to f32 (relative 2^-24 per component) and OCML's acosf / atan2f (<= 2-3 ulp):
+//   |d phi|   <= 2^-23 (conditioning of atan2 in its two inputs) + 3 ulp(2 pi)            < 2.0e-6 rad -> < 3.2e-7 w texels
+//   |d theta| <= 2^-24 / sqrt(1 - n.y^2) + 3 ulp(pi)  <= 2^-24 * 22.4 + 7.2e-7 < 2.1e-6 rad -> < 6.7e-7 h texels  while |n.y| <= 0.999
+// so a texel coordinate farther than 4e-6 w (8e-6 h) from the nearest integer — six and twelve times those bounds — is on the
+// same side of it in f64 and the f32 index IS the reference's index; nearer than that, or within 0.001 of a pole, the f64
+// expressions decide (about 1.5 % of the hits of a 1200 x 600 map).  Either way the texel is the reference's.
+template <typename R> RT_HD void image_texel_deferred(const ImageRec& im, V3<R> n, uint32_t& i, uint32_t& j) {
+    const float nx = float(n.x), ny = float(n.y), nz = float(n.z);
+    const float pi = 3.14159265358979323846f;
+    const float theta = acosf(-ny), phi = atan2f(-nz, nx) + pi;
+    const float fw = float(im.w), fh = float(im.h);
+    const float fi = phi * (0.15915494309189533577f * fw), fj = (1.0f - theta * 0.31830988618379067154f) * fh;
+    const float ri = rintf(fi), rj = rintf(fj);
+    const bool sure = rt_fabs(fi - ri) > 4e-6f * fw && rt_fabs(fj - rj) > 8e-6f * fh && rt_fabs(ny) <= 0.999f && fi > 0.f && fj > 0.f &&
+                      fi < fw && fj < fh;
+    if (sure) {
+        i = uint32_t(fi);
+        j = uint32_t(fj);
+    } else {
+        R u, v;
+        sphere_uv(n, u, v);
+        image_texel(im, u, v, i, j);
+    }
+}
+
 template <typename R, typename Cnt>
-RT_HD V3<R> texture_value(const SceneView<R>& sc, int32_t tex, R u, R v, V3<R> p, Cnt& cnt) {
+RT_HD V3<R> texture_value(const SceneView<R>& sc, int32_t tex, const HitRecord<R>& rec, Cnt& cnt) {
+    const V3<R> p = rec.p;
     for (;;) {
         const TextureRec<R>& t = sc.texs[tex];
         if (t.type == TEX_CHECKER) { // texture.rs:20-29
@@ -1079,16 +1139,9 @@ RT_HD V3<R> texture_value(const SceneView<R>& sc, int32_t tex, R u, R v, V3<R> p
         }
         if (t.type == TEX_IMAGE) { // texture.rs:78-101
             const ImageRec im = sc.images[t.a];
-            if (u < R(0)) u = R(0);
-            if (u > R(1)) u = R(1);
-            if (v < R(0)) v = R(0);
-            if (v > R(1)) v = R(1);
-            v = R(1) - v;
-            R fi = u * R(im.w), fj = v * R(im.h);
-            uint32_t i = (fi == fi && fi > R(0)) ? uint32_t(fi) : 0u; // `as u32`: NaN -> 0, saturating
-            uint32_t j = (fj == fj && fj > R(0)) ? uint32_t(fj) : 0u;
-            if (i >= im.w) i = im.w - 1;
-            if (j >= im.h) j = im.h - 1;
+            uint32_t i, j;
+            if (rec.uv_deferred) image_texel_deferred(im, rec.front_face ? rec.normal : -rec.normal, i, j);
+            else image_texel(im, rec.u, rec.v, i, j);
             cnt.texel();
             uint32_t px = sc.texels[im.offset + size_t(j) * im.w + i];
             const R s = R(1) / R(255);
@@ -1101,7 +1154,7 @@ RT_HD V3<R> texture_value(const SceneView<R>& sc, int32_t tex, R u, R v, V3<R> p
 template <typename R, typename Cnt>
 RT_HD V3<R> material_color(const SceneView<R>& sc, const MaterialRec<R>& m, const HitRecord<R>& rec, Cnt& cnt) {
     if (m.tex < 0) return V3<R>(m.albedo);
-    return texture_value(sc, m.tex, rec.u, rec.v, rec.p, cnt);
+    return texture_value(sc, m.tex, rec, cnt);
 }
 
 // ---------------------------------------------------------------- scatter (material.rs)

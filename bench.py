@@ -58,7 +58,8 @@ N_SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (same table)
 VALU_CYCLES = {"f32": 2.0, "f64": 4.0}   # cycles per wave64 VALU instruction: f32 2 (SIMD-32, per-instruction table), f64 at half rate (78.6 vs 157.3 TFLOP/s)
 NODE_VISIT_BYTES = 32.0  # ONE 32-B accounting record per node visit, whatever a record physically holds
 PROFILE_ROUND = "r03"
-KERNEL_SOURCES = ["rttnw_amd/csrc/render.hip", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp", "rttnw_amd/csrc/Makefile"]
+KERNEL_SOURCES = ["rttnw_amd/csrc/trace_kernels.hpp", "rttnw_amd/csrc/render_tiles.hpp", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp",
+                  "rttnw_amd/csrc/Makefile"]
 
 
 def log(*a):

@@ -1,0 +1,195 @@
+// render_common.hpp — host-side state of the device half of include/rttnw_hip.h, shared by its translation units:
+//   render_api.cpp   the extern "C" entry points, device state, rttnw_render_multi + RCCL (host code only)
+//   render_f32.hip   the F32 instantiation of the kernels (trace_kernels.hpp) and of their launch code (render_tiles.hpp)
+//   render_f64.hip   the F64 instantiation — a translation unit of its own because its code wants other compiler settings
+//                    than the f32 code (Makefile: machine LICM off, 1024-thread blocks) and because the two halves build in
+//                    parallel.
+#pragma once
+#include "../../include/rttnw_hip.h"
+#include "rt_core.hpp"
+#include "scene_handle.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <type_traits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace rt {
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_last_error(std::string(#expr) + ": " + hipGetErrorString(e_));             \
+            return RTTNW_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int upload(const std::vector<T>& v) {
+        release();
+        n = v.size();
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        HIP_TRY(hipMalloc((void**)&p, bytes));
+        if (n) HIP_TRY(hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+template <typename R> struct DeviceScene {
+    bool ready = false;
+    DevBuf<Bvh4Node> nodes;
+    DevBuf<SphereRec<R>> spheres;
+    DevBuf<int32_t> sphere_mat, sphere_seq;
+    DevBuf<MovingSphereRec<R>> moving;
+    DevBuf<RectRec<R>> rects;
+    DevBuf<BoxRec<R>> boxes;
+    DevBuf<InstanceRec<R>> insts;
+    DevBuf<MediumRec<R>> media;
+    DevBuf<int32_t> medium_refs;
+    DevBuf<MaterialRec<R>> mats;
+    DevBuf<TextureRec<R>> texs;
+    DevBuf<ImageRec> images;
+    DevBuf<uint32_t> texels;
+    DevBuf<R> perlin_vec;
+    DevBuf<uint8_t> perlin_perm;
+    SceneView<R> view{};
+    size_t bytes = 0;
+
+    int upload(const FlatScene& f) {
+        std::vector<SphereRec<R>> sp;
+        for (auto& s : f.spheres) sp.push_back({R(s.cx), R(s.cy), R(s.cz), R(s.r)});
+        std::vector<MovingSphereRec<R>> mv;
+        for (auto& m : f.moving) {
+            MovingSphereRec<R> o{};
+            for (int k = 0; k < 3; ++k) { o.c0[k] = R(m.c0[k]); o.c1[k] = R(m.c1[k]); }
+            o.r = R(m.r); o.t0 = R(m.t0); o.t1 = R(m.t1); o.mat = m.mat; o.seq = m.seq;
+            mv.push_back(o);
+        }
+        std::vector<RectRec<R>> rc_;
+        for (auto& r : f.rects) rc_.push_back({R(r.a0), R(r.a1), R(r.b0), R(r.b1), R(r.k), r.plane, r.mat, r.seq});
+        std::vector<BoxRec<R>> bx;
+        for (auto& b : f.boxes) {
+            BoxRec<R> o{};
+            for (int k = 0; k < 3; ++k) { o.mn[k] = R(b.mn[k]); o.mx[k] = R(b.mx[k]); }
+            o.mat = b.mat; o.seq = b.seq;
+            bx.push_back(o);
+        }
+        std::vector<InstanceRec<R>> in;
+        for (auto& i : f.insts) {
+            InstanceRec<R> o{};
+            o.n_ops = i.n_ops; o.root = i.root; o.single_leaf = i.single_leaf;
+            for (int k = 0; k < MAX_INSTANCE_OPS; ++k) {
+                o.ops[k].type = i.ops[k].type;
+                for (int c = 0; c < 3; ++c) o.ops[k].v[c] = R(i.ops[k].v[c]);
+            }
+            in.push_back(o);
+        }
+        std::vector<MediumRec<R>> md;
+        for (auto& m : f.media) md.push_back({m.b_first, m.b_count, m.inst, m.n_outer, m.mat, m.ref0, R(m.neg_inv_density)});
+        std::vector<MaterialRec<R>> mt;
+        for (auto& m : f.mats) mt.push_back({m.type, m.tex, {R(m.albedo[0]), R(m.albedo[1]), R(m.albedo[2])}, R(m.param)});
+        std::vector<TextureRec<R>> tx;
+        for (auto& t : f.texs) tx.push_back({t.type, t.a, t.b, 0, {R(t.color[0]), R(t.color[1]), R(t.color[2])}, R(t.scale)});
+        std::vector<R> pv;
+        for (double v : f.perlin_vec) pv.push_back(R(v));
+
+        int rc;
+        if ((rc = nodes.upload(f.nodes4)) || (rc = spheres.upload(sp)) || (rc = sphere_mat.upload(f.sphere_mat)) ||
+            (rc = sphere_seq.upload(f.sphere_seq)) || (rc = moving.upload(mv)) || (rc = rects.upload(rc_)) ||
+            (rc = boxes.upload(bx)) || (rc = insts.upload(in)) || (rc = media.upload(md)) || (rc = medium_refs.upload(f.medium_refs)) || (rc = mats.upload(mt)) ||
+            (rc = texs.upload(tx)) || (rc = images.upload(f.images)) || (rc = texels.upload(f.texels)) ||
+            (rc = perlin_vec.upload(pv)) || (rc = perlin_perm.upload(f.perlin_perm)))
+            return rc;
+        view.nodes = nodes.p; view.spheres = spheres.p; view.sphere_mat = sphere_mat.p; view.sphere_seq = sphere_seq.p;
+        view.moving = moving.p; view.rects = rects.p; view.boxes = boxes.p; view.insts = insts.p; view.media = media.p; view.medium_refs = medium_refs.p;
+        view.mats = mats.p; view.texs = texs.p; view.images = images.p; view.texels = texels.p;
+        view.perlin_vec = perlin_vec.p; view.perlin_perm = perlin_perm.p;
+        view.top_root = f.top_root;
+        view.n_media = int32_t(f.media.size());
+        bytes = f.nodes4.size() * sizeof(Bvh4Node) + sp.size() * sizeof(SphereRec<R>) + mv.size() * sizeof(MovingSphereRec<R>) +
+                rc_.size() * sizeof(RectRec<R>) + bx.size() * sizeof(BoxRec<R>) + in.size() * sizeof(InstanceRec<R>);
+        ready = true;
+        return 0;
+    }
+    void release() {
+        nodes.release(); spheres.release(); sphere_mat.release(); sphere_seq.release(); moving.release(); rects.release();
+        boxes.release(); insts.release(); media.release(); medium_refs.release(); mats.release(); texs.release(); images.release();
+        texels.release(); perlin_vec.release(); perlin_perm.release();
+        ready = false;
+    }
+};
+
+struct DeviceState {
+    int device = -1;
+    int num_cus = 0;
+    DeviceScene<float> s32;
+    DeviceScene<double> s64;
+    // workspace, grown on demand and kept
+    void* partial = nullptr;
+    size_t partial_bytes = 0;
+    void* pool_r = nullptr; size_t pool_r_bytes = 0; // path-slot state (reals / words), SoA over all slots
+    void* pool_u = nullptr; size_t pool_u_bytes = 0;
+    void* spill = nullptr; size_t spill_bytes = 0;   // traversal-stack entries beyond LDS_STACK_ENTRIES, per thread of the launch
+    unsigned long long* job_counter = nullptr; // [0] job counter, then DeviceCounters
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;              // rttnw_render_multi: this device's launch stream
+    void* multi_packed = nullptr; size_t multi_packed_bytes = 0; // packed tiles of the logical ranks living on this device
+    void* gathered = nullptr; size_t gathered_bytes = 0;         // root device: every rank's packed tiles
+    // scratch for the blocking host-output render()
+    void* packed = nullptr; size_t packed_bytes = 0;
+    void* linear = nullptr; size_t linear_bytes = 0;
+    uint8_t* rgba = nullptr; size_t rgba_bytes = 0;
+};
+
+int grow(void** p, size_t* have, size_t want); // a workspace buffer kept at its high-water mark (render_api.cpp)
+int device_state_create(DeviceState*& out, std::string& err);
+
+template <typename R> DeviceScene<R>& scene_of(DeviceState* d);
+template <> inline DeviceScene<float>& scene_of<float>(DeviceState* d) { return d->s32; }
+template <> inline DeviceScene<double>& scene_of<double>(DeviceState* d) { return d->s64; }
+
+template <typename R> CameraRec<R> narrow_camera(const CameraRec<double>& c) {
+    CameraRec<R> o;
+    for (int k = 0; k < 3; ++k) {
+        o.origin[k] = R(c.origin[k]); o.lower_left_corner[k] = R(c.lower_left_corner[k]);
+        o.horizontal[k] = R(c.horizontal[k]); o.vertical[k] = R(c.vertical[k]); o.u[k] = R(c.u[k]); o.v[k] = R(c.v[k]);
+    }
+    o.lens_radius = R(c.lens_radius); o.open_time = R(c.open_time); o.close_time = R(c.close_time);
+    return o;
+}
+
+void fill_layout(uint32_t w, uint32_t h, uint32_t world, rttnw_tile_layout& L);
+int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p);
+
+// The launch code of one precision (render_tiles.hpp), instantiated in render_f32.hip / render_f64.hip.
+template <typename R>
+int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
+                   rttnw_stats* stats, bool sync_for_stats = true, bool prepare_only = false);
+template <typename R>
+int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row, uint32_t sample,
+                 double* out, uint32_t max_out);
+template <typename R>
+int untile_launch(uint32_t width, uint32_t height, uint32_t world, const void* d_gathered, void* d_linear_rgb, uint8_t* d_rgba8, hipStream_t stream);
+extern template int render_tiles_t<float>(::rttnw_scene*, DeviceState*, const rttnw_camera_desc*, const rttnw_params*, void*, hipStream_t, rttnw_stats*, bool, bool);
+extern template int render_tiles_t<double>(::rttnw_scene*, DeviceState*, const rttnw_camera_desc*, const rttnw_params*, void*, hipStream_t, rttnw_stats*, bool, bool);
+extern template int probe_path_t<float>(::rttnw_scene*, const rttnw_camera_desc*, const rttnw_params*, uint32_t, uint32_t, uint32_t, double*, uint32_t);
+extern template int probe_path_t<double>(::rttnw_scene*, const rttnw_camera_desc*, const rttnw_params*, uint32_t, uint32_t, uint32_t, double*, uint32_t);
+extern template int untile_launch<float>(uint32_t, uint32_t, uint32_t, const void*, void*, uint8_t*, hipStream_t);
+extern template int untile_launch<double>(uint32_t, uint32_t, uint32_t, const void*, void*, uint8_t*, hipStream_t);
+
+} // namespace rt

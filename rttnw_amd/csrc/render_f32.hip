@@ -1,0 +1,6 @@
+// render_f32.hip — the F32 (throughput) kernels and their launch code: one translation unit per precision (render_common.hpp).
+#include "render_tiles.hpp"
+
+namespace rt {
+RT_INSTANTIATE_PRECISION(float)
+} // namespace rt

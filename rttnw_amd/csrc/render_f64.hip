@@ -1,0 +1,7 @@
+// render_f64.hip — the F64 kernels (the reference's arithmetic) and their launch code: one translation unit per precision
+// (render_common.hpp); built with its own flags (Makefile HIPFLAGS_F64).
+#include "render_tiles.hpp"
+
+namespace rt {
+RT_INSTANTIATE_PRECISION(double)
+} // namespace rt

@@ -1,0 +1,254 @@
+// render_tiles.hpp — launch code of one precision: rttnw_render_tiles_device's body (passes, kernel selection, workspace),
+// the per-bounce probe and the un-tile launch, as templates over the arithmetic type.
+#pragma once
+#include "trace_kernels.hpp"
+
+namespace rt {
+
+// prepare_only: upload the scene on first use and grow every workspace buffer this render will need (blocking hipMalloc /
+// hipMemcpy / hipFree calls), launch nothing — rttnw_render_multi does that for ALL its ranks before the first launch, so
+// that no allocation (a device-wide synchronisation) sits between two ranks' kernels.
+template <typename R>
+int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
+                   rttnw_stats* stats, bool sync_for_stats, bool prepare_only) {
+    HIP_TRY(hipSetDevice(d->device));
+    DeviceScene<R>& ds = scene_of<R>(d);
+    if (!ds.ready)
+        if (int rc = ds.upload(s->flat)) return rc;
+
+    rttnw_tile_layout L;
+    fill_layout(p->width, p->height, p->tile_world, L);
+    RenderConsts rc{};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
+    rc.tiles_x = L.tiles_x; rc.tiles_y = L.tiles_y; rc.n_tiles = L.n_tiles;
+    rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;
+    rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
+    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    rc.profile = p->collect_counters;
+    rc.sample_begin = p->sample_begin;
+    rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
+    // Passes over consecutive sample ranges (rt_types.hpp plan_passes): one for ordinary renders; more when the chunk
+    // sums of the whole render would not fit the workspace budget.  Decided by the image size and spp alone.
+    const uint32_t n_pass = plan_passes(p->spp, p->spp_chunk, uint64_t(L.n_tiles) * 64, 3 * sizeof(R));
+
+    CameraRec<double> cam64;
+    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
+                cam->focus_distance, cam->open_time, cam->close_time, cam64);
+    const CameraRec<R> camr = narrow_camera<R>(cam64);
+
+    const bool count = p->collect_counters != 0;
+    // Two forms of the same loop (DESIGN.md "Kernels"): measured on MI355X the lane-owns-a-path form wins on shallow
+    // scenes (cornell_box, final_scene: <= ~1k nodes), the decoupled form on deep BVHs where traversal lengths vary
+    // most (1M spheres).  RTTNW_KERNEL=plain|plainglobal|wave overrides the choice (experiments only).
+    const char* kv = getenv("RTTNW_KERNEL");
+    // (crossover measured on spheres_1m-like scenes of 2e4 - 2.5e5 spheres, 512x512 spp 256: f32 at ~24 k 4-wide nodes — 19.6 k:
+    // 3105 against 2972 Msamples/s, 28.3 k: 2258 against 2452 — f64 at ~50 k — 28.3 k: 2022 against 1740, 50.9 k: 1284 against 1318)
+    bool plain = s->flat.nodes4.size() < (sizeof(R) == 4 ? 24576u : 49152u);
+    if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
+    if (kv && std::strcmp(kv, "wave") == 0) plain = false;
+    if (!prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
+    DeviceCounters* dc = reinterpret_cast<DeviceCounters*>(d->job_counter + 1);
+    auto persistent_grid = [&](const void* kernel, size_t lds_bytes, size_t waves_needed, size_t& grid) -> int {
+        if (lds_bytes > 160 * 1024) { set_last_error("render: queues + traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+        int blocks_per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, TRACE_BLOCK, lds_bytes));
+        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+        // what the chip holds at once (no inter-workgroup dependency, so a little over-subscription is harmless),
+        // but never more waves than there is work for
+        grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + 3) / 4));
+        return 0;
+    };
+    // stack entries beyond the LDS-resident ones, for every thread of a launch
+    auto grow_spill = [&](size_t threads, uint32_t lds_entries = LDS_STACK_ENTRIES) -> int {
+        const size_t extra = rc.stack_depth > lds_entries ? rc.stack_depth - lds_entries : 0;
+        return grow(&d->spill, &d->spill_bytes, std::max<size_t>(threads * extra, 1) * sizeof(int32_t));
+    };
+    // One pass: trace kernel over the pass's jobs, then the resolve step.
+    auto trace_pass = [&]() -> int {
+        const size_t n_jobs = rc.n_jobs;
+        if (plain) {
+            // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
+            // 1024 threads (4 waves/SIMD at <= 128 VGPRs) for f32, 512 threads (2 waves/SIMD, all the 256-VGPR f64 code allows)
+            constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : RT_F64_BLOCK;
+            const uint32_t n4 = uint32_t(s->flat.nodes4.size());
+            const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) <= 160 * 1024;
+            rc.lds_nodes = want_lds ? n4 : 0u;
+            const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
+            const bool gen = s->flat.needs_general; // rare graph shapes: the instantiation that carries their code
+            const void* kernel =
+                want_lds ? (count ? (gen ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, false>)
+                                  : (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false>))
+                         : (count ? (gen ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, false>)
+                                  : (gen ? (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false, false>));
+            const size_t lds_bytes = lds_form_bytes(want_lds ? n4 : 0u, rc.stack_depth, uint32_t(block));
+            if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
+            HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
+            int blocks_per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, lds_bytes));
+            blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+            const size_t waves_per_block = size_t(block) / 64;
+            const size_t grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, ((n_jobs + 63) / 64 + waves_per_block - 1) / waves_per_block));
+            if (int g = grow_spill(grid * size_t(block))) return g;
+            if (n_jobs > 0 && !prepare_only) {
+                R bg0 = R(p->background[0]), bg1 = R(p->background[1]), bg2 = R(p->background[2]), tmin = R(p->t_min);
+                R* part = (R*)d->partial;
+                unsigned long long* jc = d->job_counter;
+                SceneView<R> view = ds.view;
+                CameraRec<R> camv = camr;
+                int32_t* sp = (int32_t*)d->spill;
+                void* args[] = {&view, &camv, &rc, &bg0, &bg1, &bg2, &tmin, &part, &jc, &dc, &sp};
+                HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
+            }
+        } else {
+            const bool gen = s->flat.needs_general;
+            auto kernel = count ? (gen ? trace_kernel<R, true, true> : trace_kernel<R, true, false>) : (gen ? trace_kernel<R, false, true> : trace_kernel<R, false, false>);
+            const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
+            size_t grid = 1;
+            if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
+            const size_t n_slots = grid * (TRACE_BLOCK / 64) * SLOTS_PER_WAVE;
+            if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
+            if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
+            if (int g = grow_spill(grid * size_t(TRACE_BLOCK), wave_stack_entries<R>())) return g;
+            if (n_jobs > 0 && !prepare_only) {
+                hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
+                                   R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
+                                   (uint32_t*)d->pool_u, uint32_t(n_slots), (int32_t*)d->spill);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        return 0;
+    };
+    if (stats && !prepare_only) HIP_TRY(hipEventRecord(d->ev0, stream));
+    for (uint32_t k = 0; k < n_pass; ++k) {
+        const uint32_t s0 = pass_begin(p->spp, n_pass, k), s1 = pass_begin(p->spp, n_pass, k + 1);
+        rc.spp = s1 - s0;                          // this pass's samples; the kernels see a render of [sample_begin, +spp)
+        rc.sample_begin = uint64_t(p->sample_begin) + s0;
+        plan_chunks(rc, rc.spp, p->spp_chunk, uint64_t(L.n_tiles) * 64, 3 * sizeof(R)); // whole image: the same schedule on every rank
+        if (!plan_jobs(rc)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
+        if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(size_t(rc.jobs_per_chunk) * rc.n_chunks, 1) * 3 * sizeof(R))) return g;
+        if (k && !prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long), stream)); // the job counter only: statistics add up
+        if (int g = trace_pass()) return g;
+        if (prepare_only) continue;
+        if (stats && k + 1 == n_pass) HIP_TRY(hipEventRecord(d->ev1, stream));
+        hipLaunchKernelGGL(resolve_kernel<R>, dim3((L.pixels_per_rank + 255) / 256), dim3(256), 0, stream, (const R*)d->partial,
+                           (R*)d_packed, rc, L.pixels_per_rank, uint32_t(k == 0), uint32_t(k + 1 == n_pass), p->spp);
+        HIP_TRY(hipGetLastError());
+    }
+    rc.spp = p->spp;
+    if (prepare_only) return RTTNW_OK;
+
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        if (sync_for_stats) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+            stats->kernel_ms = ms;
+        }
+        // samples traced by this rank: pixels of its tiles that lie inside the image
+        uint64_t px_count = 0;
+        for (uint32_t t = 0; t < rc.my_tiles; ++t) {
+            uint32_t tx, ty;
+            tile_unpermute(rc.tile_rank + t * rc.tile_world, rc.tiles_x, tx, ty);
+            uint32_t w = std::min(8u, rc.width - tx * 8), h = std::min(8u, rc.height - ty * 8);
+            px_count += uint64_t(w) * h;
+        }
+        stats->samples = px_count * rc.spp;
+        if (count && sync_for_stats) {
+            DeviceCounters hc;
+            HIP_TRY(hipMemcpy(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
+            stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
+            if (getenv("RTTNW_DEBUG_SCHED") && plain) {
+                const double tot = double(hc.dbg[0] + hc.dbg[1] + hc.dbg[2] + hc.dbg[3]);
+                fprintf(stderr, "[plain] wave clock: hand-out %.1f%%  begin %.1f%%  walk %.1f%%  shade %.1f%% (media + hit record %.1f%%, material %.1f%%)\n", 100 * hc.dbg[0] / tot,
+                        100 * hc.dbg[1] / tot, 100 * hc.dbg[2] / tot, 100 * hc.dbg[3] / tot, 100 * hc.dbg[15] / tot, 100 * (hc.dbg[3] - hc.dbg[15]) / tot);
+                fprintf(stderr, "[plain] walk: %.1f lockstep iterations/round (%.1f with node lanes, %.1f with leaf lanes); lanes served per iteration %.1f of 64\n",
+                        double(hc.dbg[4]) / hc.dbg[9], double(hc.dbg[7]) / hc.dbg[9], double(hc.dbg[8]) / hc.dbg[9],
+                        double(hc.dbg[5] + hc.dbg[6]) / hc.dbg[4]);
+                fprintf(stderr, "[plain] walk clock: node steps %.1f%%, leaf steps %.1f%% of the walk\n", 100.0 * hc.dbg[13] / hc.dbg[2], 100.0 * hc.dbg[14] / hc.dbg[2]);
+                for (uint32_t m = 1; m < 64; ++m)
+                    if (hc.dbg[80 + m] * 200 > hc.dbg[8])
+                        fprintf(stderr, "[plain]   leaf iterations serving {%s%s%s%s%s%s}: %.1f%% of them, %.1f%% of the leaf clock, %.0f clocks each\n", m & 1 ? "sphere " : "",
+                                m & 2 ? "moving " : "", m & 4 ? "rect " : "", m & 8 ? "box " : "", m & 16 ? "instance " : "", m & 32 ? "empty " : "",
+                                100.0 * hc.dbg[80 + m] / hc.dbg[8], 100.0 * hc.dbg[16 + m] / hc.dbg[14], double(hc.dbg[16 + m]) / hc.dbg[80 + m]);
+                fprintf(stderr, "[plain]   node iterations: %.0f clocks each\n", double(hc.dbg[13]) / hc.dbg[7]);
+                if (rc.profile == 3u) { // collect_counters = 3: distribution of walk lengths, in trips
+                    fprintf(stderr, "[plain] trips per walk (lanes):");
+                    for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", hc.dbg[16 + k]);
+                    fprintf(stderr, "\n[plain] walks / mean trips by result (miss, sphere, moving, rect, box, -, in instance):");
+                    for (int k = 0; k < 7; ++k) fprintf(stderr, " %llu / %.1f", hc.dbg[152 + k], hc.dbg[152 + k] ? double(hc.dbg[144 + k]) / hc.dbg[152 + k] : 0.0);
+                    fprintf(stderr, "\n[plain] trips of the longest walk per round (waves):");
+                    for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", hc.dbg[80 + k]);
+                    fprintf(stderr, "\n");
+                }
+                fprintf(stderr, "[plain] node lanes per node iteration %.1f, leaf lanes per leaf iteration %.1f; rounds/sample %.2f, lanes alive per round %.1f; begin in %.0f%% of rounds, %.1f lanes each\n",
+                        double(hc.dbg[5]) / hc.dbg[7], double(hc.dbg[6]) / hc.dbg[8], double(hc.dbg[9]) * 64 / stats->samples,
+                        double(hc.dbg[10]) / hc.dbg[9], 100.0 * hc.dbg[11] / hc.dbg[9], hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
+            } else if (getenv("RTTNW_DEBUG_SCHED")) {
+                const double w64 = double(stats->samples) / 64.0;
+                fprintf(stderr, "[decoupled] bursts/64smp %.1f  shades/64smp %.2f (lanes %.1f)  refills/64smp %.1f (lanes %.1f)\n", hc.dbg[8] / w64, hc.dbg[9] / w64,
+                        hc.dbg[9] ? double(hc.dbg[10]) / hc.dbg[9] : 0.0, hc.dbg[11] / w64, hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
+            }
+        }
+        stats->n_nodes = uint32_t(s->flat.nodes4.size());
+        stats->n_prims = s->flat.n_prims_in_bvh;
+        stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
+        stats->reserved = plain ? 0u : 1u; // which kernel form ran: 0 lane-owns-path, 1 decoupled
+    }
+    return RTTNW_OK;
+}
+
+template <typename R>
+int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row, uint32_t sample,
+                 double* out, uint32_t max_out) {
+    DeviceState* d = s->device;
+    HIP_TRY(hipSetDevice(d->device));
+    DeviceScene<R>& ds = scene_of<R>(d);
+    if (!ds.ready)
+        if (int rc = ds.upload(s->flat)) return rc;
+    RenderConsts rc{};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
+    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    CameraRec<double> cam64;
+    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
+                cam->focus_distance, cam->open_time, cam->close_time, cam64);
+    DevBuf<double> d_out; // released on every exit path
+    DevBuf<int32_t> d_n;
+    if (int r = d_out.upload(std::vector<double>(size_t(max_out) * PROBE_STRIDE + 4, 0.0))) return r;
+    if (int r = d_n.upload(std::vector<int32_t>(1, 0))) { d_out.release(); return r; }
+    struct Release { DevBuf<double>& a; DevBuf<int32_t>& b; ~Release() { a.release(); b.release(); } } release{d_out, d_n};
+    DevBuf<int32_t> d_spill;
+    if (int r = d_spill.upload(std::vector<int32_t>(std::max<size_t>(rc.stack_depth, 1), 0))) { d_out.release(); d_n.release(); return r; }
+    struct Release2 { DevBuf<int32_t>& a; ~Release2() { a.release(); } } release2{d_spill};
+    const size_t lds = size_t(LDS_STACK_ENTRIES + 1) * 64 * sizeof(int32_t);
+    hipLaunchKernelGGL(probe_path_kernel<R>, dim3(1), dim3(64), lds, 0, ds.view, narrow_camera<R>(cam64), rc, R(p->t_min), px, row,
+                       sample, d_out.p, max_out, d_n.p, d_spill.p);
+    HIP_TRY(hipGetLastError());
+    int32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, d_n.p, sizeof(n), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_out.p, size_t(n) * PROBE_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
+    // radiance of the sample (path_step loop) is returned after the last possible bounce record
+    HIP_TRY(hipMemcpy(out + size_t(max_out) * PROBE_STRIDE, d_out.p + size_t(max_out) * PROBE_STRIDE, 4 * sizeof(double), hipMemcpyDeviceToHost));
+    return n;
+}
+
+template <typename R>
+int untile_launch(uint32_t width, uint32_t height, uint32_t world, const void* d_gathered, void* d_linear_rgb, uint8_t* d_rgba8, hipStream_t stream) {
+    rttnw_tile_layout L;
+    fill_layout(width, height, world, L);
+    dim3 block(32, 8), grid((width + 31) / 32, (height + 7) / 8);
+    hipLaunchKernelGGL(untile_kernel<R>, grid, block, 0, stream, (const R*)d_gathered, (R*)d_linear_rgb, d_rgba8, width, height, L.tiles_x, world,
+                       L.pixels_per_rank);
+    HIP_TRY(hipGetLastError());
+    return RTTNW_OK;
+}
+
+// what a precision's translation unit instantiates
+#define RT_INSTANTIATE_PRECISION(R)                                                                                                             \
+    template int render_tiles_t<R>(::rttnw_scene*, DeviceState*, const rttnw_camera_desc*, const rttnw_params*, void*, hipStream_t, rttnw_stats*, \
+                                   bool, bool);                                                                                                 \
+    template int probe_path_t<R>(::rttnw_scene*, const rttnw_camera_desc*, const rttnw_params*, uint32_t, uint32_t, uint32_t, double*, uint32_t); \
+    template int untile_launch<R>(uint32_t, uint32_t, uint32_t, const void*, void*, uint8_t*, hipStream_t);
+
+} // namespace rt

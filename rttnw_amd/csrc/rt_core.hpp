@@ -11,6 +11,10 @@
 #include "rt_types.hpp"
 #include <math.h>
 
+#ifndef RT_DEFER_UV
+#define RT_DEFER_UV 1 // experiments: 0 evaluates a sphere's (u, v) at the hit in every kernel
+#endif
+
 #ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 2 // node steps per trip round the walk loop (closest_solid)
 #endif
@@ -639,7 +643,7 @@ struct HitRef {
 //
 // The walk is written as RESUMABLE STEPS over an explicit per-lane state, so that the trace kernel's
 // intra-wave scheduler can run "one inner-node step" or "one primitive test" for whichever lanes
-// are waiting on it (render.hip), while closest_solid() below simply drives the same steps to
+// are waiting on it (trace_kernels.hpp), while closest_solid() below simply drives the same steps to
 // completion (probe kernel, host build).  The per-lane sequence of steps — hence every result and
 // counter — is the same whoever drives it.
 constexpr int32_t TRAV_DONE = INT32_MIN + 2; // Trav::node once the stack has run empty
@@ -876,7 +880,7 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
             // f64: Sphere::uv's acos + atan2 (hittable.rs:77-83) are ~250 instructions that the whole wave issues for the few
             // lanes on an image-textured sphere, and all they feed is a nearest-texel index (texture.rs:78-101).  An untransformed
             // sphere leaves them to texture_value(): `normal` is +-outward exactly, nothing else is needed.
-            if constexpr (sizeof(R) == 8 && !XUV) {
+            if constexpr (sizeof(R) == 8 && !XUV && RT_DEFER_UV) {
                 if (ref.inst < 0) rec.uv_deferred = true;
                 else sphere_uv(outward, rec.u, rec.v);
             } else {

@@ -316,7 +316,7 @@ RT_HD void chunk_samples(const RenderConsts& rc, uint32_t chunk, uint32_t& s, ui
 
 struct DeviceCounters {
     unsigned long long rays, nodes, prims, texels;
-    unsigned long long dbg[160]; // statistics of the counting variants (RTTNW_DEBUG_SCHED prints them; meaning per kernel in render.hip)
+    unsigned long long dbg[160]; // statistics of the counting variants (RTTNW_DEBUG_SCHED prints them; meaning per kernel in trace_kernels.hpp)
 };
 
 } // namespace rt

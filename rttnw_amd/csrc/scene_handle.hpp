@@ -1,5 +1,5 @@
 // scene_handle.hpp — what `rttnw_scene*` points at.  The recording half (capi_builder.cpp) is plain
-// C++; the device half (render.hip) hangs its state off `device`.
+// C++; the device half (render_api.cpp, render_f32.hip / render_f64.hip) hangs its state off `device`.
 #pragma once
 #include "scene_lower.hpp"
 
@@ -8,12 +8,12 @@
 #include <vector>
 
 namespace rt {
-struct DeviceState; // defined in render.hip
+struct DeviceState; // defined in render_common.hpp
 // Called by rttnw_scene_commit after lowering; uploads to the current HIP device.
 int device_commit(struct ::rttnw_scene* s, std::string& err);
 void device_release(DeviceState* d);
 // The device BVH builder bound to scene `s` (accumulates its kernel time in s->build_kernel_ms); fails without a
-// usable HIP device.  Defined in render.hip (and as a failing stub in the host-only test build).
+// usable HIP device.  Defined in render_api.cpp (and as a failing stub in the host-only test build).
 int device_bvh_builder(struct ::rttnw_scene* s, BvhBuilder& out, std::string& err);
 void set_last_error(const std::string& msg);
 } // namespace rt

@@ -1,0 +1,670 @@
+// trace_kernels.hpp — the kernels of the device half of include/rttnw_hip.h for gfx950 (MI355X), templates over the arithmetic type;
+// instantiated per precision in render_f32.hip / render_f64.hip.
+//
+// One kernel does the whole per-pixel sample loop of main.rs:202-229:
+//   * persistent workgroups pull JOBS from one global counter.  A job is (pixel, chunk of samples) — rt_types.hpp
+//     plan_chunks, rt_core.hpp job_decode: 64 consecutive jobs are a 2x2 pixel block x 16 chunks, so the lanes of a
+//     wave start nearly the same ray.  Idle lanes are counted with __ballot and pick distinct jobs by popcount rank
+//     out of a batch of 256 job indices the wave reserved with ONE atomic — lanes never wait for the longest path in
+//     the wave (path lengths run 1..50, the Cornell blocks trap rays).
+//   * a lane folds its job's samples sequentially (main.rs:211) with one path per lane: regenerate a
+//     camera ray when the path dies, otherwise do one world.hit + scatter (rt_core.hpp).
+//   * BVH traversal keeps its stack in LDS, interleaved by lane (entry e of lane l at e*blockDim+l:
+//     conflict-free ds_read/ds_write_b32); small scenes keep the node records there too.
+//   * job sums go to a partial buffer; a resolve kernel adds a pixel's chunks in chunk order, so the
+//     image is bit-identical whatever the scheduling, the grid size or the number of GPUs.
+// Two forms of the loop: trace_kernel_plain (a lane owns a path) and trace_kernel (paths decoupled
+// from lanes through wave-private queues, for trees that live in HBM).
+// No CPU fallback: every entry point needs a HIP device.
+#pragma once
+#include "render_common.hpp"
+
+#ifndef RT_F64_BLOCK
+#define RT_F64_BLOCK 1024 // threads per block of the LDS-resident f64 kernel (4 waves/SIMD at 128 VGPRs; see the Makefile's f64 flags and profiles/r03/README.md)
+#endif
+
+namespace rt {
+
+// ---------------------------------------------------------------------------------------------
+// device-side helpers
+// ---------------------------------------------------------------------------------------------
+// Traversal memory of a lane: its BVH stack — the first LDS_STACK_ENTRIES entries in LDS (entry e of lane l at
+// e*stride + l: conflict-free b32 accesses), deeper ones in a strip of global memory (entry e of thread g at
+// e*spill_stride + g; a 4-wide walk can have three pending children per level but rarely has more than a dozen) — and
+// the way it reads node records.
+typedef __attribute__((address_space(3))) int32_t* LdsIntPtr;    // explicit address spaces: the compiler otherwise merges
+typedef __attribute__((address_space(1))) int32_t* GlobalIntPtr; // the two halves of get() into one FLAT load
+template <uint32_t STRIDE, uint32_t ENTRIES = LDS_STACK_ENTRIES> struct LdsStack { // STRIDE = lanes sharing the LDS stack area: entry e of a lane at base[e * STRIDE]; ENTRIES kept in LDS
+    static constexpr int SPARE = int(ENTRIES); // a lane's extra LDS slot: target of the node step's masked-off stores
+    LdsIntPtr base;        // &lds[threadIdx.x]
+    GlobalIntPtr spill;    // &spill_buffer[global thread]
+    uint32_t spill_stride; // threads of the launch
+    __device__ __forceinline__ void set(int i, int32_t v) {
+        if (uint32_t(i) < ENTRIES) base[uint32_t(i) * STRIDE] = v;
+        else spill[size_t(uint32_t(i) - ENTRIES) * spill_stride] = v;
+    }
+    __device__ __forceinline__ int32_t get(int i) const {
+        if (uint32_t(i) < ENTRIES) return base[uint32_t(i) * STRIDE];
+        return spill[size_t(uint32_t(i) - ENTRIES) * spill_stride];
+    }
+    // a node step that finds entries i, i+1, i+2 inside the LDS part writes them without looking at the spill strip
+    __device__ __forceinline__ bool room_for_three(int i) const { return uint32_t(i) + 3u <= ENTRIES; }
+    __device__ __forceinline__ void set_fast(int i, int32_t v) { base[uint32_t(i) * STRIDE] = v; }
+    // node records in global memory: a plane piece is addressed by its index inside the 128-byte record
+    __device__ __forceinline__ uint32_t plane_off(uint32_t q) const { return q; }
+    template <typename R> __device__ __forceinline__ void fetch(const SceneView<R>& sc, int32_t i, const uint32_t* near_off, Planes4& out) const {
+        const int4* rec = reinterpret_cast<const int4*>(sc.nodes + i);
+        union { int4 q[7]; struct { float nr[3][4], fr[3][4]; int32_t child[4]; } p; } u;
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a) {
+            u.q[a] = rec[near_off[a]];
+            u.q[3 + a] = rec[2u * a + 3u - near_off[a]]; // the other one of (a, a + 3)
+        }
+        u.q[6] = rec[6];
+        __builtin_memcpy(&out, &u, sizeof(out));
+    }
+};
+// Same, with the whole node array resident in LDS in PIECE-MAJOR order: the q-th 16 bytes of node i at
+// piece[q*n_nodes + i] (q < 7: the pad is left out).  64 lanes fetching the same piece of 64 unrelated nodes then spread
+// over all the 16-byte bank slots (i mod 16); in node-major order the 128-byte records would all start at the same two
+// — measured on the 64-byte binary records: 31 % of the LDS cycles were bank conflicts that way.
+template <uint32_t STRIDE> struct LdsStackNodes : LdsStack<STRIDE> {
+    const int4* piece; // LDS
+    uint32_t n_nodes;
+    __device__ __forceinline__ uint32_t plane_off(uint32_t q) const { return q * n_nodes; }
+    template <typename R> __device__ __forceinline__ void fetch(const SceneView<R>&, int32_t i, const uint32_t* near_off, Planes4& out) const {
+        union { int4 q[7]; struct { float nr[3][4], fr[3][4]; int32_t child[4]; } p; } u;
+#pragma unroll
+        for (uint32_t a = 0; a < 3; ++a) {
+            u.q[a] = piece[near_off[a] + uint32_t(i)];
+            u.q[3 + a] = piece[(2u * a + 3u) * n_nodes - near_off[a] + uint32_t(i)];
+        }
+        u.q[6] = piece[6u * n_nodes + uint32_t(i)];
+        __builtin_memcpy(&out, &u, sizeof(out));
+    }
+};
+
+template <bool COUNT, bool GENERAL> struct CounterSel { using type = NoCountersT<GENERAL>; };
+template <bool GENERAL> struct CounterSel<true, GENERAL> { using type = LaneCountersT<GENERAL>; };
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Hands a distinct job index to every lane of `mask` (wave-uniform).  Jobs come from the batch [next, end) the wave
+// has reserved; when it runs short the wave leader reserves JOB_BATCH more with ONE atomic on the global counter.
+// (One atomic per refill event saturated the single counter address at ~10^8 small jobs per second.)
+constexpr unsigned long long JOB_BATCH = 256;
+__device__ __forceinline__ unsigned long long wave_take_jobs(unsigned long long mask, uint32_t lane, unsigned long long& next,
+                                                              unsigned long long& end, unsigned long long* __restrict__ job_counter) {
+    const uint32_t want = uint32_t(__popcll(mask)), rank = uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+    const unsigned long long avail = end - next;
+    if (avail >= want) {
+        const unsigned long long job = next + rank;
+        next += want;
+        return job;
+    }
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned long long base = 0;
+    if (int(lane) == leader) base = atomicAdd(job_counter, JOB_BATCH);
+    const uint32_t blo = __shfl(uint32_t(base), leader, 64), bhi = __shfl(uint32_t(base >> 32), leader, 64);
+    base = (unsigned long long)blo | ((unsigned long long)bhi << 32);
+    const unsigned long long job = rank < avail ? next + rank : base + (rank - avail);
+    next = base + (want - avail);
+    end = base + JOB_BATCH;
+    return job;
+}
+
+constexpr int TRACE_BLOCK = 256;
+constexpr uint32_t SLOTS_PER_WAVE = 128; // paths owned by one wave64: 64 being traversed + up to 64 queued
+constexpr uint32_t QCAP = 128;           // capacity of a wave's ray queue and hit queue (entries)
+
+// Path state of a slot, in global memory (L2-resident), struct-of-arrays over all slots of the launch.
+enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_LX, PR_LY, PR_LZ, PR_AX, PR_AY, PR_AZ, PR_COUNT };
+enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
+// bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
+// LDS stack entries of the decoupled kernel: 16 for f32; 12 for f64, whose queues are twice as wide — with 16 a 256-thread
+// block needs 58 368 B and only TWO fit in a CU's 160 KB, i.e. 2 waves/SIMD however few registers the kernel is held to;
+// with 12 it is 54 272 B and three fit (the spill strip in global memory takes the rare deeper entries).
+template <typename R> __host__ __device__ constexpr uint32_t wave_stack_entries() { return sizeof(R) == 8 ? 12u : LDS_STACK_ENTRIES; }
+template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
+    return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (wave_stack_entries<R>() + 1u) * 64u * 4u; // stack: + the spare slot
+}
+constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
+
+// The per-pixel sample loop of main.rs:202-229 as ONE persistent kernel in which PATHS ARE DECOUPLED FROM LANES.
+//
+// A wave64 owns 128 path slots whose state (ray, throughput, radiance, RNG key, pixel/sample bookkeeping) lives in
+// global memory; a lane only ever holds a RAY BEING TRAVERSED (origin, direction, closest hit, BVH cursor), so the
+// traversal loop is tight and nothing else is loop-carried.  Two wave-private LDS queues connect the two halves:
+//   * TRAVERSE iteration: lanes without a ray pop one from the ray queue (ranks by __ballot/popcount — the queues are
+//     private to the wave, no atomics), every lane advances its ray by one walk trip (a few node steps and a leaf
+//     step), lanes whose ray is finished push (slot, t, primitive) onto the hit queue and are free for the next ray:
+//     no lane waits for the longest traversal in the wave.
+//   * SHADE: as soon as 64 hits are queued the whole wave processes them at full occupancy — media, hit record,
+//     emitted + scatter (rt_core.hpp path_shade) — and pushes the 64 continuation rays.  A path that ended adds its
+//     radiance to its job's sequential sum (main.rs:211-216) and starts the job's next sample; a slot whose job is
+//     finished writes the job's partial sum and takes the next job ((pixel, sample chunk), see job_decode) from the
+//     wave's batch of job indices (one atomic on the global counter per 256 jobs).
+// Results do not depend on any of this scheduling: every draw is keyed by (pixel, sample, bounce), every job is a
+// sequential fold, and the resolve kernel adds a pixel's jobs in chunk order.
+// Re-read a by-value kernel argument from the kernarg segment at its (cold) point of use, so that it does not hold
+// SGPRs for the whole kernel: the trace kernels are at the 102-SGPR limit and spill to VGPR lanes otherwise.  The
+// pointer is passed through an empty asm so that the loads stay where they are written.
+template <typename T> __device__ __forceinline__ T kernarg_reload(uint32_t offset) {
+    typedef const char __attribute__((address_space(4)))* KPtr;
+    KPtr p = (KPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    T v;
+    __builtin_memcpy(&v, p + offset, sizeof(T));
+    return v;
+}
+// Layout of the first three kernel arguments: the kernarg segment places by-value arguments in order at their natural
+// alignment, which is what this struct does with its members (the GPU parity tests would not survive a mismatch).
+template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; };
+static_assert(alignof(SceneView<float>) <= 8 && alignof(CameraRec<double>) <= 8 && alignof(RenderConsts) <= 8, "kernarg_reload assumes naturally aligned arguments");
+
+template <typename R, bool COUNT, bool GENERAL>
+// (at least 3 waves/SIMD: 170 VGPRs — the f32 code needs 164; the f64 code, allowed 256, ran at 2 waves/SIMD and waited on
+// the fabric: spheres_1m f64 167 -> 264 Msamples/s with 140 registers spilled; 4 waves/SIMD: 205)
+__global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+                                                            R bg_b, R t_min, R* __restrict__ partial,
+                                                            unsigned long long* __restrict__ job_counter,
+                                                            DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,
+                                                            uint32_t* __restrict__ pool_u, uint32_t n_slots, int32_t* __restrict__ spill) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    typename CounterSel<COUNT, GENERAL>::type cnt;
+    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    unsigned char* wbase = lds_raw + wave_in_block * wave_lds_bytes<R>(rc.stack_depth);
+    R* const rq_f = reinterpret_cast<R*>(wbase);            // ray queue [7][QCAP]: o.xyz, d.xyz, time
+    R* const hq_t = rq_f + 7u * QCAP;                       // hit queue: t
+    uint32_t* const rq_slot = reinterpret_cast<uint32_t*>(hq_t + QCAP);
+    int32_t* const hq_prim = reinterpret_cast<int32_t*>(rq_slot + QCAP);
+    int32_t* const hq_inst = hq_prim + QCAP;
+    uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
+    LdsStack<64, wave_stack_entries<R>()> stack{(LdsIntPtr)(reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane), (GlobalIntPtr)(spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x)), gridDim.x * TRACE_BLOCK};
+
+    const uint32_t wave_global = blockIdx.x * (TRACE_BLOCK / 64) + wave_in_block;
+    const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;
+    const unsigned long long n_jobs = rc.n_jobs;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const V3<R> background(bg_r, bg_g, bg_b);
+
+    // every slot starts out needing its first job
+    hq_meta[lane] = lane | HIT_FRESH;
+    hq_meta[lane + 64u] = (lane + 64u) | HIT_FRESH;
+    uint32_t ray_n = 0, hit_n = SLOTS_PER_WAVE; // wave-uniform queue fill levels
+    unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
+
+    uint32_t dbg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    bool has_ray = false;
+    uint32_t slot = 0;
+    Ray<R> wray; // the ray this lane is traversing, in world space
+    Trav<R> tr;
+
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        const bool any_ray = __ballot(has_ray) != 0ull;
+        if (hit_n >= 64u || (!any_ray && ray_n == 0u)) {
+            if (hit_n == 0u) break; // nothing traversing, nothing queued: this wave is done
+            // ================================================================== SHADE (up to 64 queued hits)
+            const uint32_t m = hit_n < 64u ? hit_n : 64u;
+            if constexpr (COUNT) { dbg[9] += 1; dbg[10] += m; }
+            const bool on = lane < m;
+            const uint32_t e = hit_n - 1u - (on ? lane : 0u);
+            hit_n -= m;
+            const uint32_t meta = on ? hq_meta[e] : HIT_FRESH;
+            const uint32_t hslot = meta & 0x7Fu;
+            const bool fresh = (meta & HIT_FRESH) != 0u;
+            const size_t g = gbase + hslot;
+            R* const pr = pool_r + g;
+            uint32_t* const pu = pool_u + g;
+
+            PathState<R> ps;
+            bool emit = false, need_sample = false, slot_done = false;
+            uint32_t pxrow = 0, smp = 0, smp_end = 0;
+            unsigned long long job = ~0ull;
+            V3<R> acc;
+            if (on && !fresh) {
+                ps.ray.o = V3<R>(pr[size_t(PR_OX) * n_slots], pr[size_t(PR_OY) * n_slots], pr[size_t(PR_OZ) * n_slots]);
+                ps.ray.d = V3<R>(pr[size_t(PR_DX) * n_slots], pr[size_t(PR_DY) * n_slots], pr[size_t(PR_DZ) * n_slots]);
+                ps.ray.time = pr[size_t(PR_TIME) * n_slots];
+                ps.throughput = V3<R>(pr[size_t(PR_TX) * n_slots], pr[size_t(PR_TY) * n_slots], pr[size_t(PR_TZ) * n_slots]);
+                ps.radiance = V3<R>(pr[size_t(PR_LX) * n_slots], pr[size_t(PR_LY) * n_slots], pr[size_t(PR_LZ) * n_slots]);
+                ps.key = (unsigned long long)pu[size_t(PU_KEY_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_KEY_HI) * n_slots] << 32);
+                ps.bounce = pu[size_t(PU_BOUNCE) * n_slots];
+                HitRef best;
+                best.prim = hq_prim[e];
+                best.inst = hq_inst[e];
+                best.aux = int32_t((meta >> 8) & 7u);
+                const bool found = ref_kind(best.prim) != PRIM_NONE;
+                // (scene view and constants re-read from the kernarg segment: the traversal loop keeps only the pointers it uses)
+                if (path_shade(ps, kernarg_reload<SceneView<R>>(offsetof(TraceArgsHead<R>, sc)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), background, t_min,
+                               found, hq_t[e], best, cnt)) {
+                    emit = true; // next world.hit of the same path
+                } else {         // main.rs:216: acc + color(...)
+                    pxrow = pu[size_t(PU_PXROW) * n_slots];
+                    smp = pu[size_t(PU_S) * n_slots];
+                    smp_end = pu[size_t(PU_SEND) * n_slots];
+                    job = (unsigned long long)pu[size_t(PU_JOB_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_JOB_HI) * n_slots] << 32);
+                    acc = V3<R>(pr[size_t(PR_AX) * n_slots], pr[size_t(PR_AY) * n_slots], pr[size_t(PR_AZ) * n_slots]) + ps.radiance;
+                    ++smp;
+                    need_sample = true;
+                }
+            } else if (on) {
+                need_sample = true; // fresh slot: smp == smp_end == 0, no job yet
+            }
+            // job hand-out for the slots whose job is finished: wave-aggregated, one atomic per round.  An empty job
+            // (a tile pixel outside the image) is finished at once, hence the loop.
+            for (;;) {
+                const bool need_job = need_sample && !slot_done && smp >= smp_end;
+                const unsigned long long jm = __ballot(need_job);
+                if (jm == 0ull) break;
+                if (need_job && job != ~0ull) { // retire the finished job: its sequential sum
+                    R* dst = partial + job * 3ull;
+                    dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
+                }
+                const unsigned long long mine = wave_take_jobs(jm, lane, batch_next, batch_end, job_counter);
+                if (need_job) {
+                    job = mine;
+                    if (job >= n_jobs) {
+                        slot_done = true; // no jobs left: this slot retires
+                    } else {
+                        const RenderConsts rj = kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)); // cold: keep it out of the SGPRs
+                        const JobInfo ji = job_decode(rj, uint32_t(job));
+                        pxrow = ji.px | (ji.row << 16);
+                        smp = ji.s; smp_end = ji.s_end;
+                        job = ji.real ? (unsigned long long)ji.sum_index : ~0ull; // from here on: where the job's sum goes (none for padding)
+                        acc = V3<R>();
+                    }
+                }
+            }
+            if (need_sample && !slot_done) { // main.rs:212-215: the job's next sample
+                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), pxrow & 0xFFFFu, pxrow >> 16, smp);
+                pu[size_t(PU_KEY_LO) * n_slots] = uint32_t(ps.key);
+                pu[size_t(PU_KEY_HI) * n_slots] = uint32_t(ps.key >> 32);
+                pu[size_t(PU_PXROW) * n_slots] = pxrow;
+                pu[size_t(PU_S) * n_slots] = smp;
+                pu[size_t(PU_SEND) * n_slots] = smp_end;
+                pu[size_t(PU_JOB_LO) * n_slots] = uint32_t(job);
+                pu[size_t(PU_JOB_HI) * n_slots] = uint32_t(job >> 32);
+                pr[size_t(PR_AX) * n_slots] = acc.x; pr[size_t(PR_AY) * n_slots] = acc.y; pr[size_t(PR_AZ) * n_slots] = acc.z;
+                emit = true;
+            }
+            const unsigned long long em = __ballot(emit);
+            if (emit) { // the slot's next ray: path state back to memory, ray onto the queue
+                pr[size_t(PR_OX) * n_slots] = ps.ray.o.x; pr[size_t(PR_OY) * n_slots] = ps.ray.o.y; pr[size_t(PR_OZ) * n_slots] = ps.ray.o.z;
+                pr[size_t(PR_DX) * n_slots] = ps.ray.d.x; pr[size_t(PR_DY) * n_slots] = ps.ray.d.y; pr[size_t(PR_DZ) * n_slots] = ps.ray.d.z;
+                pr[size_t(PR_TIME) * n_slots] = ps.ray.time;
+                pr[size_t(PR_TX) * n_slots] = ps.throughput.x; pr[size_t(PR_TY) * n_slots] = ps.throughput.y; pr[size_t(PR_TZ) * n_slots] = ps.throughput.z;
+                pr[size_t(PR_LX) * n_slots] = ps.radiance.x; pr[size_t(PR_LY) * n_slots] = ps.radiance.y; pr[size_t(PR_LZ) * n_slots] = ps.radiance.z;
+                pu[size_t(PU_BOUNCE) * n_slots] = ps.bounce;
+                const uint32_t idx = ray_n + uint32_t(__popcll(em & lanes_below));
+                rq_f[0u * QCAP + idx] = ps.ray.o.x; rq_f[1u * QCAP + idx] = ps.ray.o.y; rq_f[2u * QCAP + idx] = ps.ray.o.z;
+                rq_f[3u * QCAP + idx] = ps.ray.d.x; rq_f[4u * QCAP + idx] = ps.ray.d.y; rq_f[5u * QCAP + idx] = ps.ray.d.z;
+                rq_f[6u * QCAP + idx] = ps.ray.time;
+                rq_slot[idx] = hslot;
+            }
+            ray_n += uint32_t(__popcll(em));
+            continue;
+        }
+
+        // ====================================================================== TRAVERSE (one step for every ray)
+        const unsigned long long nm = __ballot(!has_ray);
+        if (nm != 0ull && ray_n != 0u) { // hand queued rays to the idle lanes
+            const uint32_t want = uint32_t(__popcll(nm)), take = want < ray_n ? want : ray_n;
+            if constexpr (COUNT) { dbg[11] += 1; dbg[12] += take; }
+            const uint32_t rank = uint32_t(__popcll(nm & lanes_below));
+            if (!has_ray && rank < take) {
+                const uint32_t e = ray_n - 1u - rank;
+                wray.o = V3<R>(rq_f[0u * QCAP + e], rq_f[1u * QCAP + e], rq_f[2u * QCAP + e]);
+                wray.d = V3<R>(rq_f[3u * QCAP + e], rq_f[4u * QCAP + e], rq_f[5u * QCAP + e]);
+                wray.time = rq_f[6u * QCAP + e];
+                slot = rq_slot[e];
+                cnt.ray();
+                trav_begin(tr, sc, wray, stack);
+                has_ray = true;
+            }
+            ray_n -= take;
+        }
+        // A burst of walk trips (the loop body of closest_solid(), with more node steps per trip: these trees are deep): it
+        // ends once enough lanes have finished their ray to make the hand-over below worth its cost.  (An earlier form
+        // voted, per step, for ONE kind of step — inner node / sphere / box / other — to run for all lanes waiting on it;
+        // the vote cost about as much as a node step, and plain trips beat it: spheres_1m 306 -> 330 Msamples/s,
+        // final_scene through this kernel 916 -> 1084.  Node steps per trip 2 / 3 / 4 / 6: 302 / 321 / 325 / 330.)
+        {
+            const uint32_t retire_batch = ray_n != 0u ? 16u : 64u;
+            if constexpr (COUNT) dbg[8] += 1;
+            for (;;) {
+                const bool walking = has_ray && tr.node != TRAV_DONE;
+                if (__ballot(walking) == 0ull) break; // every ray of the wave is finished
+                if (walking) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+                        if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
+                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
+                }
+                if (uint32_t(__popcll(__ballot(has_ray && tr.node == TRAV_DONE))) >= retire_batch) break;
+            }
+        }
+        const bool fin = has_ray && tr.node == TRAV_DONE;
+        const unsigned long long fm = __ballot(fin);
+        if (fm != 0ull) { // finished rays: hit onto the queue, lane free again
+            if (fin) {
+                const uint32_t idx = hit_n + uint32_t(__popcll(fm & lanes_below));
+                hq_t[idx] = tr.closest;
+                hq_prim[idx] = tr.found ? tr.best.prim : make_ref(PRIM_NONE, 0);
+                hq_inst[idx] = tr.best.inst;
+                hq_meta[idx] = slot | (uint32_t(tr.best.aux) << 8);
+                has_ray = false;
+            }
+            hit_n += uint32_t(__popcll(fm));
+        }
+    }
+
+    if constexpr (COUNT) {
+        uint32_t r = wave_sum(cnt.rays), nn = wave_sum(cnt.nodes), p = wave_sum(cnt.prims), t = wave_sum(cnt.texels);
+        if (lane == 0) {
+            atomicAdd(&counters->rays, (unsigned long long)r);
+            atomicAdd(&counters->nodes, (unsigned long long)nn);
+            atomicAdd(&counters->prims, (unsigned long long)p);
+            atomicAdd(&counters->texels, (unsigned long long)t);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) atomicAdd(&counters->dbg[k], (unsigned long long)dbg[k]);
+        }
+    }
+}
+
+// The plain form of the same loop: a lane OWNS a path (and its job) and alternates "regenerate or advance by one
+// bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
+// bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
+// decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
+template <typename R, bool COUNT, int BLOCK, bool LDSN, bool GENERAL>
+// (the 256-thread form — nodes in global memory — asks for at least 3 waves/SIMD like the decoupled kernel: its f64 code,
+// allowed 256 VGPRs, ran at 2: a 20 000-sphere scene 29.9 -> 13.7 ms per 67 Msamples)
+__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+                                                            R bg_b, R t_min, R* __restrict__ partial,
+                                                            unsigned long long* __restrict__ job_counter,
+                                                            DeviceCounters* __restrict__ counters, int32_t* __restrict__ spill) {
+    // LDSN: the whole node array is copied into LDS (piece-major, see LdsStackNodes) in front of the stacks — small
+    // scenes: one dependent ~100-cycle LDS read per node visit instead of an L1/L2 round trip
+    extern __shared__ __align__(16) int32_t lds_stack[];
+    typename std::conditional<LDSN, LdsStackNodes<BLOCK>, LdsStack<BLOCK>>::type stack;
+    stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * blockDim.x + threadIdx.x));
+    stack.spill_stride = gridDim.x * blockDim.x;
+    if constexpr (LDSN) {
+        const uint32_t n = rc.lds_nodes;
+        const int4* src = reinterpret_cast<const int4*>(sc.nodes);
+        int4* dst = reinterpret_cast<int4*>(lds_stack);
+        for (uint32_t i = threadIdx.x; i < n * 8u; i += blockDim.x)
+            if ((i & 7u) < BVH4_USED_SIXTEENTHS) dst[(i & 7u) * n + (i >> 3)] = src[i];
+        __syncthreads();
+        stack.base = (LdsIntPtr)(lds_stack + n * (4u * BVH4_USED_SIXTEENTHS) + threadIdx.x);
+        stack.piece = dst;
+        stack.n_nodes = n;
+    } else {
+        stack.base = (LdsIntPtr)(lds_stack + threadIdx.x);
+    }
+    typename CounterSel<COUNT, GENERAL>::type cnt;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long n_jobs = rc.n_jobs;
+    const V3<R> background(bg_r, bg_g, bg_b);
+
+    bool has_job = false, alive = false, done = false;
+    unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
+    unsigned long long job = 0;
+    uint32_t px = 0, row = 0, s = 0, s_end = 0;
+    V3<R> acc;
+    PathState<R> ps;
+
+    // counting variant only: where a wave's time and lanes go (RTTNW_DEBUG_SCHED prints it) — wave clock per phase
+    // [0..3], lockstep iterations of the BVH walk [4] (with a node lane [7], with a leaf lane [8]) against the lane
+    // steps they served [5] node / [6] leaf, bounce rounds [9] and the lanes alive in them [10], regenerations [11,12]
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (;;) {
+        long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        if constexpr (COUNT) tk0 = clock64();
+        // ---- job hand-out: wave-aggregated, one atomic per refill event
+        const bool need = !done && !alive && s >= s_end;
+        const unsigned long long mask = __ballot(need);
+        if (mask != 0ull) {
+            if (need && has_job) { // retire the finished job: its sequential sum
+                R* dst = partial + job * 3ull;
+                dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
+                has_job = false;
+            }
+            const unsigned long long mine = wave_take_jobs(mask, lane, batch_next, batch_end, job_counter);
+            if (need) {
+                job = mine;
+                if (job >= n_jobs) {
+                    done = true;
+                } else {
+                    const JobInfo ji = job_decode(rc, uint32_t(job));
+                    px = ji.px; row = ji.row; s = ji.s; s_end = ji.s_end;
+                    job = ji.sum_index; // from here on: where the job's sum goes
+                    acc = V3<R>();
+                    has_job = ji.real; // padding jobs have no sum to write
+                }
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+
+        // ---- one path per lane: regenerate or advance by one bounce
+        if constexpr (!COUNT) {
+            if (!done) {
+                if (!alive && s < s_end) {
+                    path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, px, row, s);
+                    alive = true;
+                }
+                if (alive) {
+                    alive = path_step(ps, sc, rc, background, t_min, stack, cnt);
+                    if (!alive) { // main.rs:216: acc + color(...)
+                        acc = acc + ps.radiance;
+                        ++s;
+                    }
+                }
+            }
+        } else { // the same steps, with the wave clock read between the phases and the lockstep loop tallied
+            tk1 = clock64();
+            const bool begin = !done && !alive && s < s_end;
+            const unsigned long long bm = __ballot(begin);
+            if (begin) {
+                path_begin(ps, cam, rc, px, row, s);
+                alive = true;
+            }
+            tk2 = clock64();
+            const unsigned long long am = __ballot(alive);
+            bool found = false;
+            R closest = R(0);
+            HitRef best;
+            best.prim = 0; best.inst = -1; best.aux = 0;
+            uint32_t my_trips = 0;
+            if (alive) {
+                cnt.ray();
+                Trav<R> tr;
+                trav_begin(tr, sc, ps.ray, stack);
+                while (tr.node != TRAV_DONE) {
+                    ++my_trips;
+                    // the loop body of closest_solid() (two node steps, then a leaf step for the lanes at a leaf by then), tallied
+                    const unsigned long long act = __ballot(true);
+                    const bool is_node = tr.node >= 0;
+                    const unsigned long long nm = __ballot(is_node);
+                    const long long q0 = clock64();
+                    if (is_node) { prof[5] += 1; trav_node_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    if (tr.node >= 0) { prof[5] += 1; trav_node_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    const long long q1 = clock64();
+                    const bool is_leaf = tr.node < 0 && tr.node != TRAV_DONE;
+                    const unsigned long long lm = __ballot(is_leaf);
+                    uint32_t kmask = 0; // kinds among the leaf lanes: bit k = record kind k, bit 5 = empty slot
+                    {
+                        const uint32_t kd = tr.node == CHILD_EMPTY ? 5u : leaf_kind(tr.node);
+#pragma unroll
+                        for (uint32_t k = 0; k < 6; ++k) kmask |= __ballot(is_leaf && kd == k) != 0ull ? (1u << k) : 0u;
+                    }
+                    const long long q1b = clock64();
+                    if (is_leaf) { prof[6] += 1; trav_leaf_step(tr, sc, ps.ray, t_min, stack, cnt); }
+                    const long long q2 = clock64();
+                    if (lane == uint32_t(__ffsll((long long)act) - 1)) {
+                        prof[4] += 1;
+                        prof[7] += nm != 0ull;
+                        prof[8] += lm != 0ull;
+                        prof[13] += (unsigned long long)(q1 - q0);
+                        prof[14] += (unsigned long long)(q2 - q1b);
+                        if (kmask && rc.profile == 2u) { // leaf time by the set of record kinds the iteration served: dbg[16+set], count dbg[80+set]
+                            atomicAdd(&counters->dbg[16 + kmask], (unsigned long long)(q2 - q1b));
+                            atomicAdd(&counters->dbg[80 + kmask], 1ull);
+                        }
+                    }
+                }
+                found = tr.found; closest = tr.closest; best = tr.best;
+                if (rc.profile == 3u) {
+                    atomicAdd(&counters->dbg[16 + min(my_trips, 63u)], 1ull); // histogram of trips per walk
+                    // ... and trips by what the walk found: 0 miss, 1 + kind (sphere, moving, rect, box), 6 anything inside an instance
+                    const uint32_t cls = !tr.found ? 0u : (tr.best.inst >= 0 ? 6u : 1u + ref_kind(tr.best.prim));
+                    atomicAdd(&counters->dbg[144 + cls], (unsigned long long)my_trips);
+                    atomicAdd(&counters->dbg[152 + cls], 1ull);
+                }
+            }
+            if (rc.profile == 3u) { // ... and of the trips of the wave's longest walk, per round
+                uint32_t mx = my_trips;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx = max(mx, uint32_t(__shfl_xor(int(mx), off, 64)));
+                if (lane == 0) atomicAdd(&counters->dbg[80 + min(mx, 63u)], 1ull);
+            }
+            tk3 = clock64();
+            long long tk3b = tk3;
+            if (alive) { // path_shade(), with the wave clock read between its two halves
+                HitRecord<R> rec;
+                const bool hit = world_hit_finish(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, found, closest, best, rec, cnt);
+                tk3b = clock64();
+                if (!hit) {
+                    ps.radiance = ps.radiance + ps.throughput * background;
+                    alive = false;
+                } else {
+                    V3<R> att, emitted;
+                    const bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, emitted, cnt);
+                    ps.radiance = ps.radiance + ps.throughput * emitted;
+                    if (cont) { ps.throughput = ps.throughput * att; ps.bounce += 1; }
+                    alive = cont && ps.bounce < rc.max_depth;
+                }
+                if (!alive) {
+                    acc = acc + ps.radiance;
+                    ++s;
+                }
+            }
+            const long long tk4 = clock64();
+            if (lane == 0) {
+                prof[0] += (unsigned long long)(tk1 - tk0);
+                prof[1] += (unsigned long long)(tk2 - tk1);
+                prof[2] += (unsigned long long)(tk3 - tk2);
+                prof[3] += (unsigned long long)(tk4 - tk3);
+                prof[15] += (unsigned long long)(tk3b - tk3);
+                prof[9] += 1;
+                prof[10] += (unsigned long long)__popcll(am);
+                prof[11] += bm != 0ull;
+                prof[12] += (unsigned long long)__popcll(bm);
+            }
+        }
+    }
+
+    if constexpr (COUNT) {
+        uint32_t r = wave_sum(cnt.rays), n = wave_sum(cnt.nodes), p = wave_sum(cnt.prims), t = wave_sum(cnt.texels);
+        if (lane == 0) {
+            atomicAdd(&counters->rays, (unsigned long long)r);
+            atomicAdd(&counters->nodes, (unsigned long long)n);
+            atomicAdd(&counters->prims, (unsigned long long)p);
+            atomicAdd(&counters->texels, (unsigned long long)t);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (prof[k]) atomicAdd(&counters->dbg[k], prof[k]);
+    }
+}
+
+// Sum a pixel's chunk partials of ONE PASS in chunk order and add them to the pixel's running sum (pass 0 starts it);
+// the last pass divides by the render's spp (main.rs:217): packed pixel records (r, g, b, 1).  Pad tiles
+// (>= my_tiles) are zero-filled.  The running sum lives in `packed` itself.
+template <typename R>
+__global__ void resolve_kernel(const R* __restrict__ partial, R* __restrict__ packed, RenderConsts rc, uint32_t pixels_per_rank,
+                               uint32_t first_pass, uint32_t last_pass, uint32_t total_spp) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pixels_per_rank) return;
+    R* dst = packed + (unsigned long long)p * 4ull;
+    R r = 0, g = 0, b = 0, a = 0;
+    const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
+    if (p < jobs_per_chunk) {
+        for (uint32_t c = 0; c < rc.n_chunks; ++c) {
+            const R* src = partial + ((unsigned long long)c * jobs_per_chunk + p) * 3ull;
+            r = r + src[0]; g = g + src[1]; b = b + src[2];
+        }
+        if (!first_pass) { r = dst[0] + r; g = dst[1] + g; b = dst[2] + b; }
+        if (last_pass) {
+            const R spp = R(total_spp);
+            r = r / spp; g = g / spp; b = b / spp;
+            a = R(1);
+        }
+    }
+    dst[0] = r; dst[1] = g; dst[2] = b; dst[3] = a;
+}
+
+// Gathered packed records (rank-major) -> row-major top-first framebuffer + RGBA8 (main.rs:219-225).
+template <typename R>
+__global__ void untile_kernel(const R* __restrict__ gathered, R* __restrict__ linear_rgb, uint8_t* __restrict__ rgba8, uint32_t width,
+                              uint32_t height, uint32_t tiles_x, uint32_t world, uint32_t pixels_per_rank) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= width || y >= height) return;
+    const uint32_t permuted = tile_permuted(x >> 3, y >> 3, tiles_x);
+    const uint32_t owner = permuted % world, local_tile = permuted / world;
+    const unsigned long long src = (unsigned long long)owner * pixels_per_rank + local_tile * 64ull + ((y & 7u) << 3) + (x & 7u);
+    const R r = gathered[src * 4], g = gathered[src * 4 + 1], b = gathered[src * 4 + 2];
+    const unsigned long long o = (unsigned long long)y * width + x;
+    if (linear_rgb) { linear_rgb[o * 3] = r; linear_rgb[o * 3 + 1] = g; linear_rgb[o * 3 + 2] = b; }
+    if (rgba8) {
+        rgba8[o * 4] = quantise(r); rgba8[o * 4 + 1] = quantise(g); rgba8[o * 4 + 2] = quantise(b); rgba8[o * 4 + 3] = 255;
+    }
+}
+
+// Debug probe: one lane walks one sample's path and dumps every hit record (t, p, normal, material, u, v,
+// front_face) plus the ray it was found with — the device half of the per-bounce CPU-vs-GPU vector tests.
+constexpr int PROBE_STRIDE = 20;
+template <typename R>
+__global__ void probe_path_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R t_min, uint32_t px, uint32_t row,
+                                  uint32_t sample, double* __restrict__ out, uint32_t max_out, int32_t* __restrict__ n_out,
+                                  int32_t* __restrict__ spill) {
+    extern __shared__ int32_t lds_stack[];
+    if (threadIdx.x != 0) return;
+    LdsStack<64> stack{(LdsIntPtr)lds_stack, (GlobalIntPtr)spill, 1u};
+    ProbeCounters cnt; // every graph shape; (u, v) evaluated at every hit that reads them (the trace kernels defer them, rt_core.hpp)
+    PathState<R> ps;
+    path_begin(ps, cam, rc, px, row, sample);
+    uint32_t n = 0;
+    while (n < max_out) {
+        HitRecord<R> rec;
+        const Ray<R> ray = ps.ray;
+        if (!world_hit(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, rec, stack, cnt)) break;
+        double* o = out + size_t(n) * PROBE_STRIDE;
+        o[0] = rec.t; o[1] = rec.p.x; o[2] = rec.p.y; o[3] = rec.p.z;
+        o[4] = rec.normal.x; o[5] = rec.normal.y; o[6] = rec.normal.z; o[7] = double(rec.mat);
+        o[8] = rec.u; o[9] = rec.v; o[10] = rec.front_face ? 1.0 : 0.0;
+        o[11] = ray.o.x; o[12] = ray.o.y; o[13] = ray.o.z; o[14] = ray.d.x; o[15] = ray.d.y; o[16] = ray.d.z; o[17] = ray.time;
+        ++n;
+        V3<R> att, em;
+        const bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, em, cnt);
+        o[18] = em.x; o[19] = cont ? att.x : -1.0;
+        if (!cont) break;
+        ps.bounce += 1;
+        if (ps.bounce >= rc.max_depth) break;
+    }
+    *n_out = int32_t(n);
+    // the same sample again through path_step(), exactly as the trace kernel runs it: radiance after `out`
+    path_begin(ps, cam, rc, px, row, sample);
+    while (path_step(ps, sc, rc, V3<R>(), t_min, stack, cnt)) {}
+    double* tail = out + size_t(max_out) * PROBE_STRIDE;
+    tail[0] = ps.radiance.x; tail[1] = ps.radiance.y; tail[2] = ps.radiance.z; tail[3] = double(ps.bounce);
+}
+
+} // namespace rt

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE — host build of the product's per-lane tracing core (rttnw_amd/csrc/rt_core.hpp)
 // and lowering, used by tests to debug/verify the kernel LOGIC in a container without a GPU and to
 // cross-check the device counters.  It is never loaded by the rttnw_amd package: the product path has
-// no CPU fallback.  Job order and per-job accumulation mirror render.hip's trace kernel exactly.
+// no CPU fallback.  Job order and per-job accumulation mirror trace_kernels.hpp's trace kernel exactly.
 #include "../../include/rttnw_hip.h"
 #include "../../rttnw_amd/csrc/rt_core.hpp"
 #include "../../rttnw_amd/csrc/scene_handle.hpp"
@@ -135,7 +135,7 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
             if (row >= rc.height) break;
             for (uint32_t px = 0; px < rc.width; ++px) {
                 V3<R> total;
-                for (uint32_t k = 0; k < n_pass; ++k) { // passes over consecutive sample ranges, as render.hip launches them
+                for (uint32_t k = 0; k < n_pass; ++k) { // passes over consecutive sample ranges, as render_tiles.hpp launches them
                     RenderConsts rp = rc;
                     const uint32_t b0 = pass_begin(p->spp, n_pass, k);
                     rp.spp = pass_begin(p->spp, n_pass, k + 1) - b0;
@@ -268,7 +268,7 @@ void hostsim_walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const 
 int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
                    rttnw_stats* stats, int n_threads) {
     if (!s || !s->committed || !cam || !p || !out_linear) return RTTNW_ERR_INVALID;
-    if (!s->flat.moving.empty() && (cam->open_time < s->flat.time0 || cam->close_time > s->flat.time1)) { // as render.hip validate()
+    if (!s->flat.moving.empty() && (cam->open_time < s->flat.time0 || cam->close_time > s->flat.time1)) { // as render_api.cpp validate()
         std::string err;
         FlatScene wider;
         if (int rc = lower_scene(s->graph, wider, err, nullptr, std::min(s->flat.time0, cam->open_time), std::max(s->flat.time1, cam->close_time))) return rc;

@@ -207,21 +207,19 @@ def test_full_size_invariants(gpu, scenes_lib, earth):
 @pytest.mark.parametrize("scene", [("cornell_box", 0), ("final_scene", 0), ("smoke_cornell_box", 0), ("spheres_1m", 20000)],
                          ids=lambda s: s[0])
 def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatch):
-    """The forms of the trace loop — lane-owns-path with the nodes in LDS, the same with the nodes in global memory, the
-    decoupled (queued) kernel that large scenes select, and its LDS-node variant with the rays kept in registers
-    (RTTNW_KERNEL=stream, experimental) — run the same per-path steps in different
-    schedules: their f64 images must be bit-identical (the library picks one by scene size; RTTNW_KERNEL forces it)."""
+    """The forms of the trace loop — lane-owns-path with the nodes in LDS, the same with the nodes in global memory, and the
+    decoupled (queued) kernel that large scenes select — run the same per-path steps in different schedules: their f64
+    images must be bit-identical (the library picks one by scene size; RTTNW_KERNEL forces it)."""
     name, param = scene
     sc, setup = util.build(gpu, scenes_lib, name, earth, param)
     cam, p = util.params_for(setup, 72, 56, 6, spp_chunk=2, precision=precision, seed=11, collect_counters=1)
     out = {}
-    for form in ("plain", "plainglobal", "wave", "stream"):
+    for form in ("plain", "plainglobal", "wave"):
         monkeypatch.setenv("RTTNW_KERNEL", form)
         lin, rgba, st = gpu_render(gpu, sc, cam, p)
-        fits = name != "spheres_1m"   # the stream form needs the node records in LDS: otherwise the library picks by itself
-        assert st.reserved == (1 if form == "wave" or (form == "stream" and fits) else 0)
+        assert st.reserved == (1 if form == "wave" else 0)
         out[form] = (lin, rgba, st.rays, st.nodes_visited, st.prims_tested)
-    for form in ("plainglobal", "wave", "stream"):
+    for form in ("plainglobal", "wave"):
         if precision == abi.F64 or form == "plainglobal":
             assert np.array_equal(out[form][0], out["plain"][0]), form
             assert np.array_equal(out[form][1], out["plain"][1]), form

@@ -11,6 +11,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -26,14 +27,33 @@ struct BuildPrim {
 };
 static_assert(sizeof(BuildPrim) == 32, "BuildPrim must be 32 bytes");
 
-// Build a tree over prims (size >= 2).  Appends its size-1 inner nodes to `nodes` (child slots already offset),
-// sets `root` (index into `nodes`) and `levels` (inner-node levels on the longest root-to-leaf path).
-using BvhBuilder = std::function<int(const std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes, int32_t& root,
-                                     uint32_t& levels, std::string& err)>;
+// A tree the device builder made and LEFT ON THE DEVICE ("the step before the path" hands its result
+// to the path without a round trip through the host): the 4-wide records the kernels walk (rt_types.hpp Bvh4Node, root =
+// record 0, records in the pre-order of the binary tree they were collapsed from) and, for inspection, the builder's binary
+// tree (BvhNode, pre-order, root = 0).  Child indices are LOCAL to the tree until `rebase` has added the tree's place in
+// the scene's node array.  The buffers are owned by the shared pointers (freed on the device they live on).
+struct DeviceTree {
+    std::shared_ptr<void> nodes4, nodes2;
+    uint32_t count4 = 0, count2 = 0; // records in nodes4 / nodes2
+    uint32_t need = 0;               // stack entries a walk of this tree can have pending (exact, as scene_lower.cpp collapse4 counts)
+    uint32_t levels = 0;             // inner levels of the binary tree
+    uint32_t base4 = 0, base2 = 0;   // where the tree sits in the scene's 4-wide / binary node arrays (set by the lowering)
+    int device = -1;
+};
 
-// The HIP implementation (bvh_build.hip); runs on the current device, synchronous.  `kernel_ms` (optional)
-// accumulates the device time of the build kernels + sort.
-int lbvh_build_device(const std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes, int32_t& root, uint32_t& levels,
-                      double* kernel_ms, std::string& err);
+// The device builder as the lowering sees it (scene_lower.cpp is plain C++: it calls through these).
+struct DeviceBvhApi {
+    // build a tree over prims (size >= 2) on the current device
+    std::function<int(const std::vector<BuildPrim>& prims, DeviceTree& out, std::string& err)> build;
+    // add base4 to the inner child indices of the tree's 4-wide records (and remember base4 / base2 in the tree)
+    std::function<int(DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& err)> rebase;
+};
+// Copy a device tree's records to the host (inspection, other devices): out4 / out2 may be null.
+int device_tree_download(const DeviceTree& tree, Bvh4Node* out4, BvhNode* out2, std::string& err);
+
+// The HIP implementation (bvh_build.hip); runs on the current device, synchronous.  `kernel_ms` (optional) accumulates the
+// device time of the build kernels + sort + collapse.
+int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& out, double* kernel_ms, std::string& err);
+int device_tree_rebase(DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& err);
 
 } // namespace rt

@@ -196,7 +196,7 @@ int rttnw_scene_commit(rttnw_scene* s) {
     if (!s) return fail(RTTNW_ERR_INVALID, "scene is NULL");
     if (s->committed) return RTTNW_OK; // idempotent
     std::string err;
-    rt::BvhBuilder device_builder;
+    rt::DeviceBvhApi device_builder;
     const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
     if (on_device)
         if (int brc = rt::device_bvh_builder(s, device_builder, err)) return fail(brc, err.c_str());
@@ -222,7 +222,7 @@ int rttnw_scene_build_info(const rttnw_scene* s, rttnw_build_info* out) {
     if (!s || !out) return fail(RTTNW_ERR_INVALID, "scene_build_info: NULL argument");
     if (!s->committed) return fail(RTTNW_ERR_STATE, "scene_build_info: scene is not committed");
     out->builder = s->bvh_builder;
-    out->n_nodes = uint32_t(s->flat.nodes4.size());
+    out->n_nodes = s->flat.total_nodes4();
     out->n_prims = s->flat.n_prims_in_bvh;
     out->stack_depth = s->flat.stack_depth;
     out->lower_ms = s->lower_ms;
@@ -232,6 +232,10 @@ int rttnw_scene_build_info(const rttnw_scene* s, rttnw_build_info* out) {
 
 int rttnw_debug_scene_nodes(const rttnw_scene* s, void* out_nodes, uint32_t max_nodes, int32_t* top_root) {
     if (!s || !s->committed) return fail(RTTNW_ERR_STATE, "debug_scene_nodes: scene is not committed");
+    {   // trees the device builder left on the device are fetched when someone looks (once)
+        std::string err;
+        if (int rc = rt::materialize_host_nodes(const_cast<rttnw_scene*>(s)->flat, err)) return fail(rc, err.c_str());
+    }
     const uint32_t n = uint32_t(std::min<size_t>(s->flat.nodes.size(), max_nodes));
     if (out_nodes && n) std::memcpy(out_nodes, s->flat.nodes.data(), size_t(n) * sizeof(rt::BvhNode));
     if (top_root) *top_root = s->flat.top_root2;
@@ -240,6 +244,10 @@ int rttnw_debug_scene_nodes(const rttnw_scene* s, void* out_nodes, uint32_t max_
 
 int rttnw_debug_scene_nodes4(const rttnw_scene* s, void* out_nodes, uint32_t max_nodes, int32_t* top_root) {
     if (!s || !s->committed) return fail(RTTNW_ERR_STATE, "debug_scene_nodes4: scene is not committed");
+    {
+        std::string err;
+        if (int rc = rt::materialize_host_nodes(const_cast<rttnw_scene*>(s)->flat, err)) return fail(rc, err.c_str());
+    }
     const uint32_t n = uint32_t(std::min<size_t>(s->flat.nodes4.size(), max_nodes));
     if (out_nodes && n) std::memcpy(out_nodes, s->flat.nodes4.data(), size_t(n) * sizeof(rt::Bvh4Node));
     if (top_root) *top_root = s->flat.top_root;

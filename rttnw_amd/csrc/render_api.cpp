@@ -42,15 +42,29 @@ void device_release(DeviceState* d) {
     delete d;
 }
 
-int device_bvh_builder(::rttnw_scene* s, BvhBuilder& out, std::string& err) {
+int device_bvh_builder(::rttnw_scene* s, DeviceBvhApi& out, std::string& err) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         err = "no HIP device available (the device BVH builder has no CPU fallback)";
         return RTTNW_ERR_HIP;
     }
-    out = [s](const std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes, int32_t& root, uint32_t& levels, std::string& e) {
-        return lbvh_build_device(prims, nodes, root, levels, &s->build_kernel_ms, e);
+    out.build = [s](const std::vector<BuildPrim>& prims, DeviceTree& tree, std::string& e) {
+        return lbvh_build_device_tree(prims, tree, &s->build_kernel_ms, e);
     };
+    out.rebase = [](DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& e) { return device_tree_rebase(tree, base4, base2, e); };
+    return 0;
+}
+
+int materialize_host_nodes(FlatScene& f, std::string& err) {
+    if (f.device_trees.empty() || f.nodes4.size() == f.total_nodes4()) return 0;
+    f.nodes4.resize(f.total_nodes4());
+    f.nodes.resize(f.total_nodes2());
+    for (const DeviceTree& t : f.device_trees)
+        if (device_tree_download(t, f.nodes4.data() + t.base4, f.nodes.data() + t.base2, err)) {
+            f.nodes4.resize(f.n_host4);
+            f.nodes.resize(f.n_host2);
+            return RTTNW_ERR_HIP;
+        }
     return 0;
 }
 
@@ -110,7 +124,7 @@ int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
         if (!s->flat.moving.empty() && (cam->open_time < s->flat.time0 || cam->close_time > s->flat.time1)) {
             const double t0 = std::min(s->flat.time0, cam->open_time), t1 = std::max(s->flat.time1, cam->close_time);
             std::string err;
-            BvhBuilder device_builder;
+            DeviceBvhApi device_builder;
             const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
             if (on_device)
                 if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
@@ -164,10 +178,10 @@ int rttnw_tile_layout_get(uint32_t width, uint32_t height, uint32_t world, rttnw
 int rttnw_scene_info(rttnw_scene* s, rttnw_stats* out) {
     if (!s || !out || !s->committed) { rt::set_last_error("scene_info: scene not committed"); return RTTNW_ERR_STATE; }
     std::memset(out, 0, sizeof(*out));
-    out->n_nodes = uint32_t(s->flat.nodes4.size());
+    out->n_nodes = s->flat.total_nodes4();
     out->n_prims = s->flat.n_prims_in_bvh;
     const auto& f = s->flat;
-    size_t b32 = f.nodes4.size() * sizeof(rt::Bvh4Node) + f.spheres.size() * sizeof(rt::SphereRec<float>) +
+    size_t b32 = size_t(f.total_nodes4()) * sizeof(rt::Bvh4Node) + f.spheres.size() * sizeof(rt::SphereRec<float>) +
                  f.moving.size() * sizeof(rt::MovingSphereRec<float>) + f.rects.size() * sizeof(rt::RectRec<float>) +
                  f.boxes.size() * sizeof(rt::BoxRec<float>) + f.insts.size() * sizeof(rt::InstanceRec<float>);
     out->scene_bytes = uint32_t(std::min<size_t>(b32, 0xFFFFFFFFu));

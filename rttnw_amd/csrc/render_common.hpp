@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
 #include <chrono>
 #include <mutex>
 #include <type_traits>
@@ -44,9 +45,17 @@ template <typename T> struct DevBuf {
         return 0;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && !adopted) (void)hipFree(p);
+        adopted.reset();
         p = nullptr;
         n = 0;
+    }
+    std::shared_ptr<void> adopted; // set: p is a buffer someone else made on this device (a device-built tree); kept alive, not freed here
+    void adopt(const std::shared_ptr<void>& buf, size_t count) {
+        release();
+        adopted = buf;
+        p = (T*)buf.get();
+        n = count;
     }
 };
 
@@ -69,6 +78,35 @@ template <typename R> struct DeviceScene {
     DevBuf<uint8_t> perlin_perm;
     SceneView<R> view{};
     size_t bytes = 0;
+
+    // The scene's node array on the current device: the host-built records followed by the device-built trees.  A scene whose
+    // nodes are ONE device-built tree on this very device (spheres_1m: 57 MB) simply adopts the builder's buffer; otherwise the
+    // pieces are put together — device-to-device for trees built here, through the host copy (materialize_host_nodes) for
+    // trees built on another device.
+    int upload_nodes(const FlatScene& f) {
+        int dev = -1;
+        HIP_TRY(hipGetDevice(&dev));
+        if (f.device_trees.empty()) return nodes.upload(f.nodes4);
+        if (f.n_host4 == 0 && f.device_trees.size() == 1 && f.device_trees[0].device == dev) {
+            nodes.adopt(f.device_trees[0].nodes4, f.device_trees[0].count4);
+            return 0;
+        }
+        nodes.release();
+        const size_t total = f.total_nodes4();
+        HIP_TRY(hipMalloc((void**)&nodes.p, std::max<size_t>(total, 1) * sizeof(Bvh4Node)));
+        nodes.n = total;
+        if (f.n_host4) HIP_TRY(hipMemcpy(nodes.p, f.nodes4.data(), size_t(f.n_host4) * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+        for (const DeviceTree& t : f.device_trees) {
+            if (t.device == dev) {
+                HIP_TRY(hipMemcpy(nodes.p + t.base4, t.nodes4.get(), size_t(t.count4) * sizeof(Bvh4Node), hipMemcpyDeviceToDevice));
+            } else {
+                std::string err;
+                if (int mrc = materialize_host_nodes(const_cast<FlatScene&>(f), err)) { set_last_error(err); return mrc; }
+                HIP_TRY(hipMemcpy(nodes.p + t.base4, f.nodes4.data() + t.base4, size_t(t.count4) * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+            }
+        }
+        return 0;
+    }
 
     int upload(const FlatScene& f) {
         std::vector<SphereRec<R>> sp;
@@ -109,7 +147,7 @@ template <typename R> struct DeviceScene {
         for (double v : f.perlin_vec) pv.push_back(R(v));
 
         int rc;
-        if ((rc = nodes.upload(f.nodes4)) || (rc = spheres.upload(sp)) || (rc = sphere_mat.upload(f.sphere_mat)) ||
+        if ((rc = upload_nodes(f)) || (rc = spheres.upload(sp)) || (rc = sphere_mat.upload(f.sphere_mat)) ||
             (rc = sphere_seq.upload(f.sphere_seq)) || (rc = moving.upload(mv)) || (rc = rects.upload(rc_)) ||
             (rc = boxes.upload(bx)) || (rc = insts.upload(in)) || (rc = media.upload(md)) || (rc = medium_refs.upload(f.medium_refs)) || (rc = mats.upload(mt)) ||
             (rc = texs.upload(tx)) || (rc = images.upload(f.images)) || (rc = texels.upload(f.texels)) ||
@@ -121,7 +159,7 @@ template <typename R> struct DeviceScene {
         view.perlin_vec = perlin_vec.p; view.perlin_perm = perlin_perm.p;
         view.top_root = f.top_root;
         view.n_media = int32_t(f.media.size());
-        bytes = f.nodes4.size() * sizeof(Bvh4Node) + sp.size() * sizeof(SphereRec<R>) + mv.size() * sizeof(MovingSphereRec<R>) +
+        bytes = size_t(f.total_nodes4()) * sizeof(Bvh4Node) + sp.size() * sizeof(SphereRec<R>) + mv.size() * sizeof(MovingSphereRec<R>) +
                 rc_.size() * sizeof(RectRec<R>) + bx.size() * sizeof(BoxRec<R>) + in.size() * sizeof(InstanceRec<R>);
         ready = true;
         return 0;

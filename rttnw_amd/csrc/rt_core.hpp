@@ -11,10 +11,6 @@
 #include "rt_types.hpp"
 #include <math.h>
 
-#ifndef RT_DEFER_UV
-#define RT_DEFER_UV 1 // experiments: 0 evaluates a sphere's (u, v) at the hit in every kernel
-#endif
-
 #ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 2 // node steps per trip round the walk loop (closest_solid)
 #endif
@@ -218,12 +214,8 @@ template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bo
 // Counter policies.  Their template flag GENERAL also selects, at compile time, whether the code for the rare graph shapes
 // (more than FAST_INSTANCE_OPS wrappers around an object, List / BvhTree medium boundaries, media inside transformed groups;
 // FlatScene::needs_general) is compiled into a kernel at all: it costs the common kernels registers even when it never runs.
-// EXACT_UV: a sphere's (u, v) are always evaluated with the reference's f64 acos / atan2 at the hit (the per-bounce probes, which
-// report them); otherwise the f64 kernels defer them to the one place that reads them, the image texture's texel choice,
-// and make that choice in f32 wherever f32 is certain of it (texture_value).
-template <bool G, bool XUV = false> struct NoCountersT {
+template <bool G> struct NoCountersT {
     static constexpr bool GENERAL = G;
-    static constexpr bool EXACT_UV = XUV;
     RT_HD void ray() {}
     RT_HD void node() {}
     RT_HD void prim() {}
@@ -231,15 +223,13 @@ template <bool G, bool XUV = false> struct NoCountersT {
 };
 template <bool G> struct LaneCountersT {
     static constexpr bool GENERAL = G;
-    static constexpr bool EXACT_UV = false;
     uint32_t rays = 0, nodes = 0, prims = 0, texels = 0;
     RT_HD void ray() { ++rays; }
     RT_HD void node() { ++nodes; }
     RT_HD void prim() { ++prims; }
     RT_HD void texel() { ++texels; }
 };
-using NoCounters = NoCountersT<true>;     // host build: every shape
-using ProbeCounters = NoCountersT<true, true>; // the per-bounce probes: every shape, (u, v) evaluated at every hit that reads them
+using NoCounters = NoCountersT<true>;     // host build, probes: every shape
 using LaneCounters = LaneCountersT<true>;
 
 // ---------------------------------------------------------------- camera (camera.rs:63-84)
@@ -276,17 +266,21 @@ template <typename R> struct SlabRay { // what a ray contributes to every slab t
 };
 // f64: the boxes are f32 and only cull, so the f64 kernels test them in f32 too — CONSERVATIVELY, which the f32
 // kernels need not be: origin and 1/d are rounded to f32 once per walk (1/d as v_rcp_f32 of the rounded d: 1 ulp — three
-// f64 divisions per walk start, instance entry and instance exit were 5 % of the f64 kernel's instructions), and every
-// plane distance is widened by a bound on what that rounding can have done to it.  With o32 = o(1+e), |e| <= 2^-24,
-// inv32 = inv(1+e'), |e'| <= 2^-24 + 2^-23:
-//   t32 = fl(fl(b - o32) inv32) = t (1+E) - (o32 - o) inv (1+E),  |E| <= 2 * 2^-24 + |e'| + ...  ~ 3.0e-7
-//   |t32 - t| <= 3.0e-7 |t| + 6.0e-8 |o inv|      (t = (b - o) inv exactly, b a float)
-// so near planes move down and far planes up by 3.6e-7 |t32| + slack, slack = 1.2e-7 |o32 inv32|, the range's ends
-// are rounded outward, and NaN / inf (axis-parallel rays) never cull.  A box the exact test would pass always
-// passes: images and hits are those of f64 slab tests, a node step costs about a third (f64 runs at half rate and
-// selects move register pairs).
+// f64 divisions per walk start, instance entry and instance exit were 5 % of the f64 kernel's instructions), a plane
+// distance is ONE fused multiply-add, t32 = fl(b inv32 - oi32) with oi32 = fl(o32 inv32) kept per walk (round 3: 6 instead
+// of 12 operations per box, a sixth of a node step), and every plane distance is widened by a bound on what the roundings
+// can have done to it.  With o32 = o(1+e0), |e0| <= 2^-24, inv32 = inv(1+e1), |e1| <= 2^-24 + 2^-23, oi32 = o32 inv32 (1+e2),
+// |e2| <= 2^-24, and the fma's single rounding e3:
+//   t32 = [ (b - o) inv (1+e1) - o inv (1+e1)((1+e0)(1+e2) - 1) ] (1+e3)
+//   |t32 - t| <= 2.4e-7 |t| + 1.2e-7 |o inv|          (t = (b - o) inv exactly, b a float)
+// so near planes move down and far planes up by 3.6e-7 |t32| + slack, slack = 2.4e-7 |oi32| (twice the bound, as before;
+// the two-operation form fl(fl(b - o32) inv32) it replaces had 6e-8 |o inv| there and used 1.2e-7), the range's ends are
+// rounded outward, and NaN / inf (axis-parallel rays) never cull.  A box the exact test would pass always passes: images
+// and hits are those of f64 slab tests, a node step costs about a third (f64 runs at half rate and selects move register
+// pairs).  (The f32 kernels keep the two-operation form: they carry no slack, and the fma form's absolute error
+// eps |o inv| is larger than a leaf for spheres_1m's far-away primary rays.)
 template <> struct SlabRay<double> {
-    float o[3], inv[3];
+    float oinv[3], inv[3]; // o * (1 / d) and 1 / d: a plane distance is ONE fma, plane * inv - oinv (below)
     float slack; // the largest of the three axes' slacks: one widening of the box's entry / exit serves all planes (below)
 };
 template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
@@ -296,7 +290,7 @@ template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
         sr.slack = 0.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            sr.o[a] = float(oo[a]);
+            const float o32 = float(oo[a]);
             float inv = rt_rcp(float(dd[a]));
             // an axis the ray is exactly parallel to (or whose direction component underflows in f32): 1/d = inf would make
             // the ONE slack below infinite and the whole walk lose its culling.  NaN instead: every plane distance of this
@@ -304,7 +298,8 @@ template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
             // exact test could at most cull more) and stays out of the slack.
             if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
             sr.inv[a] = inv;
-            sr.slack = rt_max(sr.slack, rt_fabs(sr.o[a] * inv) * 1.2e-7f); // maxNum: a NaN axis drops out
+            sr.oinv[a] = o32 * inv;
+            sr.slack = rt_max(sr.slack, rt_fabs(sr.oinv[a]) * 2.4e-7f); // maxNum: a NaN axis drops out
         }
     } else {
         sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -327,6 +322,16 @@ template <typename R> RT_HD uint32_t near_piece(int a, const SlabRay<R>& sr) {
 // near-plane distance, tf[c] = the smallest far-plane distance.  (As 24 PACKED f32 operations — v_pk_add_f32 / v_pk_mul_f32
 // with the ray's component splat by op_sel, which the by-axis layout makes natural — it measured SLOWER: final_scene f32
 // 1389 against 1452, spheres_1m 340 against 397: on wave64 a packed operation issues no faster than its two halves.)
+RT_HD void slab4_planes_fma(const Planes4& nd, const float oinv[3], const float inv[3], float tn[4], float tf[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float nx = __builtin_fmaf(nd.nr[0][c], inv[0], -oinv[0]), fx = __builtin_fmaf(nd.fr[0][c], inv[0], -oinv[0]);
+        const float ny = __builtin_fmaf(nd.nr[1][c], inv[1], -oinv[1]), fy = __builtin_fmaf(nd.fr[1][c], inv[1], -oinv[1]);
+        const float nz = __builtin_fmaf(nd.nr[2][c], inv[2], -oinv[2]), fz = __builtin_fmaf(nd.fr[2][c], inv[2], -oinv[2]);
+        tn[c] = rt_max(nz, rt_max(ny, nx));
+        tf[c] = rt_min(fz, rt_min(fy, fx));
+    }
+}
 RT_HD void slab4_planes(const Planes4& nd, const float o[3], const float inv[3], float tn[4], float tf[4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -344,7 +349,7 @@ RT_HD void slab4_planes(const Planes4& nd, const float o[3], const float inv[3],
 // would pass still always passes.  NaN / inf (axis-parallel rays) never cull.
 RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float e[4], bool h[4]) {
     float tn[4], tf[4];
-    slab4_planes(nd, sr.o, sr.inv, tn, tf);
+    slab4_planes_fma(nd, sr.oinv, sr.inv, tn, tf);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float n = __builtin_fmaf(-rt_fabs(tn[c]), 3.6e-7f, tn[c]) - sr.slack;
@@ -837,7 +842,6 @@ template <typename R> struct HitRecord { // hittable.rs:15-27
     R u, v;
     int32_t mat;
     bool front_face;
-    bool uv_deferred; // a sphere's (u, v) have not been evaluated: `normal` (= +-outward, by front_face) still determines them
 };
 template <typename R> RT_HD void face_normal(V3<R> dir, V3<R> outward, V3<R>& normal, bool& front) { // hittable.rs:30-44
     front = dot(dir, outward) < R(0);
@@ -855,10 +859,9 @@ template <typename R> RT_HD void sphere_uv(V3<R> p, R& u, R& v) { // hittable.rs
 // an image texture — possibly under a checker — ever reads them: they are computed only then.  Same results.
 RT_HD bool uv_is_read(int32_t mat_ref) { return (mat_ref & MAT_UV_FLAG) != 0; } // decided by the lowering, see MAT_UV_FLAG
 
-template <bool G, bool XUV = true, typename R>
+template <bool G, typename R>
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim);
-    rec.uv_deferred = false;
     uint32_t idx = ref_index(ref.prim);
     if (kind == PRIM_SPHERE && ref.inst < 0) { // the world-space copy of a transformed group's sphere: its record is made in
         const int32_t home = sc.sphere_mat[idx]; // object space through the group's chain, like the reference's (scene_lower.cpp)
@@ -876,17 +879,9 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         const int32_t mref = sc.sphere_mat[idx];
         rec.mat = mref & MAT_INDEX_MASK;
         rec.u = R(0); rec.v = R(0);
-        if (uv_is_read(mref)) {
-            // f64: Sphere::uv's acos + atan2 (hittable.rs:77-83) are ~250 instructions that the whole wave issues for the few
-            // lanes on an image-textured sphere, and all they feed is a nearest-texel index (texture.rs:78-101).  An untransformed
-            // sphere leaves them to texture_value(): `normal` is +-outward exactly, nothing else is needed.
-            if constexpr (sizeof(R) == 8 && !XUV && RT_DEFER_UV) {
-                if (ref.inst < 0) rec.uv_deferred = true;
-                else sphere_uv(outward, rec.u, rec.v);
-            } else {
-                sphere_uv(outward, rec.u, rec.v);
-            }
-        }
+        // (f64: deferring these ~250 instructions to the image texture's texel choice, made in f32 wherever f32 is certain of the
+        // texel and in f64 otherwise, was built, bit-identical and 1 % SLOWER — profiles/r03/README.md)
+        if (uv_is_read(mref)) sphere_uv(outward, rec.u, rec.v);
     } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
         const MovingSphereRec<R> m = sc.moving[idx];
         rec.p = ray.at(t);
@@ -1027,7 +1022,6 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
         rec.t = closest;
         rec.normal = V3<R>(R(1), R(0), R(0));
         rec.front_face = true;
-        rec.uv_deferred = false;
         rec.u = R(0); rec.v = R(0);
         rec.mat = md.mat;
         rec.p = ray.at(closest);
@@ -1038,7 +1032,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
                 unwind_record<true>(in, md.n_outer, ray.d, quirks, rec.p, rec.normal, rec.front_face);
             }
     } else {
-        make_record<Cnt::GENERAL, Cnt::EXACT_UV>(sc, ray, best, closest, quirks, rec);
+        make_record<Cnt::GENERAL>(sc, ray, best, closest, quirks, rec);
     }
     return true;
 }
@@ -1097,33 +1091,6 @@ template <typename R> RT_HD void image_texel(const ImageRec& im, R u, R v, uint3
     if (i >= im.w) i = im.w - 1;
     if (j >= im.h) j = im.h - 1;
 }
-// The same texel for a sphere hit whose (u, v) were deferred (make_record), from the outward unit normal n.  Sphere::uv
-// (hittable.rs:77-83) in f32 first: theta = acos(-n.y), phi = atan2(-n.z, n.x) + pi, texel = (phi / 2 pi * w, (1 - theta / pi) * h).
-// With n rounded to f32 (relative 2^-24 per component) and OCML's acosf / atan2f (<= 2-3 ulp):
-//   |d phi|   <= 2^-23 (conditioning of atan2 in its two inputs) + 3 ulp(2 pi)            < 2.0e-6 rad -> < 3.2e-7 w texels
-//   |d theta| <= 2^-24 / sqrt(1 - n.y^2) + 3 ulp(pi)  <= 2^-24 * 22.4 + 7.2e-7 < 2.1e-6 rad -> < 6.7e-7 h texels  while |n.y| <= 0.999
-// so a texel coordinate farther than 4e-6 w (8e-6 h) from the nearest integer — six and twelve times those bounds — is on the
-// same side of it in f64 and the f32 index IS the reference's index; nearer than that, or within 0.001 of a pole, the f64
-// expressions decide (about 1.5 % of the hits of a 1200 x 600 map).  Either way the texel is the reference's.
-template <typename R> RT_HD void image_texel_deferred(const ImageRec& im, V3<R> n, uint32_t& i, uint32_t& j) {
-    const float nx = float(n.x), ny = float(n.y), nz = float(n.z);
-    const float pi = 3.14159265358979323846f;
-    const float theta = acosf(-ny), phi = atan2f(-nz, nx) + pi;
-    const float fw = float(im.w), fh = float(im.h);
-    const float fi = phi * (0.15915494309189533577f * fw), fj = (1.0f - theta * 0.31830988618379067154f) * fh;
-    const float ri = rintf(fi), rj = rintf(fj);
-    const bool sure = rt_fabs(fi - ri) > 4e-6f * fw && rt_fabs(fj - rj) > 8e-6f * fh && rt_fabs(ny) <= 0.999f && fi > 0.f && fj > 0.f &&
-                      fi < fw && fj < fh;
-    if (sure) {
-        i = uint32_t(fi);
-        j = uint32_t(fj);
-    } else {
-        R u, v;
-        sphere_uv(n, u, v);
-        image_texel(im, u, v, i, j);
-    }
-}
-
 template <typename R, typename Cnt>
 RT_HD V3<R> texture_value(const SceneView<R>& sc, int32_t tex, const HitRecord<R>& rec, Cnt& cnt) {
     const V3<R> p = rec.p;
@@ -1144,8 +1111,7 @@ RT_HD V3<R> texture_value(const SceneView<R>& sc, int32_t tex, const HitRecord<R
         if (t.type == TEX_IMAGE) { // texture.rs:78-101
             const ImageRec im = sc.images[t.a];
             uint32_t i, j;
-            if (rec.uv_deferred) image_texel_deferred(im, rec.front_face ? rec.normal : -rec.normal, i, j);
-            else image_texel(im, rec.u, rec.v, i, j);
+            image_texel(im, rec.u, rec.v, i, j);
             cnt.texel();
             uint32_t px = sc.texels[im.offset + size_t(j) * im.w + i];
             const R s = R(1) / R(255);

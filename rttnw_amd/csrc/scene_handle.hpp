@@ -14,7 +14,11 @@ int device_commit(struct ::rttnw_scene* s, std::string& err);
 void device_release(DeviceState* d);
 // The device BVH builder bound to scene `s` (accumulates its kernel time in s->build_kernel_ms); fails without a
 // usable HIP device.  Defined in render_api.cpp (and as a failing stub in the host-only test build).
-int device_bvh_builder(struct ::rttnw_scene* s, BvhBuilder& out, std::string& err);
+int device_bvh_builder(struct ::rttnw_scene* s, DeviceBvhApi& out, std::string& err);
+// Bring the records of the device-built trees into f.nodes4 / f.nodes (behind their host-built part), once; a no-op for scenes
+// without device trees.  Inspection calls and the upload to a second device use it; the render path on the building device
+// never does.  Defined in render_api.cpp (a no-op stub in the host-only test build, which has no device trees).
+int materialize_host_nodes(FlatScene& f, std::string& err);
 void set_last_error(const std::string& msg);
 } // namespace rt
 

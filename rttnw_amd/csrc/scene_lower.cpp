@@ -116,11 +116,11 @@ struct Lowering {
     std::string& err;
     std::vector<int32_t> tex_index, mat_index; // graph id -> flat index
     int rc = 0;
-    const BvhBuilder* builder = nullptr;
+    const DeviceBvhApi* builder = nullptr; // the device builder, or null: host binned SAH
     size_t max_leaf = 4; // records per leaf of the host SAH build (lower_scene picks it)
     double time0 = 0.0, time1 = 1.0; // shutter interval the moving spheres' boxes must cover
 
-    Lowering(const SceneGraph& graph, FlatScene& flat, std::string& error, const BvhBuilder* bvh_builder, size_t leaf_records, double t0, double t1)
+    Lowering(const SceneGraph& graph, FlatScene& flat, std::string& error, const DeviceBvhApi* bvh_builder, size_t leaf_records, double t0, double t1)
         : g(graph), fs(flat), err(error), builder(bvh_builder), max_leaf(leaf_records), time0(t0), time1(t1) {}
 
     int fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return code; }
@@ -319,6 +319,7 @@ struct Lowering {
 
     // Build a BVH whose root is always a node record.  Returns the root index; `depth_out` = levels of inner nodes on
     // the longest root-to-leaf path (what bounds the traversal stack: one pending sibling per inner level).
+    static constexpr int32_t DEVICE_ROOT = 0x40000000; // build_root's result for a tree the device builder made: DEVICE_ROOT + its index in fs.device_trees
     int32_t build_root(std::vector<Item>& items, uint32_t& depth_out, Box3& box_out) {
         uint32_t md = 0;
         if (items.empty()) {
@@ -342,12 +343,12 @@ struct Lowering {
                 box_out.grow(items[i].box);
             }
             fs.n_prims_in_bvh += uint32_t(items.size());
-            int32_t root = 0;
-            uint32_t levels = 0;
+            DeviceTree tree;
             std::string berr;
-            if (int brc = (*builder)(prims, fs.nodes, root, levels, berr)) { fail(brc, berr); depth_out = 1; return 0; }
-            depth_out = levels;
-            return root;
+            if (int brc = builder->build(prims, tree, berr)) { fail(brc, berr); depth_out = 1; return 0; }
+            depth_out = tree.levels;
+            fs.device_trees.push_back(std::move(tree));
+            return DEVICE_ROOT + int32_t(fs.device_trees.size() - 1); // a handle: the tree's place in the node array is known only at the end (run())
         }
         // reserve the root slot first so that it precedes its subtree
         int32_t code = build(items, 0, items.size(), 1, md, box_out);
@@ -685,23 +686,48 @@ struct Lowering {
         fs.top_root2 = build_root(top, top_depth, wb);
         if (rc) return rc;
         const auto t_built = now();
-        // The kernels walk 4-wide records: collapse the top tree and every instance's tree.
+        // The kernels walk 4-wide records: collapse the host-built trees here; the device builder has collapsed its own.
+        // The node array is [host-built records][device tree 0][device tree 1]...: the device trees learn their place now.
         uint32_t top_need = 0, inst_need = 0;
-        fs.top_root = collapse4(fs.top_root2, top_need);
+        if (fs.top_root2 < DEVICE_ROOT) fs.top_root = collapse4(fs.top_root2, top_need);
         bool any_tree = false;
         for (auto& in : fs.insts) {
             if (in.root < 0) continue; // a medium's transform chain: no tree
+            any_tree = true;
+            if (in.root >= DEVICE_ROOT) continue;
             uint32_t need = 0;
             in.root = collapse4(in.root, need);
             inst_need = std::max(inst_need, need);
-            any_tree = true;
         }
+        fs.n_host4 = uint32_t(fs.nodes4.size());
+        fs.n_host2 = uint32_t(fs.nodes.size());
+        {
+            uint32_t base4 = fs.n_host4, base2 = fs.n_host2;
+            for (DeviceTree& t : fs.device_trees) {
+                std::string berr;
+                if (int brc = builder->rebase(t, base4, base2, berr)) return fail(brc, berr);
+                base4 += t.count4;
+                base2 += t.count2;
+            }
+        }
+        if (fs.top_root2 >= DEVICE_ROOT) {
+            const DeviceTree& t = fs.device_trees[size_t(fs.top_root2 - DEVICE_ROOT)];
+            fs.top_root = int32_t(t.base4); // record 0 of a device tree is its root
+            fs.top_root2 = int32_t(t.base2);
+            top_need = t.need;
+        }
+        for (auto& in : fs.insts)
+            if (in.root >= DEVICE_ROOT) {
+                const DeviceTree& t = fs.device_trees[size_t(in.root - DEVICE_ROOT)];
+                in.root = int32_t(t.base4);
+                inst_need = std::max(inst_need, t.need);
+            }
         // Entries a lane's stack can hold at once: the pending children of the top tree and, while inside an instance,
         // one sentinel plus the pending children of the instance's tree.  +1 spare.
         fs.stack_depth = top_need + (any_tree ? 1u + inst_need : 0u) + 1u;
         if (timing)
             fprintf(stderr, "[lower] collect %.1f ms, top tree (%zu items) %.1f ms, 4-wide collapse (%zu -> %zu records) %.1f ms\n", ms(t_start, t_collected),
-                    top.size(), ms(t_collected, t_built), fs.nodes.size(), fs.nodes4.size(), ms(t_built, now()));
+                    top.size(), ms(t_collected, t_built), size_t(fs.total_nodes2()), size_t(fs.total_nodes4()), ms(t_built, now()));
         for (const auto& in : fs.insts) fs.needs_general = fs.needs_general || in.n_ops > FAST_INSTANCE_OPS;
         for (const auto& md : fs.media) fs.needs_general = fs.needs_general || md.b_count > 1 || md.n_outer > 0;
         return 0;
@@ -716,9 +742,9 @@ struct Lowering {
 // instead of 891 no longer fit beside the stacks, -14 %).  So: the finest of 1 / 2 / 4 records per leaf whose tree
 // still fits; big scenes (which never fit) take 4 and save a third of the node memory.
 static bool fits_lds_form(const FlatScene& f) {
-    return lds_form_bytes(uint32_t(f.nodes4.size()), f.stack_depth, 1024) <= 160 * 1024;
+    return lds_form_bytes(f.total_nodes4(), f.stack_depth, 1024) <= 160 * 1024;
 }
-int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder, double time0, double time1) {
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const DeviceBvhApi* builder, double time0, double time1) {
     const bool small = g.objs.size() <= 8192 && builder == nullptr;
     const char* forced = getenv("RTTNW_MAX_LEAF"); // experiments: force the leaf size of the host SAH build (1, 2 or 4)
     for (size_t max_leaf : {size_t(1), size_t(2), size_t(4)}) {

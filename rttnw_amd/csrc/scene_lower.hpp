@@ -41,6 +41,14 @@ struct FlatScene {
     std::vector<BvhNode> nodes;   // the builders' binary trees (kept for inspection: rttnw_debug_scene_nodes); not uploaded
     std::vector<Bvh4Node> nodes4; // what the kernels walk: the same trees collapsed to 4-wide records
     int32_t top_root2 = 0;        // root of the top-level binary tree in `nodes`
+    // Trees the DEVICE builder made stay on the device (bvh_build.hpp DeviceTree): the scene's node array is the n_host4
+    // host-built records of `nodes4` followed by the device trees in order (tree.base4 = where each starts; likewise base2 /
+    // n_host2 for the binary records).  `nodes4` / `nodes` hold only their host-built part until someone asks to look at
+    // the rest (materialize_host_nodes(), scene_handle.hpp: inspection calls, a second device).
+    std::vector<DeviceTree> device_trees;
+    uint32_t n_host4 = 0, n_host2 = 0;
+    uint32_t total_nodes4() const { uint32_t n = n_host4; for (const auto& t : device_trees) n += t.count4; return n; }
+    uint32_t total_nodes2() const { uint32_t n = n_host2; for (const auto& t : device_trees) n += t.count2; return n; }
     std::vector<SphereRec<double>> spheres;
     std::vector<int32_t> sphere_mat;
     std::vector<int32_t> sphere_seq;
@@ -64,9 +72,10 @@ struct FlatScene {
     uint32_t n_prims_in_bvh = 0;
 };
 
-// Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.  `builder` (optional)
-// replaces the host binned-SAH build for every tree of two or more leaves (bvh_build.hpp).
-int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const BvhBuilder* builder = nullptr, double time0 = 0.0,
+// Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.  `device` (optional)
+// replaces the host binned-SAH build for every tree of two or more leaves by the device builder (bvh_build.hpp); those
+// trees stay on the device.
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const DeviceBvhApi* device = nullptr, double time0 = 0.0,
                 double time1 = 1.0);
 
 // Camera::new — camera.rs:32-61 (computed once on the host, in f64)

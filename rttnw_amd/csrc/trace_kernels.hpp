@@ -638,7 +638,7 @@ __global__ void probe_path_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConst
     extern __shared__ int32_t lds_stack[];
     if (threadIdx.x != 0) return;
     LdsStack<64> stack{(LdsIntPtr)lds_stack, (GlobalIntPtr)spill, 1u};
-    ProbeCounters cnt; // every graph shape; (u, v) evaluated at every hit that reads them (the trace kernels defer them, rt_core.hpp)
+    NoCounters cnt;
     PathState<R> ps;
     path_begin(ps, cam, rc, px, row, sample);
     uint32_t n = 0;

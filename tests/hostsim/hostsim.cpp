@@ -15,10 +15,11 @@
 namespace rt {
 int device_commit(::rttnw_scene*, std::string&) { return 0; } // no device in the host build
 void device_release(DeviceState*) {}
-int device_bvh_builder(::rttnw_scene*, BvhBuilder&, std::string& err) {
+int device_bvh_builder(::rttnw_scene*, DeviceBvhApi&, std::string& err) {
     err = "the host test build has no device BVH builder";
     return RTTNW_ERR_HIP;
 }
+int materialize_host_nodes(FlatScene&, std::string&) { return 0; } // no device trees without a device builder
 } // namespace rt
 
 namespace {
@@ -191,7 +192,7 @@ static int probe_path_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttn
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth; rc.quirks = p->quirks; rc.seed = p->seed;
     PathState<R> ps;
     path_begin(ps, camr, rc, px, row, sample);
-    HostStack stack; ProbeCounters cnt;
+    HostStack stack; NoCounters cnt;
     uint32_t n = 0;
     while (n < max_out) { // same record layout as rttnw_debug_probe_path (include/rttnw_hip.h): 20 doubles per bounce
         HitRecord<R> rec;
@@ -289,19 +290,6 @@ int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t n_tiles, uint32_t w
     const bool ok = plan_jobs(rc);
     out[0] = rc.spp_chunk; out[1] = rc.n_main; out[2] = rc.n_chunks; out[3] = rc.n_jobs; out[4] = n_pass; out[5] = rc.spp;
     return ok ? 0 : -1;
-}
-// The texel an image texture of w x h reads for a sphere hit with outward unit normal n, by the deferred f32-first choice the
-// f64 kernels make (rt_core.hpp image_texel_deferred) and by the reference's f64 expressions (Sphere::uv + ImageTexture::value).
-int hostsim_texel_choice(uint32_t n, const double* normals, uint32_t w, uint32_t h, uint32_t* fast_ij, uint32_t* exact_ij) {
-    const ImageRec im{0u, w, h, 0u};
-    for (uint32_t k = 0; k < n; ++k) {
-        const V3<double> nn(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2]);
-        image_texel_deferred(im, nn, fast_ij[2 * k], fast_ij[2 * k + 1]);
-        double u, v;
-        sphere_uv(nn, u, v);
-        image_texel(im, u, v, exact_ij[2 * k], exact_ij[2 * k + 1]);
-    }
-    return 0;
 }
 // Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).
 int hostsim_max_stack() { return g_max_stack.exchange(0); }

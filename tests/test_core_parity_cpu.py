@@ -222,36 +222,3 @@ def test_core_per_bounce_records_equal_oracle(hostsim, oracle, scenes_lib, earth
                                        lambda x, y, s: rto.probe_path(so, cam, p, x, y, s), pairs)
     assert n == 120 and bounces > 150
 
-
-def test_deferred_texel_choice_is_the_reference_texel(hostsim):
-    """The f64 kernels leave an untransformed sphere's (u, v) (hittable.rs:77-83: f64 acos + atan2) to the image texture's
-    nearest-texel lookup (texture.rs:78-101) and choose the texel in f32 wherever f32 is certain of it, in f64 otherwise
-    (rt_core.hpp image_texel_deferred).  The chosen texel must be the reference's for EVERY normal: random directions, and
-    directions placed on and within a few f32 / f64 ulps of texel boundaries, the poles and the phi = 0 / 2 pi seam."""
-    import ctypes as C
-    rng = np.random.default_rng(5)
-    w, h = 1200, 600
-    v = rng.normal(size=(400000, 3))
-    v /= np.linalg.norm(v, axis=1)[:, None]
-    # boundary-hugging directions: theta = pi (1 - j / h), phi = 2 pi i / w exactly representable as f64 up to rounding, +- tiny offsets
-    k = 60000
-    jj = rng.integers(0, h + 1, k)
-    ii = rng.integers(0, w + 1, k)
-    eps = rng.choice([0.0, 1e-16, -1e-16, 1e-12, -1e-12, 1e-9, -1e-9, 3e-8, -3e-8, 1e-6, -1e-6, 1e-5, -1e-5], (k, 2))
-    on_j = rng.random(k) < 0.5
-    theta = np.where(on_j, np.pi * (1.0 - jj / h) + eps[:, 0], rng.random(k) * np.pi)
-    phi = np.where(~on_j, 2.0 * np.pi * ii / w + eps[:, 1], rng.random(k) * 2.0 * np.pi)
-    # hittable.rs:77-83: theta = acos(-y), phi = atan2(-z, x) + pi  =>  y = -cos(theta), x = -cos(phi) sin(theta), z = sin(phi) sin(theta)
-    b = np.stack([-np.cos(phi) * np.sin(theta), -np.cos(theta), np.sin(phi) * np.sin(theta)], axis=1)
-    poles = np.array([[0, 1, 0], [0, -1, 0], [1e-9, 1, 0], [0, -1, 1e-12], [1, 0, 0], [-1, 0, 0], [-1, 0, 1e-17], [-1, 0, -1e-17],
-                      [0, 0, 1], [0, 0, -1]], dtype=np.float64)
-    normals = np.ascontiguousarray(np.concatenate([v, b, poles]))
-    n = len(normals)
-    fast = np.zeros((n, 2), dtype=np.uint32)
-    exact = np.zeros((n, 2), dtype=np.uint32)
-    hostsim.lib.hostsim_texel_choice.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
-    for (ww, hh) in [(w, h), (64, 32), (4096, 2048), (1, 1), (3, 7)]:
-        assert hostsim.lib.hostsim_texel_choice(n, normals.ctypes.data, ww, hh, fast.ctypes.data, exact.ctypes.data) == 0
-        bad = np.nonzero((fast != exact).any(axis=1))[0]
-        assert len(bad) == 0, (ww, hh, len(bad), normals[bad[:5]], fast[bad[:5]], exact[bad[:5]])
-        assert exact[:, 0].max() < ww and exact[:, 1].max() < hh

@@ -200,6 +200,9 @@ enum : uint32_t { SLOT_JITTER_U = 0, SLOT_JITTER_V = 1, SLOT_TIME = 2, SLOT_LENS
 RT_HD uint32_t rng_ctr(uint32_t block, uint32_t slot) { return block * 1024u + slot; }
 
 // Vec3f::random_in_unit_space — vec3.rs:149-160: rejection sampling of the unit BALL
+// (A wave runs this loop to the iteration count of its unluckiest lane, about six trips for a mean of 1.9: 11 % of the f64
+// kernel.  What a trip costs is its three 64-bit hashes; an f64 form that decided on the words' f32 view and formed the f64
+// candidate once after the loop — same draws, same decisions — measured no faster: profiles/r03/README.md.)
 template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bounce) {
     uint32_t c = rng_ctr(bounce + 1, SLOT_SCATTER);
     for (;;) {

@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <array>
+#include <atomic>
+#include <thread>
 
 namespace rt {
 
@@ -84,6 +87,34 @@ void make_camera(const double lookfrom[3], const double lookat[3], const double 
 }
 
 namespace {
+
+// Host threads for the two loops of the lowering that touch every object of a big flat list (10^6 graph objects are 130 MB
+// to read): chunks of `grain` indices, at most 32 threads; small ranges run inline.
+template <typename F> void parallel_for(size_t n, size_t grain, F&& fn) {
+    const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+    const size_t n_threads = std::min<size_t>(std::min<size_t>(hw, 32), (n + grain - 1) / grain);
+    if (n_threads <= 1) { fn(size_t(0), n); return; }
+    const size_t per = (n + n_threads - 1) / n_threads;
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < n_threads; ++t) th.emplace_back([&, t] { fn(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    fn(size_t(0), std::min(n, per));
+    for (auto& x : th) x.join();
+}
+// x moved `steps` representable floats towards -inf / +inf (what a chain of nextafterf calls does, without the calls:
+// 18 libm calls per box were 90 ms of a 10^6-leaf commit).  Finite x; stops at +-FLT_MAX.
+inline float float_step(float x, int steps, bool up) {
+    int32_t i;
+    std::memcpy(&i, &x, 4);
+    // map the sign-magnitude bit pattern to a monotone integer line: negative floats -> negative integers
+    int64_t k = i >= 0 ? int64_t(i) : -int64_t(i & 0x7FFFFFFF);
+    k += up ? steps : -steps;
+    const int64_t top = 0x7F7FFFFF; // FLT_MAX
+    k = std::max<int64_t>(-top, std::min<int64_t>(top, k));
+    const int32_t o = k >= 0 ? int32_t(k) : int32_t(uint32_t(-k) | 0x80000000u);
+    float r;
+    std::memcpy(&r, &o, 4);
+    return r;
+}
 
 struct Box3 {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -160,40 +191,85 @@ struct Lowering {
     }
 
     // ---- record emission
+    // The records of items[0, n) — one per item, instances excepted — appended to their kinds' arrays in item order, in
+    // parallel: idx_out[i] = the record index of item i (an instance's own index for instances).
+    void emit_all(const std::vector<Item>& items, std::vector<uint32_t>& idx_out) {
+        const size_t n = items.size();
+        idx_out.resize(n);
+        if (n < 16384) {
+            for (size_t i = 0; i < n; ++i) idx_out[i] = items[i].kind == PRIM_INSTANCE ? uint32_t(items[i].obj) : emit(items[i]);
+            return;
+        }
+        // per-chunk counts by kind -> where every chunk's records start
+        const size_t grain = 8192, n_chunks = (n + grain - 1) / grain;
+        std::vector<std::array<uint32_t, 4>> start(n_chunks + 1); // sphere, moving, rect, box
+        parallel_for(n_chunks, 1, [&](size_t a, size_t b) {
+            for (size_t c = a; c < b; ++c) {
+                std::array<uint32_t, 4> k{0, 0, 0, 0};
+                for (size_t i = c * grain; i < std::min(n, (c + 1) * grain); ++i)
+                    if (items[i].kind <= PRIM_BOX) ++k[items[i].kind];
+                start[c + 1] = k;
+            }
+        });
+        start[0] = {uint32_t(fs.spheres.size()), uint32_t(fs.moving.size()), uint32_t(fs.rects.size()), uint32_t(fs.boxes.size())};
+        for (size_t c = 1; c <= n_chunks; ++c)
+            for (int k = 0; k < 4; ++k) start[c][k] += start[c - 1][k];
+        fs.spheres.resize(start[n_chunks][0]); fs.sphere_mat.resize(start[n_chunks][0]); fs.sphere_seq.resize(start[n_chunks][0]);
+        fs.moving.resize(start[n_chunks][1]); fs.rects.resize(start[n_chunks][2]); fs.boxes.resize(start[n_chunks][3]);
+        parallel_for(n_chunks, 1, [&](size_t a, size_t b) {
+            for (size_t c = a; c < b; ++c) {
+                std::array<uint32_t, 4> at = start[c];
+                for (size_t i = c * grain; i < std::min(n, (c + 1) * grain); ++i) {
+                    const Item& it = items[i];
+                    idx_out[i] = it.kind == PRIM_INSTANCE ? uint32_t(it.obj) : emit_at(it, at[it.kind]++);
+                }
+            }
+        });
+    }
     uint32_t emit(const Item& it) {
+        switch (it.kind) {
+        case PRIM_SPHERE: fs.spheres.emplace_back(); fs.sphere_mat.emplace_back(); fs.sphere_seq.emplace_back(); return emit_at(it, uint32_t(fs.spheres.size() - 1));
+        case PRIM_MOVING_SPHERE: fs.moving.emplace_back(); return emit_at(it, uint32_t(fs.moving.size() - 1));
+        case PRIM_RECT: fs.rects.emplace_back(); return emit_at(it, uint32_t(fs.rects.size() - 1));
+        case PRIM_BOX: fs.boxes.emplace_back(); return emit_at(it, uint32_t(fs.boxes.size() - 1));
+        default: return 0;
+        }
+    }
+    // write item `it`'s record into slot `at` of its kind's array (which already has that slot)
+    uint32_t emit_at(const Item& it, uint32_t at) {
         const GraphObj& o = g.objs[it.obj];
         switch (it.kind) {
         case PRIM_SPHERE: {
             if (it.world_copy >= 0) {
                 const WorldSphere& w = world_spheres[it.world_copy];
-                fs.spheres.push_back({w.c[0], w.c[1], w.c[2], w.r});
-                fs.sphere_mat.push_back(MAT_HOME_FLAG | (w.inst << MAT_HOME_INST_SHIFT) | w.home); // not a material: where its record is made
+                fs.spheres[at] = {w.c[0], w.c[1], w.c[2], w.r};
+                fs.sphere_mat[at] = MAT_HOME_FLAG | (w.inst << MAT_HOME_INST_SHIFT) | w.home; // not a material: where its record is made
             } else {
-                fs.spheres.push_back({o.v[0], o.v[1], o.v[2], o.v[3]});
-                fs.sphere_mat.push_back(mat_index[o.a]);
+                fs.spheres[at] = {o.v[0], o.v[1], o.v[2], o.v[3]};
+                fs.sphere_mat[at] = mat_index[o.a];
             }
-            fs.sphere_seq.push_back(it.seq);
-            return uint32_t(fs.spheres.size() - 1);
+            fs.sphere_seq[at] = it.seq;
+            return at;
         }
         case PRIM_MOVING_SPHERE: {
             MovingSphereRec<double> m{};
             for (int k = 0; k < 3; ++k) { m.c0[k] = o.v[k]; m.c1[k] = o.v[3 + k]; }
             m.t0 = o.v[6]; m.t1 = o.v[7]; m.r = o.v[8]; m.mat = mat_index[o.a]; m.seq = it.seq;
-            fs.moving.push_back(m);
-            return uint32_t(fs.moving.size() - 1);
+            fs.moving[at] = m;
+            return at;
         }
         case PRIM_RECT: {
             RectRec<double> r{o.v[0], o.v[1], o.v[2], o.v[3], o.v[4], o.c, mat_index[o.a], it.seq};
-            fs.rects.push_back(r);
-            return uint32_t(fs.rects.size() - 1);
+            fs.rects[at] = r;
+            return at;
         }
         case PRIM_BOX: {
             BoxRec<double> bx{};
             for (int k = 0; k < 3; ++k) { bx.mn[k] = o.v[k]; bx.mx[k] = o.v[3 + k]; }
             bx.mat = mat_index[o.a];
             bx.seq = it.seq;
-            fs.boxes.push_back(bx);
-            return uint32_t(fs.boxes.size() - 1);
+            fs.boxes[at] = bx;
+            return at;
         }
         default: return 0;
         }
@@ -203,10 +279,8 @@ struct Lowering {
         for (int k = 0; k < 3; ++k) {
             float l = float(b.lo[k]), h = float(b.hi[k]);
             // round outward, then pad two ulps: covers the f32 narrowing of the primitives themselves
-            if (double(l) > b.lo[k]) l = std::nextafterf(l, -INFINITY);
-            if (double(h) < b.hi[k]) h = std::nextafterf(h, INFINITY);
-            l = std::nextafterf(std::nextafterf(l, -INFINITY), -INFINITY);
-            h = std::nextafterf(std::nextafterf(h, INFINITY), INFINITY);
+            if (std::isfinite(l)) l = float_step(l, double(l) > b.lo[k] ? 3 : 2, false);
+            if (std::isfinite(h)) h = float_step(h, double(h) < b.hi[k] ? 3 : 2, true);
             lo[k] = l; hi[k] = h;
         }
     }
@@ -334,14 +408,18 @@ struct Lowering {
         if (builder && items.size() >= 2) {
             // external builder (device LBVH): every item is a one-record leaf; records are emitted in item order
             std::vector<BuildPrim> prims(items.size());
+            std::vector<uint32_t> idx;
+            emit_all(items, idx);
+            parallel_for(items.size(), 8192, [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; ++i) {
+                    set_box(prims[i].lo, prims[i].hi, items[i].box);
+                    prims[i].leaf = make_leaf(items[i].kind, 1, idx[i]);
+                    prims[i].pad = 0;
+                }
+            });
             box_out = Box3();
-            for (size_t i = 0; i < items.size(); ++i) {
-                const uint32_t idx = items[i].kind == PRIM_INSTANCE ? uint32_t(items[i].obj) : emit(items[i]);
-                set_box(prims[i].lo, prims[i].hi, items[i].box);
-                prims[i].leaf = make_leaf(items[i].kind, 1, idx);
-                prims[i].pad = 0;
-                box_out.grow(items[i].box);
-            }
+            for (const BuildPrim& q : prims) // (the root's box is only used for a wrapping instance's bounds: the f32 boxes cover the f64 ones)
+                for (int k = 0; k < 3; ++k) { box_out.lo[k] = std::min(box_out.lo[k], double(q.lo[k])); box_out.hi[k] = std::max(box_out.hi[k], double(q.hi[k])); }
             fs.n_prims_in_bvh += uint32_t(items.size());
             DeviceTree tree;
             std::string berr;
@@ -446,9 +524,40 @@ struct Lowering {
         case GraphObj::RECT_K: out.push_back({PRIM_RECT, id, bounds_of(o), next_seq++}); break;
         case GraphObj::CUBE_K: out.push_back({PRIM_BOX, id, bounds_of(o), next_seq++}); break;
         case GraphObj::LIST_K:
-        case GraphObj::BVH_K:
-            for (int32_t it : o.items) collect(it, out, outer);
+        case GraphObj::BVH_K: {
+            // a big flat list of plain leaves (10^6 spheres): its items in parallel — same Items, same sequence numbers
+            const size_t n = o.items.size();
+            bool flat = n >= 16384;
+            if (flat) {
+                std::atomic<bool> all_leaves{true};
+                parallel_for(n, 8192, [&](size_t a, size_t b) {
+                    for (size_t i = a; i < b; ++i) {
+                        const GraphObj::Kind k = g.objs[o.items[i]].kind;
+                        if (k != GraphObj::SPHERE_K && k != GraphObj::MOVING_K && k != GraphObj::RECT_K && k != GraphObj::CUBE_K) { all_leaves = false; return; }
+                    }
+                });
+                flat = all_leaves;
+            }
+            if (!flat) {
+                for (int32_t it : o.items) collect(it, out, outer);
+                break;
+            }
+            const size_t base = out.size();
+            const int32_t seq0 = next_seq;
+            out.resize(base + n);
+            next_seq += int32_t(n);
+            parallel_for(n, 8192, [&](size_t a, size_t b) {
+                for (size_t i = a; i < b; ++i) {
+                    const int32_t it = o.items[i];
+                    const GraphObj& q = g.objs[it];
+                    const uint32_t kind = q.kind == GraphObj::SPHERE_K ? PRIM_SPHERE : q.kind == GraphObj::MOVING_K ? PRIM_MOVING_SPHERE
+                                          : q.kind == GraphObj::RECT_K ? PRIM_RECT : PRIM_BOX;
+                    Item item{kind, it, bounds_of(q), seq0 + int32_t(i)};
+                    out[base + i] = item;
+                }
+            });
             break;
+        }
         case GraphObj::TRANSLATE_K:
         case GraphObj::ROTATE_K: {
             InstanceRec<double> own;
@@ -553,24 +662,71 @@ struct Lowering {
     }
 
     void lower_textures_materials() {
-        tex_index.assign(g.objs.size(), -1);
-        mat_index.assign(g.objs.size(), -1);
-        for (size_t id = 0; id < g.objs.size(); ++id) {
-            const GraphObj& o = g.objs[id];
-            if (o.kind > GraphObj::TEX_IMAGE_K) continue;
-            TextureRec<double> t{};
-            switch (o.kind) {
-            case GraphObj::TEX_SOLID_K: t.type = TEX_SOLID; t.color[0] = o.v[0]; t.color[1] = o.v[1]; t.color[2] = o.v[2]; break;
-            case GraphObj::TEX_CHECKER_K: t.type = TEX_CHECKER; t.a = o.a; t.b = o.b; break; // remapped below
-            case GraphObj::TEX_NOISE_K: t.type = TEX_NOISE; t.a = o.a; t.scale = o.v[0]; break;
-            default: // image
-                if (o.a < 0) { t.type = TEX_CYAN; break; }
-                t.type = TEX_IMAGE; t.a = o.a;
-                break;
+        // Texture and material records in graph-id order.  Scenes give every sphere its own material (and colour: 3 x 10^6 graph
+        // objects for spheres_1m), so both passes run in parallel over id chunks: count, prefix, fill.
+        const size_t n_obj = g.objs.size(), grain = 16384, n_chunks = (n_obj + grain - 1) / grain;
+        tex_index.assign(n_obj, -1);
+        mat_index.assign(n_obj, -1);
+        std::vector<uint32_t> tex_start(n_chunks + 1, 0), mat_start(n_chunks + 1, 0);
+        parallel_for(n_chunks, 1, [&](size_t ca, size_t cb) {
+            for (size_t c = ca; c < cb; ++c) {
+                uint32_t nt = 0, nm = 0;
+                for (size_t id = c * grain; id < std::min(n_obj, (c + 1) * grain); ++id) {
+                    const GraphObj::Kind k = g.objs[id].kind;
+                    nt += k <= GraphObj::TEX_IMAGE_K;
+                    nm += k == GraphObj::MAT_K;
+                }
+                tex_start[c + 1] = nt; mat_start[c + 1] = nm;
             }
-            tex_index[id] = int32_t(fs.texs.size());
-            fs.texs.push_back(t);
-        }
+        });
+        for (size_t c = 1; c <= n_chunks; ++c) { tex_start[c] += tex_start[c - 1]; mat_start[c] += mat_start[c - 1]; }
+        fs.texs.resize(tex_start[n_chunks]);
+        fs.mats.resize(mat_start[n_chunks]);
+        parallel_for(n_chunks, 1, [&](size_t ca, size_t cb) { // indices first: a material may name a texture of another chunk
+            for (size_t c = ca; c < cb; ++c) {
+                uint32_t at = tex_start[c], am = mat_start[c];
+                for (size_t id = c * grain; id < std::min(n_obj, (c + 1) * grain); ++id) {
+                    const GraphObj::Kind k = g.objs[id].kind;
+                    if (k <= GraphObj::TEX_IMAGE_K) tex_index[id] = int32_t(at++);
+                    else if (k == GraphObj::MAT_K) mat_index[id] = int32_t(am++);
+                }
+            }
+        });
+        parallel_for(n_chunks, 1, [&](size_t ca, size_t cb) {
+            for (size_t c = ca; c < cb; ++c) {
+                for (size_t id = c * grain; id < std::min(n_obj, (c + 1) * grain); ++id) {
+                    const GraphObj& o = g.objs[id];
+                    if (o.kind == GraphObj::MAT_K) {
+                        MaterialRec<double> m{};
+                        m.type = o.c;
+                        m.tex = -1;
+                        m.albedo[0] = o.v[0]; m.albedo[1] = o.v[1]; m.albedo[2] = o.v[2];
+                        m.param = o.v[3];
+                        if (o.a >= 0) { // textured: inline a solid colour (read off the graph object), else point at the texture record
+                            const GraphObj& t = g.objs[o.a];
+                            if (t.kind == GraphObj::TEX_SOLID_K) { m.albedo[0] = t.v[0]; m.albedo[1] = t.v[1]; m.albedo[2] = t.v[2]; }
+                            else m.tex = tex_index[o.a];
+                            // an image texture, possibly under a checker, reads the hit's (u, v) (a missing image is TEX_CYAN and reads nothing)
+                            if ((t.kind == GraphObj::TEX_IMAGE_K && t.a >= 0) || t.kind == GraphObj::TEX_CHECKER_K) mat_index[id] |= MAT_UV_FLAG;
+                        }
+                        fs.mats[size_t(mat_index[id] & MAT_INDEX_MASK)] = m;
+                        continue;
+                    }
+                    if (o.kind > GraphObj::TEX_IMAGE_K) continue;
+                    TextureRec<double> t{};
+                    switch (o.kind) {
+                    case GraphObj::TEX_SOLID_K: t.type = TEX_SOLID; t.color[0] = o.v[0]; t.color[1] = o.v[1]; t.color[2] = o.v[2]; break;
+                    case GraphObj::TEX_CHECKER_K: t.type = TEX_CHECKER; t.a = o.a; t.b = o.b; break; // remapped below
+                    case GraphObj::TEX_NOISE_K: t.type = TEX_NOISE; t.a = o.a; t.scale = o.v[0]; break;
+                    default: // image
+                        if (o.a < 0) { t.type = TEX_CYAN; break; }
+                        t.type = TEX_IMAGE; t.a = o.a;
+                        break;
+                    }
+                    fs.texs[size_t(tex_index[id])] = t;
+                }
+            }
+        });
         for (auto& t : fs.texs)
             if (t.type == TEX_CHECKER) { t.a = tex_index[t.a]; t.b = tex_index[t.b]; }
         // images
@@ -592,23 +748,6 @@ struct Lowering {
                 for (int i = 0; i < 256; ++i) p[i] = uint8_t(i);
                 for (uint32_t i = 255; i >= 1; --i) std::swap(p[i], p[rng.below(i + 1)]);
             }
-        }
-        for (size_t id = 0; id < g.objs.size(); ++id) {
-            const GraphObj& o = g.objs[id];
-            if (o.kind != GraphObj::MAT_K) continue;
-            MaterialRec<double> m{};
-            m.type = o.c;
-            m.tex = -1;
-            m.albedo[0] = o.v[0]; m.albedo[1] = o.v[1]; m.albedo[2] = o.v[2];
-            m.param = o.v[3];
-            if (o.a >= 0) { // textured: inline a solid colour, else point at the texture record
-                const TextureRec<double>& t = fs.texs[tex_index[o.a]];
-                if (t.type == TEX_SOLID) { m.albedo[0] = t.color[0]; m.albedo[1] = t.color[1]; m.albedo[2] = t.color[2]; }
-                else m.tex = tex_index[o.a];
-            }
-            mat_index[id] = int32_t(fs.mats.size());
-            if (m.tex >= 0 && (fs.texs[m.tex].type == TEX_IMAGE || fs.texs[m.tex].type == TEX_CHECKER)) mat_index[id] |= MAT_UV_FLAG;
-            fs.mats.push_back(m);
         }
     }
 

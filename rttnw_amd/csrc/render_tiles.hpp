@@ -27,9 +27,12 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     rc.profile = p->collect_counters;
     rc.sample_begin = p->sample_begin;
     rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
-    // Passes over consecutive sample ranges (rt_types.hpp plan_passes): one for ordinary renders; more when the chunk
-    // sums of the whole render would not fit the workspace budget.  Decided by the image size and spp alone.
-    const uint32_t n_pass = plan_passes(p->spp, p->spp_chunk, uint64_t(L.n_tiles) * 64, 3 * sizeof(R));
+    // The render's chunk schedule (a function of spp alone) and how many of its chunks one launch traces (rt_types.hpp
+    // launch_chunks: the chunk sums of a launch stay within the 1 GB workspace; the resolve step continues every pixel's
+    // chain, so the image does not depend on the split).
+    plan_chunks(rc, p->spp, p->spp_chunk);
+    const uint32_t total_chunks = rc.n_chunks;
+    const uint32_t per_launch = launch_chunks(uint64_t(rc.my_tiles) * 64, 3 * sizeof(R), total_chunks);
 
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
@@ -120,22 +123,20 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         return 0;
     };
     if (stats && !prepare_only) HIP_TRY(hipEventRecord(d->ev0, stream));
-    for (uint32_t k = 0; k < n_pass; ++k) {
-        const uint32_t s0 = pass_begin(p->spp, n_pass, k), s1 = pass_begin(p->spp, n_pass, k + 1);
-        rc.spp = s1 - s0;                          // this pass's samples; the kernels see a render of [sample_begin, +spp)
-        rc.sample_begin = uint64_t(p->sample_begin) + s0;
-        plan_chunks(rc, rc.spp, p->spp_chunk, uint64_t(L.n_tiles) * 64, 3 * sizeof(R)); // whole image: the same schedule on every rank
-        if (!plan_jobs(rc)) { set_last_error("render: more than 2^32 jobs; use a larger spp_chunk"); return RTTNW_ERR_UNSUPPORTED; }
+    for (uint32_t c0 = 0; c0 < total_chunks; c0 += per_launch) {
+        rc.chunk_base = c0;
+        rc.n_chunks = std::min(per_launch, total_chunks - c0);
+        const bool first = c0 == 0, last = c0 + per_launch >= total_chunks;
+        if (!plan_jobs(rc)) { set_last_error("render: more than 2^32 jobs in a launch"); return RTTNW_ERR_UNSUPPORTED; }
         if (int g = grow(&d->partial, &d->partial_bytes, std::max<size_t>(size_t(rc.jobs_per_chunk) * rc.n_chunks, 1) * 3 * sizeof(R))) return g;
-        if (k && !prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long), stream)); // the job counter only: statistics add up
+        if (!first && !prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long), stream)); // the job counter only: statistics add up
         if (int g = trace_pass()) return g;
         if (prepare_only) continue;
-        if (stats && k + 1 == n_pass) HIP_TRY(hipEventRecord(d->ev1, stream));
+        if (stats && last) HIP_TRY(hipEventRecord(d->ev1, stream));
         hipLaunchKernelGGL(resolve_kernel<R>, dim3((L.pixels_per_rank + 255) / 256), dim3(256), 0, stream, (const R*)d->partial,
-                           (R*)d_packed, rc, L.pixels_per_rank, uint32_t(k == 0), uint32_t(k + 1 == n_pass), p->spp);
+                           (R*)d_packed, rc, L.pixels_per_rank, uint32_t(first), uint32_t(last), p->spp);
         HIP_TRY(hipGetLastError());
     }
-    rc.spp = p->spp;
     if (prepare_only) return RTTNW_OK;
 
     if (stats) {

@@ -1312,7 +1312,7 @@ RT_HD JobInfo job_decode(const RenderConsts& rc, uint32_t job) {
     j.row = ty * 8u + y;
     j.real = chunk < rc.n_chunks;
     j.s = j.s_end = 0;
-    if (j.real) chunk_samples(rc, chunk, j.s, j.s_end);
+    if (j.real) chunk_samples(rc, rc.chunk_base + chunk, j.s, j.s_end);
     if (j.px >= rc.width || j.row >= rc.height) j.s = j.s_end; // a tile pixel outside the image: an empty job (its sum is 0)
     j.sum_index = chunk * rc.jobs_per_chunk + tile * 64u + y * 8u + x;
     return j;

@@ -201,12 +201,12 @@ inline FastDiv make_fastdiv(uint32_t d) { // d >= 1
 
 struct RenderConsts {
     uint32_t width, height, spp, max_depth;
-    uint32_t spp_chunk, n_chunks; // chunk schedule, see plan_chunks()
-    uint32_t n_main;              // chunks [0, n_main) hold spp_chunk samples, chunks [n_main, n_chunks) ONE sample each
+    uint32_t spp_chunk, n_chunks; // chunk schedule of the whole render, see plan_chunks(); n_chunks: the chunks of THIS launch
+    uint32_t n_main;              // (whole render) chunks [0, n_main) hold spp_chunk samples, the chunks after them ONE sample each
     uint32_t tiles_x, tiles_y, n_tiles;
     uint32_t tile_rank, tile_world, my_tiles; // tiles this rank really owns
     uint32_t quirks;
-    uint32_t pad_sb;
+    uint32_t chunk_base;          // the render's chunk that is this launch's chunk 0 (a long render is traced in several launches)
     uint32_t stack_depth;
     FastDiv div_jobs_per_group, div_tiles_x; // job index -> (chunk, tile, pixel) without integer division (job_decode)
     uint32_t jobs_per_chunk;                 // my_tiles * 64: the sums of chunk c start at c * jobs_per_chunk
@@ -218,21 +218,38 @@ struct RenderConsts {
 };
 
 // A pixel's samples are split into CHUNKS; a job = (pixel, chunk) folds its samples sequentially (main.rs:211-216) and
-// the resolve step adds a pixel's chunk sums in chunk order.  Jobs are handed out chunk-major, so the LAST chunks
-// decide how long the final lanes of a launch run alone.  Default schedule (user_chunk == 0): 4-sample chunks for
-// the first ~31/32 of the samples, then single-sample chunks — the launch ends on one-sample jobs whatever spp is
-// (with uniform ceil(spp/256) chunks an 8-GPU run at spp 8000 lost 11 % of a rank's throughput to its tail).
-// Short jobs also keep a wave's lanes on the same few pixels: measured on final_scene, main chunks of 16 / 8 / 4 / 2
-// samples give 1140 / 1206 / 1245 / 1250 Msamples/s (cornell_box 1589 / 1600 / 1595 / 1582).
-// The main chunk grows (and for huge images the schedule falls back to uniform chunks) when the job count or the
-// buffer of chunk sums (bytes_per_sum each) would get out of hand — which plan_passes() below keeps from happening for
-// any spp: a long render is traced as several PASSES over consecutive sample ranges, each with this schedule.
-// Schedule and passes are functions of the WHOLE image (image_tile_pixels = n_tiles * 64) and of spp only — never of the
-// number of ranks or of which tiles a rank owns: the per-pixel fold, hence the image, is bit-identical for any
-// tile_world (each rank's share of the budget below is 1/tile_world of it).
-constexpr uint64_t CHUNK_SUM_BUDGET = 16ull << 30; // bytes of chunk sums alive at once, all ranks together (one GPU alone: 16 of its 288 GB)
-// RTTNW_CHUNK_SUM_BUDGET=<bytes> overrides it (tests: makes the budget bind on small images; changes how a pixel's
-// sum is grouped, i.e. rounding only).
+// the resolve step adds a pixel's chunk sums, in chunk order, onto the pixel's running sum: ONE chain per pixel,
+//     sum = (((c0 + c1) + c2) + ...),
+// whatever else happens.  Jobs are handed out chunk-major, so the LAST chunks decide how long the final lanes of a render
+// run alone.  Default schedule (user_chunk == 0): 4-sample chunks for the first ~31/32 of the samples, then single-sample
+// chunks — the render ends on one-sample jobs whatever spp is (with uniform ceil(spp/256) chunks an 8-GPU run at spp 8000
+// lost 11 % of a rank's throughput to its tail).  Short jobs also keep a wave's lanes on the same few pixels: measured on
+// final_scene, main chunks of 16 / 8 / 4 / 2 samples give 1140 / 1206 / 1245 / 1250 Msamples/s (cornell_box 1589 / 1600 /
+// 1595 / 1582).  The schedule is a function of spp (and user_chunk) ALONE — not of the image, the rank count or the
+// workspace: the per-pixel chain, hence the image, is bit-identical for any tile_world and any launch split below.
+inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk) {
+    if (user_chunk) {
+        rc.spp_chunk = user_chunk;
+        rc.n_chunks = rc.n_main = (spp + user_chunk - 1) / user_chunk;
+        return;
+    }
+    const uint32_t tail = spp < 32u ? spp : spp / 32u;
+    rc.spp_chunk = 4;
+    rc.n_main = (spp - tail) / 4u;
+    rc.n_chunks = rc.n_main + (spp - rc.n_main * 4u);
+}
+// Launches.  The chunk sums wait in a workspace until the resolve step has added them to the running sums; a rank keeps
+// at most CHUNK_SUM_BUDGET bytes of them, so a long render is traced in LAUNCHES over consecutive chunk ranges, each
+// followed by its resolve step, of near-equal size and a multiple of the 16 chunks a job group spans (job_decode).
+// Because the resolve step CONTINUES the pixel's chain, the image does not depend on the split: any budget renders bit
+// for bit the same image (round 2 had "passes" with their own schedules and up to 16 GB of sums).
+// Why 4 GiB and not less: a launch ends with its lanes running dry one by one — a wave waits for the longest of its 64
+// last jobs, and a job is 4 samples x ~6.5 bounces x ~115 us per bounce round of a wave that shares its SIMD with three
+// others — about 10 ms per boundary on final_scene.  Measured with a 1 GiB workspace (5 launches of the headline frame):
+// f64 1139 against 1250 Msamples/s, f32 1563 against 1642.  At 4 GiB the headline frame (4.2 GB of f64 sums) is one
+// launch, spp 5000 six of ~430 ms, and one rank's share of 1600 x 1600 x 10000 five.
+constexpr uint64_t CHUNK_SUM_BUDGET = 4ull << 30; // bytes of chunk sums a rank holds at once (1.4 % of its HBM)
+// RTTNW_CHUNK_SUM_BUDGET=<bytes> overrides it (tests: many launches on small images; the image must not change)
 inline uint64_t chunk_sum_budget() {
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (const char* e = getenv("RTTNW_CHUNK_SUM_BUDGET")) {
@@ -242,68 +259,21 @@ inline uint64_t chunk_sum_budget() {
 #endif
     return CHUNK_SUM_BUDGET;
 }
-inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk, uint64_t image_tile_pixels, uint64_t bytes_per_sum) {
-    if (user_chunk) {
-        rc.spp_chunk = user_chunk;
-        rc.n_chunks = rc.n_main = (spp + user_chunk - 1) / user_chunk;
-        return;
-    }
-    // chunks per pixel the launch can afford: job indices are 32-bit (16 chunks of padding, job_decode; a rank has at
-    // most as many jobs as the whole image), and the chunk sums stay within the budget
-    const uint64_t per = image_tile_pixels ? image_tile_pixels : 1;
-    uint64_t max_chunks = ((1ull << 32) - 1) / per;
-    max_chunks = max_chunks > 16 ? max_chunks - 16 : 1;
-    const uint64_t by_bytes = chunk_sum_budget() / (per * (bytes_per_sum ? bytes_per_sum : 1));
-    if (by_bytes < max_chunks) max_chunks = by_bytes ? by_bytes : 1;
-    const uint32_t tail = spp < 32u ? spp : spp / 32u;
-    for (uint64_t m = 4; m <= spp; m *= 2) {
-        const uint32_t n_main = uint32_t((spp - tail) / m);
-        const uint64_t n_chunks = uint64_t(n_main) + (spp - n_main * m);
-        if (n_chunks <= max_chunks) {
-            rc.spp_chunk = uint32_t(m);
-            rc.n_main = n_main;
-            rc.n_chunks = uint32_t(n_chunks);
-            return;
-        }
-    }
-    if (spp <= max_chunks) { // few samples: every chunk one sample
-        rc.spp_chunk = 1;
-        rc.n_chunks = rc.n_main = spp;
-        return;
-    }
-    // an image so large that not even the single-sample tail fits: uniform chunks, as few as the budget allows
-    rc.spp_chunk = uint32_t((spp + max_chunks - 1) / max_chunks);
-    rc.n_chunks = rc.n_main = (spp + rc.spp_chunk - 1) / rc.spp_chunk;
+inline uint32_t launch_chunks(uint64_t rank_tile_pixels, uint64_t bytes_per_sum, uint32_t total_chunks) {
+    if (total_chunks <= 1) return 1;
+    const uint64_t per_chunk = (rank_tile_pixels ? rank_tile_pixels : 1) * (bytes_per_sum ? bytes_per_sum : 1);
+    uint64_t k = chunk_sum_budget() / per_chunk;
+    // job indices are 32-bit (a launch has ceil(K / 16) * 16 * rank_tile_pixels of them)
+    const uint64_t by_index = ((1ull << 32) - 1) / (rank_tile_pixels ? rank_tile_pixels : 1);
+    if (by_index < 32) k = 1; else if (k > by_index - 16) k = by_index - 16;
+    if (k >= total_chunks) return total_chunks; // the whole render in one launch
+    if (k < 16) return uint32_t(k < 1 ? 1 : k);  // an image so large that a job group's 16 chunk planes exceed the budget
+    k -= k % 16;
+    const uint64_t n_launch = (total_chunks + k - 1) / k;                 // as few launches as the budget allows ...
+    const uint64_t even = (total_chunks + n_launch - 1) / n_launch;        // ... of near-equal size
+    return uint32_t((even + 15) / 16 * 16);                               // (<= k: k is a multiple of 16 and even <= k)
 }
-// Passes.  The chunk sums of ONE launch must fit CHUNK_SUM_BUDGET with the tapered 4-sample schedule (short chunks are
-// worth 10 % of the rate, see above), so a render of many samples is split into n_pass launches over consecutive sample
-// ranges of near-equal size; the resolve step adds each pass's chunk sums (in chunk order) to the pixel's running sum (in
-// pass order).  Every pass ends on single-sample jobs, so a pass runs at the rate of a stand-alone render of its
-// size.  Returns n_pass >= 1; pass k covers samples [pass_begin(k), pass_begin(k + 1)).
-inline uint64_t tapered_chunks(uint64_t n, uint64_t m) {
-    const uint64_t tail = n < 32 ? n : n / 32, n_main = (n - tail) / m;
-    return n_main + (n - n_main * m);
-}
-inline uint32_t plan_passes(uint32_t spp, uint32_t user_chunk, uint64_t image_tile_pixels, uint64_t bytes_per_sum) {
-    const uint64_t per = image_tile_pixels ? image_tile_pixels : 1;
-    uint64_t max_chunks = ((1ull << 32) - 1) / per;
-    max_chunks = max_chunks > 16 ? max_chunks - 16 : 1;
-    const uint64_t by_bytes = chunk_sum_budget() / (per * (bytes_per_sum ? bytes_per_sum : 1));
-    if (by_bytes < max_chunks) max_chunks = by_bytes ? by_bytes : 1;
-    uint64_t n_max; // most samples one pass can take
-    if (user_chunk) {
-        n_max = max_chunks * user_chunk;
-    } else {
-        n_max = max_chunks * 4; // 4-sample chunks, tapered: a little under 3.66 samples per chunk
-        while (n_max > 1 && tapered_chunks(n_max, 4) > max_chunks) n_max -= (n_max + 63) / 64;
-    }
-    if (n_max < 1) n_max = 1;
-    return uint32_t((uint64_t(spp) + n_max - 1) / n_max);
-}
-RT_HD uint32_t pass_begin(uint32_t spp, uint32_t n_pass, uint32_t k) { // first sample of pass k (k == n_pass: spp)
-    const uint32_t base = spp / n_pass, extra = spp % n_pass;
-    return k * base + (k < extra ? k : extra);
-}
+// Chunk `chunk` of the WHOLE render -> its samples [s, s_end).
 RT_HD void chunk_samples(const RenderConsts& rc, uint32_t chunk, uint32_t& s, uint32_t& s_end) {
     if (chunk < rc.n_main) {
         s = chunk * rc.spp_chunk;

@@ -585,24 +585,25 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
     }
 }
 
-// Sum a pixel's chunk partials of ONE PASS in chunk order and add them to the pixel's running sum (pass 0 starts it);
-// the last pass divides by the render's spp (main.rs:217): packed pixel records (r, g, b, 1).  Pad tiles
-// (>= my_tiles) are zero-filled.  The running sum lives in `packed` itself.
+// Add a launch's chunk sums, in chunk order, onto the pixel's running sum — ONE chain per pixel over the whole render,
+// sum = (((c0 + c1) + c2) + ...), continued from launch to launch (the first launch starts it), so the image does not
+// depend on how the render was split into launches; the last launch divides by spp (main.rs:217): packed pixel records
+// (r, g, b, 1).  Pad tiles (>= my_tiles) are zero-filled.  The running sum lives in `packed` itself.
 template <typename R>
 __global__ void resolve_kernel(const R* __restrict__ partial, R* __restrict__ packed, RenderConsts rc, uint32_t pixels_per_rank,
-                               uint32_t first_pass, uint32_t last_pass, uint32_t total_spp) {
+                               uint32_t first_launch, uint32_t last_launch, uint32_t total_spp) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= pixels_per_rank) return;
     R* dst = packed + (unsigned long long)p * 4ull;
     R r = 0, g = 0, b = 0, a = 0;
     const unsigned long long jobs_per_chunk = (unsigned long long)rc.my_tiles * 64ull;
     if (p < jobs_per_chunk) {
+        if (!first_launch) { r = dst[0]; g = dst[1]; b = dst[2]; }
         for (uint32_t c = 0; c < rc.n_chunks; ++c) {
             const R* src = partial + ((unsigned long long)c * jobs_per_chunk + p) * 3ull;
             r = r + src[0]; g = g + src[1]; b = b + src[2];
         }
-        if (!first_pass) { r = dst[0] + r; g = dst[1] + g; b = dst[2] + b; }
-        if (last_pass) {
+        if (last_launch) {
             const R spp = R(total_spp);
             r = r / spp; g = g / spp; b = b / spp;
             a = R(1);

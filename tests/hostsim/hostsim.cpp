@@ -120,8 +120,8 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
     CameraRec<R> camr = narrow_camera<R>(cam64);
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    const uint64_t image_tile_pixels = uint64_t((p->width + 7) / 8) * ((p->height + 7) / 8) * 64;
-    const uint32_t n_pass = plan_passes(p->spp, p->spp_chunk, image_tile_pixels, 3 * sizeof(R));
+    rc.sample_begin = p->sample_begin;
+    plan_chunks(rc, p->spp, p->spp_chunk); // the render's chunk schedule: a function of spp alone (rt_types.hpp)
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));
     const R t_min = R(p->t_min);
@@ -135,27 +135,18 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
             uint32_t row = next_row.fetch_add(1);
             if (row >= rc.height) break;
             for (uint32_t px = 0; px < rc.width; ++px) {
-                V3<R> total;
-                for (uint32_t k = 0; k < n_pass; ++k) { // passes over consecutive sample ranges, as render_tiles.hpp launches them
-                    RenderConsts rp = rc;
-                    const uint32_t b0 = pass_begin(p->spp, n_pass, k);
-                    rp.spp = pass_begin(p->spp, n_pass, k + 1) - b0;
-                    rp.sample_begin = uint64_t(p->sample_begin) + b0;
-                    plan_chunks(rp, rp.spp, p->spp_chunk, image_tile_pixels, 3 * sizeof(R));
-                    V3<R> pass_sum;
-                    for (uint32_t c = 0; c < rp.n_chunks; ++c) { // one job = (pixel, chunk), folded sequentially
-                        V3<R> acc;
-                        uint32_t s0, s1;
-                        chunk_samples(rp, c, s0, s1);
-                        for (uint32_t si = s0; si < s1; ++si) {
-                            PathState<R> ps;
-                            path_begin(ps, camr, rp, px, row, si);
-                            while (path_step(ps, hs.view, rp, background, t_min, stack, cnt)) {}
-                            acc = acc + ps.radiance;
-                        }
-                        pass_sum = pass_sum + acc; // chunk partials added in chunk order (resolve kernel)
+                V3<R> total; // one chain per pixel: the chunk sums added in chunk order, however the device splits the render into launches
+                for (uint32_t c = 0; c < rc.n_chunks; ++c) { // one job = (pixel, chunk), folded sequentially
+                    V3<R> acc;
+                    uint32_t s0, s1;
+                    chunk_samples(rc, c, s0, s1);
+                    for (uint32_t si = s0; si < s1; ++si) {
+                        PathState<R> ps;
+                        path_begin(ps, camr, rc, px, row, si);
+                        while (path_step(ps, hs.view, rc, background, t_min, stack, cnt)) {}
+                        acc = acc + ps.radiance;
                     }
-                    total = k == 0 ? pass_sum : total + pass_sum; // ... and the passes in pass order
+                    total = total + acc;
                 }
                 V3<R> mean = total / R(rc.spp);
                 size_t o = (size_t(row) * rc.width + px) * 3;
@@ -278,17 +269,19 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
                                      : render_t<double>(s, cam, p, out_linear, stats, n_threads);
 }
-// Passes and chunk schedule of a render (rt_types.hpp plan_passes / plan_chunks + rt_core.hpp plan_jobs) of an image of n_tiles
-// 8x8 tiles as rank 0 of `world` ranks sees it: out = {spp_chunk, n_main, n_chunks, n_jobs of the FIRST (largest) pass, n_pass,
-// samples of the first pass}; returns 0, or -1 when the job count does not fit.
-int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t n_tiles, uint32_t world, uint32_t bytes_per_sum, uint32_t* out) {
+// Chunk schedule and launch split of a render (rt_types.hpp plan_chunks / launch_chunks + rt_core.hpp plan_jobs) as a rank that
+// owns rank_tiles 8x8 tiles sees it: out = {spp_chunk, n_main, n_chunks of the whole render, chunks per launch, launches, n_jobs
+// of the first launch}; returns 0, or -1 when the job count of a launch does not fit.
+int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t rank_tiles, uint32_t bytes_per_sum, uint32_t* out) {
     RenderConsts rc{};
-    rc.my_tiles = (n_tiles + world - 1) / world;
-    const uint32_t n_pass = plan_passes(spp, user_chunk, uint64_t(n_tiles) * 64, bytes_per_sum);
-    rc.spp = pass_begin(spp, n_pass, 1);
-    plan_chunks(rc, rc.spp, user_chunk, uint64_t(n_tiles) * 64, bytes_per_sum);
+    rc.my_tiles = rank_tiles;
+    rc.spp = spp;
+    plan_chunks(rc, spp, user_chunk);
+    const uint32_t total = rc.n_chunks, per_launch = launch_chunks(uint64_t(rank_tiles) * 64, bytes_per_sum, total);
+    out[0] = rc.spp_chunk; out[1] = rc.n_main; out[2] = total; out[3] = per_launch; out[4] = (total + per_launch - 1) / per_launch;
+    rc.n_chunks = std::min(per_launch, total);
     const bool ok = plan_jobs(rc);
-    out[0] = rc.spp_chunk; out[1] = rc.n_main; out[2] = rc.n_chunks; out[3] = rc.n_jobs; out[4] = n_pass; out[5] = rc.spp;
+    out[5] = rc.n_jobs;
     return ok ? 0 : -1;
 }
 // Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).

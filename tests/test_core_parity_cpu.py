@@ -159,45 +159,46 @@ def test_sample_ranges_compose(hostsim, oracle, scenes_lib):
     assert np.abs(parts[0][1] - parts[1][1]).max() > 1e-3  # different samples, different estimates
 
 
-def test_chunk_schedule_covers_every_sample_within_budget(hostsim):
-    """plan_passes / plan_chunks / plan_jobs for small, ordinary and very large renders: the passes partition [0, spp), the
-    chunks of a pass partition its samples exactly, every pass ends on single-sample chunks, job indices stay below 2^32,
-    the chunk sums of all ranks together below 16 GB — and nothing depends on the number of ranks (the fold of a pixel,
-    hence the image, is the same for any tile_world), including at BASELINE's flagship sizes where the budget binds."""
+def test_chunk_schedule_and_launch_split(hostsim):
+    """plan_chunks / launch_chunks / plan_jobs (rt_types.hpp) for small, ordinary and very large renders: the chunks partition
+    [0, spp) exactly and end on single-sample chunks, the schedule depends on spp ALONE (not on the image or on how many tiles
+    a rank owns — so the per-pixel chain, hence the image, is the same for any tile_world), the chunk sums of one launch stay
+    within the 4 GiB workspace, job indices of a launch below 2^32, and a launch takes whole job groups (16 chunks) wherever
+    the budget allows one."""
     out = (C.c_uint32 * 6)()
-    budget = 16 * 2**30
+    budget = 4 * 2**30
     cases = [(1, 1), (5, 10), (31, 10), (32, 10), (33, 10), (1000, 10000), (5000, 10000), (8000, 1250), (10000, 5000),
-             (10000, 40000), (100000, 40000), (7, 40000), (1000000, 160000)]
+             (10000, 40000), (100000, 40000), (7, 40000), (1000000, 160000), (1000, 4000000)]
     for spp, tiles in cases:
         for bytes_per_sum in (12, 24):
-            per_world = {}
+            schedules = set()
             for world in (1, 2, 3, 4, 8):
-                assert hostsim.lib.hostsim_plan(spp, 0, tiles, world, bytes_per_sum, out) == 0, (spp, tiles, world)
-                chunk, n_main, n_chunks, n_jobs, n_pass, pass_spp = list(out)
-                per_world[world] = (chunk, n_main, n_chunks, n_pass, pass_spp)
                 my_tiles = -(-tiles // world)
-                assert n_jobs >= n_chunks * my_tiles * 64 and n_jobs < 2**32
-            assert len(set(per_world.values())) == 1, (spp, tiles, per_world)
-            assert pass_spp == -(-spp // n_pass)                                     # near-equal passes, the first the largest
-            assert n_main * chunk + (n_chunks - n_main) == pass_spp, (spp, tiles, list(out))
-            assert n_chunks * tiles * 64 * bytes_per_sum <= budget
-            assert chunk in (1, 4) and (n_chunks - n_main >= min(pass_spp, max(1, pass_spp // 32)) or chunk == 1)  # always tapered
-    assert hostsim.lib.hostsim_plan(40, 7, 100, 1, 12, out) == 0 and list(out)[:3] == [7, 6, 6]   # explicit chunking is uniform
-    # BASELINE configs[2] and [3] (800x800 spp 5000; 1600x1600 spp 10000 over 8 ranks), f32: several passes of 4-sample chunks
-    assert hostsim.lib.hostsim_plan(5000, 0, 10000, 1, 24, out) == 0 and out[0] == 4 and out[4] == 2
-    assert hostsim.lib.hostsim_plan(10000, 0, 40000, 8, 12, out) == 0 and out[0] == 4 and out[4] >= 5
-    # the headline config is one pass
-    assert hostsim.lib.hostsim_plan(1000, 0, 10000, 1, 24, out) == 0 and out[4] == 1
+                assert hostsim.lib.hostsim_plan(spp, 0, my_tiles, bytes_per_sum, out) == 0, (spp, tiles, world)
+                chunk, n_main, n_chunks, per_launch, launches, n_jobs = list(out)
+                schedules.add((chunk, n_main, n_chunks))
+                assert launches == -(-n_chunks // per_launch) and 1 <= per_launch <= n_chunks
+                assert per_launch * my_tiles * 64 * bytes_per_sum <= budget or per_launch == 1
+                assert per_launch % 16 == 0 or per_launch == n_chunks or per_launch < 16
+                assert n_jobs >= min(per_launch, n_chunks) * my_tiles * 64 and n_jobs < 2**32
+            assert len(schedules) == 1, (spp, tiles, schedules)
+            assert chunk == 4 and n_main * 4 + (n_chunks - n_main) == spp, (spp, list(out))
+            assert n_chunks - n_main >= min(spp, max(1, spp // 32))                  # always tapered
+    assert hostsim.lib.hostsim_plan(40, 7, 100, 12, out) == 0 and list(out)[:3] == [7, 6, 6]   # explicit chunking is uniform
+    # BASELINE configs: the headline frame (800x800 spp 1000) is ONE launch in f64 (4.2 GB of sums) and f32; spp 5000 in f64: six
+    # launches of 240 chunks; 1600x1600 spp 10000 in f64: one rank of 8 six launches, the whole frame on one GPU 43 of 64 chunks
+    assert hostsim.lib.hostsim_plan(1000, 0, 10000, 24, out) == 0 and list(out)[2:5] == [274, 274, 1]
+    assert hostsim.lib.hostsim_plan(5000, 0, 10000, 24, out) == 0 and list(out)[3:5] == [240, 6]
+    assert hostsim.lib.hostsim_plan(10000, 0, 5000, 24, out) == 0 and list(out)[3:5] == [464, 6]
+    assert hostsim.lib.hostsim_plan(10000, 0, 40000, 24, out) == 0 and list(out)[3:5] == [64, 43]
 
 
-def test_core_multi_pass_equals_oracle(hostsim, oracle, scenes_lib, monkeypatch):
-    """A render split into passes (RTTNW_CHUNK_SUM_BUDGET makes the workspace budget bind on a small image): the pass-wise
-    fold differs from the oracle's flat fold by rounding only, for the tapered and for an explicit chunking."""
+def test_core_chain_equals_oracle(hostsim, oracle, scenes_lib):
+    """The host build of the core folds a pixel as ONE chain of chunk sums in chunk order (what the device's resolve step
+    continues from launch to launch): it differs from the oracle's flat fold by rounding only, for the tapered and for an
+    explicit chunking."""
     sh, setup = util.build(hostsim, scenes_lib, "cornell_box")
     so, _ = util.build(oracle, scenes_lib, "cornell_box")
-    monkeypatch.setenv("RTTNW_CHUNK_SUM_BUDGET", str(48 * 48 * 24 * 6))          # six chunk planes of a 48x48 f64 image
-    out = (C.c_uint32 * 6)()
-    assert hostsim.lib.hostsim_plan(50, 0, 36, 1, 24, out) == 0 and out[4] >= 3 and out[2] <= 6
     for chunk in (0, 3):
         cam, p = util.params_for(setup, 48, 48, 50, spp_chunk=chunk, seed=4)
         lin, _ = util.hostsim_render(hostsim, sh, cam, p)

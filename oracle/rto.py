@@ -42,6 +42,7 @@ _PROBES = [
     ("probe_reflect", None, [_dp, _dp, _dp]),
     ("probe_quantise", C.c_int, [C.c_double]),
     ("probe_uniform", C.c_double, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+    ("probe_word", C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
     ("probe_scene_rng", None, [C.c_uint64, C.c_uint64, C.c_uint32, _dp]),
     ("probe_sample", C.c_int, [abi.scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint32,
                                C.c_uint32, _dp]),

@@ -40,7 +40,7 @@ constexpr double kInf = std::numeric_limits<double>::infinity();
 
 // ---------------------------------------------------------------------------------------------
 // Keyed RNG (replaces rand::thread_rng(); spec in DESIGN.md "RNG", shared by definition — not by
-// source — with rttnw_amd/csrc/rt_rng.hpp).
+// source — with rttnw_amd/csrc/rt_core.hpp).
 // ---------------------------------------------------------------------------------------------
 constexpr uint64_t GAMMA = 0x9E3779B97F4A7C15ull;
 inline uint64_t mix64(uint64_t z) {
@@ -53,9 +53,9 @@ inline uint64_t sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
     uint64_t k1 = mix64(k0 + pixel * 0xD1B54A32D192ED03ull);
     return mix64(k1 + sample * 0x8CB92BA72F3D8DD7ull);
 }
+inline uint64_t keyed_word(uint64_t key, uint32_t ctr) { return mix64(key + (uint64_t(ctr) + 1) * GAMMA); }
 inline double keyed_uniform(uint64_t key, uint32_t ctr) {
-    uint64_t w = mix64(key + (uint64_t(ctr) + 1) * GAMMA);
-    return double(w >> 11) * (1.0 / 9007199254740992.0); // 53 bits, [0,1) like rand's gen::<f64>()
+    return double(keyed_word(key, ctr) >> 11) * (1.0 / 9007199254740992.0); // 53 bits, [0,1) like rand's gen::<f64>()
 }
 // counter layout: block 0 = camera, block b+1 = bounce b
 constexpr uint32_t SLOT_JITTER_U = 0, SLOT_JITTER_V = 1, SLOT_TIME = 2, SLOT_LENS = 8;
@@ -129,11 +129,18 @@ struct PathCtx {
     double uniform(uint32_t slot) const { return keyed_uniform(key, ctr_of(bounce + 1, slot)); }
 };
 
-// Vec3f::random_in_unit_space — vec3.rs:149-160 (rejection in the unit BALL, 3 draws/iteration)
+// Vec3f::random_in_unit_space — vec3.rs:149-160 (rejection in the unit BALL, three uniforms per iteration).
+// Draw spec of the keyed generator for these: iteration `it` owns slots 32 + 4 it .. 32 + 4 it + 3; the word
+// of the first gives the 21 leading bits of the three uniforms, the words of the other three their remaining 32 bits.
+inline double ball_uniform(const PathCtx& ctx, uint32_t it, int c) {
+    const uint64_t h = keyed_word(ctx.key, ctr_of(ctx.bounce + 1, SLOT_SCATTER + 4 * it));
+    const uint64_t low = keyed_word(ctx.key, ctr_of(ctx.bounce + 1, SLOT_SCATTER + 4 * it + 1 + uint32_t(c)));
+    const uint64_t field = c == 0 ? h >> 43 : (c == 1 ? (h >> 22) & 0x1FFFFFull : (h >> 1) & 0x1FFFFFull);
+    return double((field << 32) | (low >> 32)) * (1.0 / 9007199254740992.0);
+}
 inline V3 random_in_unit_space(const PathCtx& ctx) {
     for (uint32_t it = 0;; ++it) {
-        V3 r(ctx.uniform(SLOT_SCATTER + 3 * it + 0), ctx.uniform(SLOT_SCATTER + 3 * it + 1),
-             ctx.uniform(SLOT_SCATTER + 3 * it + 2));
+        V3 r(ball_uniform(ctx, it, 0), ball_uniform(ctx, it, 1), ball_uniform(ctx, it, 2));
         V3 v = 2.0 * r - V3(1.0, 1.0, 1.0);
         if (squared_length(v) < 1.0) return v;
     }
@@ -1209,6 +1216,9 @@ void rto_probe_reflect(const double* v, const double* n, double* out) {
 int rto_probe_quantise(double mean) { return int(quantise(mean)); }
 double rto_probe_uniform(uint64_t seed, uint64_t pixel, uint64_t sample, uint32_t block, uint32_t slot) {
     return keyed_uniform(sample_key(seed, pixel, sample), ctr_of(block, slot));
+}
+uint64_t rto_probe_word(uint64_t seed, uint64_t pixel, uint64_t sample, uint32_t block, uint32_t slot) {
+    return keyed_word(sample_key(seed, pixel, sample), ctr_of(block, slot));
 }
 // scene-construction stream: fills out[n] with next_f64() of SceneRng(seed, stream)
 void rto_probe_scene_rng(uint64_t seed, uint64_t stream, uint32_t n, double* out) {

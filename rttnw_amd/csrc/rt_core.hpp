@@ -199,18 +199,55 @@ enum : uint32_t { SLOT_JITTER_U = 0, SLOT_JITTER_V = 1, SLOT_TIME = 2, SLOT_LENS
                   SLOT_MEDIUM = 0, SLOT_DIELECTRIC = 16, SLOT_SCATTER = 32 };
 RT_HD uint32_t rng_ctr(uint32_t block, uint32_t slot) { return block * 1024u + slot; }
 
-// Vec3f::random_in_unit_space — vec3.rs:149-160: rejection sampling of the unit BALL
-// (A wave runs this loop to the iteration count of its unluckiest lane, about six trips for a mean of 1.9: 11 % of the f64
-// kernel.  What a trip costs is its three 64-bit hashes; an f64 form that decided on the words' f32 view and formed the f64
-// candidate once after the loop — same draws, same decisions — measured no faster: profiles/r03/README.md.)
+// Vec3f::random_in_unit_space — vec3.rs:149-160: rejection sampling of the unit BALL:
+//     loop { v = 2 (U, U, U) - 1; if |v|^2 < 1 return v }
+// A wave runs this loop to the iteration count of its unluckiest lane — about six trips for a mean of 1.9 — and what a trip
+// costs is its 64-bit hashes (two 64-bit multiplies each: quarter-rate integer work): with one hash per uniform the loop was
+// 12 % of the f64 kernel.  So the three uniforms of a candidate are drawn HIERARCHICALLY: one word H
+// gives the 21 leading bits of each, three more words give their remaining 32 bits,
+//     u_c = ( field_c(H) * 2^32 + (L_c >> 32) ) * 2^-53,   field_0 = H >> 43, field_1 = (H >> 22) & 0x1FFFFF, field_2 = (H >> 1) & 0x1FFFFF,
+// slots 32 + 4 i (H) and 32 + 4 i + 1 + c (L_c) of iteration i: still 53 independent uniform bits per coordinate.  H alone
+// pins the candidate to a cube of side 2^-20 around (x_c): |v|^2 lies within 1.7e-6 of |x_c|^2, so unless |x_c|^2 is within
+// 4e-6 of 1 the reference's test `|v|^2 < 1` is decided without the other three words — a rejected trip costs one hash
+// instead of three — and the accepted candidate's low words are fetched once, after the loop.  The sliver in between
+// (4e-6 of the candidates) evaluates the full candidate.  Same algorithm, same predicate on the same candidate: the oracle
+// simply evaluates every candidate in full.
+RT_HD uint32_t ball_field(uint64_t h, int c) { return c == 0 ? uint32_t(h >> 43) : (c == 1 ? uint32_t(h >> 22) & 0x1FFFFFu : uint32_t(h >> 1) & 0x1FFFFFu); }
+template <typename R> RT_HD R ball_uniform(uint32_t field, uint64_t low_word);
+template <> RT_HD double ball_uniform<double>(uint32_t field, uint64_t low_word) {
+    return double((uint64_t(field) << 32) | (low_word >> 32)) * (1.0 / 9007199254740992.0);
+}
+template <> RT_HD float ball_uniform<float>(uint32_t field, uint64_t low_word) { // the top 24 of the same 53 bits
+    const uint32_t top = (field << 3) | uint32_t(low_word >> 61);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float f;
+    asm("v_cvt_f32_u32 %0, %1" : "=v"(f) : "v"(top));
+    return f * (1.0f / 16777216.0f);
+#else
+    return float(top) * (1.0f / 16777216.0f);
+#endif
+}
+template <typename R> RT_HD V3<R> ball_candidate(uint64_t key, uint32_t c, uint64_t h) {
+    const V3<R> r(ball_uniform<R>(ball_field(h, 0), rng_word(key, c + 1)), ball_uniform<R>(ball_field(h, 1), rng_word(key, c + 2)),
+                  ball_uniform<R>(ball_field(h, 2), rng_word(key, c + 3)));
+    return R(2) * r - V3<R>(R(1), R(1), R(1));
+}
 template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bounce) {
     uint32_t c = rng_ctr(bounce + 1, SLOT_SCATTER);
+    uint64_t h;
     for (;;) {
-        V3<R> r(uniform01<R>(key, c), uniform01<R>(key, c + 1), uniform01<R>(key, c + 2));
-        V3<R> v = R(2) * r - V3<R>(R(1), R(1), R(1));
-        if (squared_length(v) < R(1)) return v;
-        c += 3;
+        h = rng_word(key, c);
+        // the cube's centre: x_c = 2 (field + 1/2) 2^-21 - 1
+        const float x = float(ball_field(h, 0)) * 9.5367431640625e-7f + (4.76837158203125e-7f - 1.f),
+                    y = float(ball_field(h, 1)) * 9.5367431640625e-7f + (4.76837158203125e-7f - 1.f),
+                    z = float(ball_field(h, 2)) * 9.5367431640625e-7f + (4.76837158203125e-7f - 1.f);
+        const float s = x * x + y * y + z * z;
+        bool inside = s < 1.f - 4e-6f;
+        if (!inside && !(s > 1.f + 4e-6f)) inside = squared_length(ball_candidate<R>(key, c, h)) < R(1);
+        if (inside) break;
+        c += 4;
     }
+    return ball_candidate<R>(key, c, h);
 }
 
 // ---------------------------------------------------------------- counters (instrumentation)

@@ -284,6 +284,16 @@ int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t rank_tiles, uint32_
     out[5] = rc.n_jobs;
     return ok ? 0 : -1;
 }
+// random_in_unit_space of the product core for n keys (f64 and f32 instantiations): out64[3 n], out32[3 n].
+int hostsim_ball(uint32_t n, const uint64_t* keys, uint32_t bounce, double* out64, float* out32) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3<double> a = random_in_unit_space<double>(keys[i], bounce);
+        const V3<float> b = random_in_unit_space<float>(keys[i], bounce);
+        out64[3 * i] = a.x; out64[3 * i + 1] = a.y; out64[3 * i + 2] = a.z;
+        out32[3 * i] = b.x; out32[3 * i + 1] = b.y; out32[3 * i + 2] = b.z;
+    }
+    return 0;
+}
 // Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).
 int hostsim_max_stack() { return g_max_stack.exchange(0); }
 int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, rects, boxes, insts, media, stack_depth */) {

@@ -223,3 +223,45 @@ def test_core_per_bounce_records_equal_oracle(hostsim, oracle, scenes_lib, earth
                                        lambda x, y, s: rto.probe_path(so, cam, p, x, y, s), pairs)
     assert n == 120 and bounces > 150
 
+
+
+def test_ball_draw_shortcut_is_the_full_rejection_loop(hostsim):
+    """random_in_unit_space (vec3.rs:149-160) in the product core decides most candidates from the ONE word that holds the
+    leading 21 bits of their three uniforms and fetches the other three words only for the accepted candidate (or when the
+    leading bits leave the test `|v|^2 < 1` open).  Against the plain loop over full candidates, restated here in numpy from
+    the draw spec, for 300 000 keys: the f64 vector is identical, the f32 vector is the f32 view of the
+    same 53-bit uniforms (its accept decision may differ from f64's only within f32 rounding of the sphere)."""
+    import ctypes as C
+    GAMMA = 0x9E3779B97F4A7C15
+    M = (1 << 64) - 1
+
+    def mix64(z):
+        z = z.copy()
+        z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    rng = np.random.default_rng(11)
+    n, bounce = 300000, 3
+    keys = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    out64 = np.zeros((n, 3)); out32 = np.zeros((n, 3), dtype=np.float32)
+    hostsim.lib.hostsim_ball.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    assert hostsim.lib.hostsim_ball(n, keys.ctypes.data, bounce, out64.ctypes.data, out32.ctypes.data) == 0
+    with np.errstate(over="ignore"):
+        word = lambda ctr: mix64(keys + np.uint64(((ctr + 1) * GAMMA) & M))   # noqa: E731
+        want = np.zeros((n, 3)); want32 = np.zeros((n, 3)); todo = np.ones(n, dtype=bool)
+        for it in range(64):
+            base = (bounce + 1) * 1024 + 32 + 4 * it
+            h = word(base)
+            fields = [h >> np.uint64(43), (h >> np.uint64(22)) & np.uint64(0x1FFFFF), (h >> np.uint64(1)) & np.uint64(0x1FFFFF)]
+            m = [(f << np.uint64(32)) | (word(base + 1 + c) >> np.uint64(32)) for c, f in enumerate(fields)]
+            v = np.stack([2.0 * (x.astype(np.float64) * 2.0**-53) - 1.0 for x in m], axis=1)
+            v32 = np.stack([2.0 * ((x >> np.uint64(29)).astype(np.float64) * 2.0**-24) - 1.0 for x in m], axis=1)
+            acc = todo & ((v * v).sum(axis=1) < 1.0)
+            want[acc] = v[acc]; want32[acc] = v32[acc]
+            todo &= ~acc
+            if not todo.any():
+                break
+    assert not todo.any() and np.array_equal(out64, want)
+    same = np.abs(out32 - want32).max(axis=1) <= 2e-7          # f32 accepted the same candidate (all but those on the sphere's f32 skin)
+    assert same.mean() > 0.9999 and ((out32.astype(np.float64) ** 2).sum(axis=1) < 1.0 + 1e-6).all()

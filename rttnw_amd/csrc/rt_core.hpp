@@ -301,9 +301,17 @@ RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key) {
 // tmax only shrinks, so `tmax < tmin` at the end <=> it held at some axis.
 // (The FMA form t = bound*inv - o*inv was tried for f32 and rejected: its error is absolute, ~eps*|o*inv|, which
 // for a far-away origin and a small direction component — spheres_1m's primary rays — is larger than a leaf.)
+// Forms of the f32 kernels' slab test (the f64 kernels always use the conservative 7-value form below): the Stack type of a
+// kernel names its form (Stack::SLAB_F32) — the lane-owns-path kernel with its nodes in LDS is bound by vector-instruction issue
+// and takes the FOLDED conservative fma form, 11 operations per box (final_scene f32 1644 -> 1752 Msamples/s); the decoupled
+// kernel of HBM-resident trees keeps the exact two-operation form (the folded form's five more live registers cost it 13 %).
+enum : int { SLAB_EXACT = 0, SLAB_FMA_FOLDED = 2 };
 template <typename R> struct SlabRay { // what a ray contributes to every slab test of its walk
-    V3<R> inv; // 1 / d
+    V3<R> inv; // 1 / d                                                               (SLAB_EXACT)
+    // near planes: t = plane * inv_n - oinv_n comes out ALREADY moved down by the error bound, far planes up   (SLAB_FMA_FOLDED)
+    float inv_n[3], oinv_n[3], inv_f[3], oinv_f[3];
 };
+template <typename Stack, typename R> constexpr int slab_form() { return sizeof(R) == 8 ? -1 : Stack::SLAB_F32; }
 // f64: the boxes are f32 and only cull, so the f64 kernels test them in f32 too — CONSERVATIVELY, which the f32
 // kernels need not be: origin and 1/d are rounded to f32 once per walk (1/d as v_rcp_f32 of the rounded d: 1 ulp — three
 // f64 divisions per walk start, instance entry and instance exit were 5 % of the f64 kernel's instructions), a plane
@@ -323,7 +331,7 @@ template <> struct SlabRay<double> {
     float oinv[3], inv[3]; // o * (1 / d) and 1 / d: a plane distance is ONE fma, plane * inv - oinv (below)
     float slack; // the largest of the three axes' slacks: one widening of the box's entry / exit serves all planes (below)
 };
-template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
+template <int FORM, typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     SlabRay<R> sr;
     if constexpr (sizeof(R) == 8) {
         const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
@@ -343,6 +351,23 @@ template <typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
         }
     } else {
         sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+        if constexpr (FORM == SLAB_FMA_FOLDED) {
+            // t32 = fl(b inv - oi), oi = fl(o inv), inv = rcp(d) (1 ulp): |t32 - t| <= 1.8e-7 |t| + 6e-8 |o inv|; the widening by
+            // 4.2e-7 |t| + 3.0e-7 |o_a inv_a| is folded into the constants: scaling by (1 -+ 4.2e-7) widens a positive distance —
+            // a negative near distance cannot set the entry (another axis's positive one or t_min does), a negative far
+            // distance means a box behind the origin — and an axis-parallel ray's NaNs drop out of max3 / min3.
+            const float oo[3] = {o.x, o.y, o.z}, ii[3] = {sr.inv.x, sr.inv.y, sr.inv.z};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                float inv = ii[a];
+                if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
+                const float oi = oo[a] * inv, slack = rt_fabs(oi) * 3.0e-7f;
+                sr.inv_n[a] = inv * (1.f - 4.2e-7f);
+                sr.inv_f[a] = inv * (1.f + 4.2e-7f);
+                sr.oinv_n[a] = __builtin_fmaf(oi, 1.f - 4.2e-7f, slack);
+                sr.oinv_f[a] = __builtin_fmaf(oi, 1.f + 4.2e-7f, -slack);
+            }
+        }
     }
     return sr;
 }
@@ -387,7 +412,7 @@ RT_HD void slab4_planes(const Planes4& nd, const float o[3], const float inv[3],
 // slack_k), so tn - 3.6e-7 |tn| - slack (slack = the largest axis slack) is a lower bound of the true entry, and likewise
 // an upper bound of the true exit: ONE widening per box instead of one per plane (round 1), a box the exact f64 test
 // would pass still always passes.  NaN / inf (axis-parallel rays) never cull.
-RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float e[4], bool h[4]) {
+template <int FORM> RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float e[4], bool h[4]) {
     float tn[4], tf[4];
     slab4_planes_fma(nd, sr.oinv, sr.inv, tn, tf);
 #pragma unroll
@@ -399,7 +424,19 @@ RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, f
         h[c] = !(hi < lo);
     }
 }
-RT_HD void slab_hit4(const Planes4& nd, V3<float> o, const SlabRay<float>& sr, float tmin, float tmax, float e[4], bool h[4]) {
+template <int FORM> RT_HD void slab_hit4(const Planes4& nd, V3<float> o, const SlabRay<float>& sr, float tmin, float tmax, float e[4], bool h[4]) {
+    if constexpr (FORM == SLAB_FMA_FOLDED) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float nx = __builtin_fmaf(nd.nr[0][c], sr.inv_n[0], -sr.oinv_n[0]), fx = __builtin_fmaf(nd.fr[0][c], sr.inv_f[0], -sr.oinv_f[0]);
+            const float ny = __builtin_fmaf(nd.nr[1][c], sr.inv_n[1], -sr.oinv_n[1]), fy = __builtin_fmaf(nd.fr[1][c], sr.inv_f[1], -sr.oinv_f[1]);
+            const float nz = __builtin_fmaf(nd.nr[2][c], sr.inv_n[2], -sr.oinv_n[2]), fz = __builtin_fmaf(nd.fr[2][c], sr.inv_f[2], -sr.oinv_f[2]);
+            const float lo = rt_max(rt_max(nz, rt_max(ny, nx)), tmin), hi = rt_min(rt_min(fz, rt_min(fy, fx)), tmax); // maxNum / minNum: a NaN drops out
+            e[c] = lo;
+            h[c] = !(hi < lo);
+        }
+        return;
+    }
     const float oo[3] = {o.x, o.y, o.z}, inv[3] = {sr.inv.x, sr.inv.y, sr.inv.z};
     float tn[4], tf[4];
     slab4_planes(nd, oo, inv, tn, tf);
@@ -709,7 +746,7 @@ template <typename R> struct Trav {
 
 template <typename R, typename Stack> RT_HD void trav_set_ray(Trav<R>& tr, const Ray<R>& ray, const Stack& stack) {
     tr.ray = ray;
-    tr.sr = slab_ray(ray.o, ray.d);
+    tr.sr = slab_ray<slab_form<Stack, R>()>(ray.o, ray.d);
 #pragma unroll
     for (int a = 0; a < 3; ++a) tr.near_off[a] = stack.plane_off(near_piece(a, tr.sr));
 }
@@ -762,7 +799,7 @@ RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     int32_t ch[4];
     float e[4];
     bool h[4];
-    slab_hit4(nd, tr.ray.o, tr.sr, lo_t, hi_t, e, h);
+    slab_hit4<slab_form<Stack, R>()>(nd, tr.ray.o, tr.sr, lo_t, hi_t, e, h);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         ch[c] = nd.child[c];

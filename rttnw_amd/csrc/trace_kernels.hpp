@@ -35,6 +35,7 @@ namespace rt {
 typedef __attribute__((address_space(3))) int32_t* LdsIntPtr;    // explicit address spaces: the compiler otherwise merges
 typedef __attribute__((address_space(1))) int32_t* GlobalIntPtr; // the two halves of get() into one FLAT load
 template <uint32_t STRIDE, uint32_t ENTRIES = LDS_STACK_ENTRIES> struct LdsStack { // STRIDE = lanes sharing the LDS stack area: entry e of a lane at base[e * STRIDE]; ENTRIES kept in LDS
+    static constexpr int SLAB_F32 = SLAB_EXACT; // node records in global memory: the f32 kernels' exact slab test (rt_core.hpp)
     static constexpr int SPARE = int(ENTRIES); // a lane's extra LDS slot: target of the node step's masked-off stores
     LdsIntPtr base;        // &lds[threadIdx.x]
     GlobalIntPtr spill;    // &spill_buffer[global thread]
@@ -69,6 +70,7 @@ template <uint32_t STRIDE, uint32_t ENTRIES = LDS_STACK_ENTRIES> struct LdsStack
 // over all the 16-byte bank slots (i mod 16); in node-major order the 128-byte records would all start at the same two
 // — measured on the 64-byte binary records: 31 % of the LDS cycles were bank conflicts that way.
 template <uint32_t STRIDE> struct LdsStackNodes : LdsStack<STRIDE> {
+    static constexpr int SLAB_F32 = SLAB_FMA_FOLDED; // the issue-bound form of the lane-owns-path kernel: the cheapest box test
     const int4* piece; // LDS
     uint32_t n_nodes;
     __device__ __forceinline__ uint32_t plane_off(uint32_t q) const { return q * n_nodes; }

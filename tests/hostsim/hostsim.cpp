@@ -28,6 +28,7 @@ using namespace rt;
 std::atomic<int> g_max_stack{0}; // deepest traversal-stack index written since the last hostsim_max_stack() call
 
 struct HostStack { // shaped like the device's: 16 entries + a spare slot "in LDS", the rest in a spill strip
+    static constexpr int SLAB_F32 = SLAB_EXACT;
     static constexpr int SPARE = 16;
     int32_t lds[17];
     int32_t spill[256];

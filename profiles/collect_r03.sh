@@ -5,7 +5,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03; mkdir -p $O
 # PMC first: the bench line reads `traffic` / `valu` from profiles/r03/pmc_*.txt while their kernel_source_sha matches
-for cfg in "final_scene f64" "final_scene f32" "cornell_box f64" "spheres_1m f32" "spheres_1m f64"; do
+for cfg in "final_scene f64" "final_scene f32" "cornell_box f64" "cornell_box f32" "spheres_1m f32" "spheres_1m f64"; do
   set -- $cfg
   PMC_QUICK=${PMC_QUICK_ALL:-} bash profiles/collect_pmc.sh $O/pmc_$1_$2 --workload $1 --precision $2 > $O/pmc_$1_$2.log 2>&1
   cp $O/pmc_$1_$2/summary.txt profiles/r03/pmc_$1_$2.txt

@@ -299,12 +299,13 @@ RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key) {
 // ---------------------------------------------------------------- AABB slab test (bound.rs:13-32)
 // The three per-axis early-outs of the reference collapse into one comparison: tmin only grows and
 // tmax only shrinks, so `tmax < tmin` at the end <=> it held at some axis.
-// (The FMA form t = bound*inv - o*inv was tried for f32 and rejected: its error is absolute, ~eps*|o*inv|, which
-// for a far-away origin and a small direction component — spheres_1m's primary rays — is larger than a leaf.)
 // Forms of the f32 kernels' slab test (the f64 kernels always use the conservative 7-value form below): the Stack type of a
-// kernel names its form (Stack::SLAB_F32) — the lane-owns-path kernel with its nodes in LDS is bound by vector-instruction issue
-// and takes the FOLDED conservative fma form, 11 operations per box (final_scene f32 1644 -> 1752 Msamples/s); the decoupled
-// kernel of HBM-resident trees keeps the exact two-operation form (the folded form's five more live registers cost it 13 %).
+// kernel names its form (Stack::SLAB_F32).  The lane-owns-path kernel with its nodes in LDS is bound by vector-instruction
+// issue and takes the FOLDED conservative fma form, t = plane * inv - o * inv with the error bound folded into the per-walk
+// constants: 11 operations per box instead of 18 (final_scene f32 1645 -> 1755 Msamples/s, cornell_box 2068 -> 2103).  The
+// kernels that read nodes from global memory (big trees) keep the exact two-operation form (plane - o) * inv: the fma form's
+// error is ABSOLUTE, ~eps |o inv|, which for a far-away origin and a small direction component — spheres_1m's primary rays —
+// is larger than a leaf, so its widening opens boxes the exact form culls (spheres_1m f32 396 -> 346 with the folded form).
 enum : int { SLAB_EXACT = 0, SLAB_FMA_FOLDED = 2 };
 template <typename R> struct SlabRay { // what a ray contributes to every slab test of its walk
     V3<R> inv; // 1 / d                                                               (SLAB_EXACT)
@@ -325,8 +326,7 @@ template <typename Stack, typename R> constexpr int slab_form() { return sizeof(
 // the two-operation form fl(fl(b - o32) inv32) it replaces had 6e-8 |o inv| there and used 1.2e-7), the range's ends are
 // rounded outward, and NaN / inf (axis-parallel rays) never cull.  A box the exact test would pass always passes: images
 // and hits are those of f64 slab tests, a node step costs about a third (f64 runs at half rate and selects move register
-// pairs).  (The f32 kernels keep the two-operation form: they carry no slack, and the fma form's absolute error
-// eps |o inv| is larger than a leaf for spheres_1m's far-away primary rays.)
+// pairs).
 template <> struct SlabRay<double> {
     float oinv[3], inv[3]; // o * (1 / d) and 1 / d: a plane distance is ONE fma, plane * inv - oinv (below)
     float slack; // the largest of the three axes' slacks: one widening of the box's entry / exit serves all planes (below)

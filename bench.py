@@ -268,14 +268,20 @@ def main():
                         "note": "achieved = SQ_INSTS_VALU x SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) / kernel time: the vector "
                                 "instructions of one launch counted as full 64-lane instructions; peak = 1024 SIMDs x 2.4 GHz / cycles "
                                 "per wave64 instruction of this kernel's arithmetic"}
-            kernel = ("rt::trace_kernel_plain<%s, ...>" if form == 0 else "rt::trace_kernel<%s, ...>") % ("float" if prec == abi.F32 else "double")
+            lds_resident = form == 0 and self.info.n_nodes * 112 <= 140 * 1024
+            # the instantiation that ran, as rocprofv3's kernel trace names it (<R, COUNT, BLOCK, LDS nodes, GENERAL>; the bench
+            # scenes have none of the rare graph shapes of the GENERAL instantiations)
+            rname = "float" if prec == abi.F32 else "double"
+            kernel = ("rt::trace_kernel<%s, false, false>" % rname if form != 0 else
+                      "rt::trace_kernel_plain<%s, false, %s, false>" % (rname, "1024, true" if lds_resident else "256, false"))
             common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
-                      "per_sample": {k: round(v, 3) for k, v in per.items()}, "hbm_algorithmic": hbm_alg, "valu": valu}
+                      "per_sample": {k: round(v, 3) for k, v in per.items()},
+                      "grays_per_s": round(per["rays"] * self.samples_rank / secs / 1e9, 3) if secs > 0 else None,  # world.hit() calls / s
+                      "hbm_algorithmic": hbm_alg, "valu": valu}
             if traffic is not None and secs > 0:
                 common["traffic_frac_of_hbm_peak"] = round(traffic / secs / 1e9 / HBM_PEAK_GBPS, 5)
             # what bounds the kernel: memory when the node records are walked in HBM / Infinity Cache (the decoupled kernel:
             # counter traffic ~ algorithmic bytes), vector-instruction issue when they are LDS-resident (counter traffic ~1 % of peak)
-            lds_resident = form == 0 and self.info.n_nodes * 112 <= 140 * 1024
             if lds_resident and valu is not None:
                 out = {"bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"], "frac": valu["frac"]}
                 out["note"] = ("node records are LDS-resident: the kernel is bound by vector-instruction issue at this lane utilisation, "

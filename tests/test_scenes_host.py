@@ -94,3 +94,26 @@ def test_wide_nodes_are_the_collapsed_binary_tree(hostsim, scenes_lib, earth, na
     dims = (C.c_uint32 * 8)()
     hostsim.lib.hostsim_scene_dims(sc.handle, dims)
     assert need + 1 <= dims[7]   # (+ the instances' trees, held against real walks by test_core_f64_equals_golden)
+
+
+def test_parallel_host_builder_is_deterministic_and_complete(hostsim, scenes_lib):
+    """A big flat list goes through the host builder's parallel paths (scene_lower.cpp: parallel collection, SAH topology by
+    splits whose halves run on two threads from 32 768 items up, record emission in chunks): every sphere must sit in exactly
+    one leaf, child boxes must nest, and two builds must be the same tree bit for bit — nothing may depend on thread timing."""
+    n_spheres = 70000
+    trees = []
+    for _ in range(2):
+        sc, _ = util.build(hostsim, scenes_lib, "spheres_1m", None, n_spheres)
+        n2, root2 = util.nodes_of(hostsim, sc)
+        n4, root4 = util.nodes_of(hostsim, sc, wide=True)
+        trees.append((n2.tobytes(), n4.tobytes(), root2, root4))
+    assert trees[0] == trees[1]
+    leaves = util.leaves_of_binary(n2, root2)                    # leaf codes: ~(kind << 28 | (records - 1) << 26 | first record)
+    records = []
+    for code in leaves:
+        bits = ~code & 0xFFFFFFFF
+        records += [(bits >> 28, (bits & 0x3FFFFFF) + k) for k in range(((bits >> 26) & 3) + 1)]
+    assert len(records) == len(set(records)) == n_spheres + 1    # every record in exactly one leaf (+ the area light)
+    assert sorted(r for k, r in records if k == 0) == list(range(n_spheres))   # PRIM_SPHERE = 0: records 0 .. n-1, emitted in leaf order
+    leaves4, need, seen = util.check_wide_tree(n4, root4)        # boxes nest, every 4-wide record reached once
+    assert leaves4 == leaves and len(seen) == len(n4)

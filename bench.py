@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--no-sub", action="store_true", help="skip the cornell_box / spheres_1m sub-records of the default run")
     ap.add_argument("--sub-steps", type=int, default=3, help="timed steps of each sub-record (after one warm-up step)")
     ap.add_argument("--spp-chunk", type=int, default=0, help="samples per work item (0 = the library's tapered schedule)")
-    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh"], help="BVH builder at commit: host binned SAH (default) or device LBVH")
+    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "dsah"], help="BVH builder at commit: host binned SAH (default), device LBVH, device binned SAH")
     ap.add_argument("--share", default=None, metavar="R/W",
                     help="trace ONE rank's share (rank R of a W-way partition) of the N = W workload on this GPU, no gather: "
                          "what each GPU of a W-GPU run does (not a bench line for the driver)")
@@ -172,7 +172,7 @@ def main():
             self.spp = self.spp1 * world  # weak scaling: fixed per-GPU work
             t0 = time.time()
             self.sc, self.setup = S.build(gpu, scenes, self.scene_name, earth, self.param,
-                                          bvh=abi.BVH_DEVICE_LBVH if args.bvh == "lbvh" else None)
+                                          bvh={"lbvh": abi.BVH_DEVICE_LBVH, "dsah": abi.BVH_DEVICE_SAH}.get(args.bvh))
             self.build_s = time.time() - t0
             self.binfo = self.sc.build_info()
             self.info = abi.Stats()

@@ -30,6 +30,7 @@ pub const RTTNW_QUIRK_YROTATE_BACKROT: u32 = 1;
 pub const RTTNW_QUIRKS_REFERENCE: u32 = RTTNW_QUIRK_YROTATE_BACKROT;
 pub const RTTNW_BVH_HOST_SAH: u32 = 0;
 pub const RTTNW_BVH_DEVICE_LBVH: u32 = 1;
+pub const RTTNW_BVH_DEVICE_SAH: u32 = 2;
 
 /// `CameraDescriptor` — src/math/camera.rs:5-15
 #[repr(C)]

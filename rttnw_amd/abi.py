@@ -11,7 +11,7 @@ ERR_NAMES = {-1: "RTTNW_ERR_INVALID", -2: "RTTNW_ERR_STATE", -3: "RTTNW_ERR_UNSU
 
 XY, XZ, YZ = 0, 1, 2
 F64, F32 = 0, 1
-BVH_HOST_SAH, BVH_DEVICE_LBVH = 0, 1
+BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_DEVICE_SAH = 0, 1, 2
 QUIRK_YROTATE_BACKROT = 1
 QUIRKS_REFERENCE = QUIRK_YROTATE_BACKROT
 

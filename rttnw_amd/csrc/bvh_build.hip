@@ -174,6 +174,293 @@ __global__ void relayout_kernel(const BvhNode* __restrict__ in, const int* __res
 }
 
 
+// ---- binned SAH on the device (RTTNW_BVH_DEVICE_SAH): the host builder's algorithm (scene_lower.cpp split(): best of the binned
+// surface-area-heuristic planes of the three axes over the centroid bounds, every leaf one record) as level-synchronous kernels.
+// A node of the tree IS its pre-order index: a node over `count` leaves has count - 1 inner nodes below and including it, so the
+// children of node s whose left side holds nl leaves are s + 1 and s + nl — numbering needs no pass of its own, and nothing
+// depends on the order in which the level's segments are processed.  The leaves of a node stand contiguously in a ping-pong pair of
+// leaf arrays ([begin, begin + count)); a level
+//   * bins the leaves of every LARGE segment (> SAH_SMALL leaves) into 3 x SAH_BINS bins — per-block LDS bins where a block's 256
+//     positions lie in one segment (the top levels), global atomics otherwise; boxes and centroid bounds as order-preserving
+//     integers, so the atomic min / max do not depend on arrival order —
+//   * picks every large segment's plane (one thread per segment), writes its node record, creates its children,
+//   * partitions the leaves stably (a scan of the "goes left" flags over all positions), and
+//   * splits every SMALL segment by an exact sweep, one wave per segment: lane i tries "everything up to leaf i's centroid goes
+//     left" on each axis, the wave takes the cheapest candidate.
+constexpr int SAH_BINS = 16;
+constexpr int SAH_SMALL = 64;
+__device__ __forceinline__ uint32_t enc_f(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float dec_f(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); }
+struct SahBin { uint32_t count; uint32_t lo[3], hi[3]; uint32_t clo[3], chi[3]; }; // boxes / centroid bounds: enc_f
+struct SahSeg { int begin, count; float clo[3], chi[3]; };                           // a node's leaves and their centroid bounds
+struct SahSplit { int axis, bin, nl, median; };                                      // how a large segment's leaves divide (median: by position)
+__device__ __forceinline__ float box_area(const float* lo, const float* hi) {
+    const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+    if (d0 < 0.f || d1 < 0.f || d2 < 0.f) return 0.f;
+    return d0 * d1 + d1 * d2 + d2 * d0;
+}
+__device__ __forceinline__ int sah_bin_of(float c, float clo, float chi) {
+    const float ext = chi - clo;
+    if (!(ext > 0.f)) return 0;
+    return min(SAH_BINS - 1, max(0, int((c - clo) * (float(SAH_BINS) / ext))));
+}
+__global__ void sah_bins_init_kernel(SahBin* __restrict__ bins, int n_bins) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bins) return;
+    SahBin b;
+    b.count = 0;
+    for (int a = 0; a < 3; ++a) { b.lo[a] = 0xFFFFFFFFu; b.hi[a] = 0u; b.clo[a] = 0xFFFFFFFFu; b.chi[a] = 0u; }
+    bins[i] = b;
+}
+// seg[i]: the large segment (node) position i belongs to, or < 0 (a small segment's, or finished)
+__global__ void sah_bin_kernel(const BuildPrim* __restrict__ prims, const int* __restrict__ seg, int n, const SahSeg* __restrict__ segs,
+                               const int* __restrict__ slot_of, SahBin* __restrict__ bins) {
+    __shared__ uint32_t lbins[3 * SAH_BINS * 13];
+    __shared__ int uniform;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = i < n ? seg[i] : -1;
+    const int first = seg[min(n - 1, int(blockIdx.x * blockDim.x))], last = seg[min(n - 1, int(blockIdx.x * blockDim.x + blockDim.x - 1))];
+    if (threadIdx.x == 0) uniform = (first >= 0 && first == last && blockIdx.x * blockDim.x + blockDim.x <= unsigned(n)) ? 1 : 0; // positions of a segment are contiguous
+    __syncthreads();
+    const bool in_lds = uniform != 0;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < 3 * SAH_BINS * 13; k += blockDim.x) {
+            const int w = k % 13;
+            lbins[k] = w == 0 ? 0u : ((w >= 1 && w <= 3) || (w >= 7 && w <= 9) ? 0xFFFFFFFFu : 0u);
+        }
+        __syncthreads();
+    }
+    if (s >= 0) {
+        const BuildPrim p = prims[i];
+        const SahSeg sg = segs[s];
+        float c[3];
+        for (int a = 0; a < 3; ++a) c[a] = 0.5f * (p.lo[a] + p.hi[a]);
+        for (int a = 0; a < 3; ++a) {
+            const int b = sah_bin_of(c[a], sg.clo[a], sg.chi[a]);
+            if (in_lds) {
+                uint32_t* q = lbins + (a * SAH_BINS + b) * 13;
+                atomicAdd(q, 1u);
+                for (int k = 0; k < 3; ++k) { atomicMin(q + 1 + k, enc_f(p.lo[k])); atomicMax(q + 4 + k, enc_f(p.hi[k])); atomicMin(q + 7 + k, enc_f(c[k])); atomicMax(q + 10 + k, enc_f(c[k])); }
+            } else {
+                SahBin* q = bins + (size_t(slot_of[s]) * 3 + a) * SAH_BINS + b;
+                atomicAdd(&q->count, 1u);
+                for (int k = 0; k < 3; ++k) { atomicMin(&q->lo[k], enc_f(p.lo[k])); atomicMax(&q->hi[k], enc_f(p.hi[k])); atomicMin(&q->clo[k], enc_f(c[k])); atomicMax(&q->chi[k], enc_f(c[k])); }
+            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        uint32_t* g = reinterpret_cast<uint32_t*>(bins + size_t(slot_of[first]) * 3 * SAH_BINS);
+        for (int k = threadIdx.x; k < 3 * SAH_BINS * 13; k += blockDim.x) {
+            const int w = k % 13;
+            const uint32_t v = lbins[k];
+            if (w == 0) { if (v) atomicAdd(g + k, v); }
+            else if ((w >= 1 && w <= 3) || (w >= 7 && w <= 9)) { if (v != 0xFFFFFFFFu) atomicMin(g + k, v); }
+            else if (v != 0u) atomicMax(g + k, v);
+        }
+    }
+}
+struct SahLists { int n_large, n_small; }; // the NEXT level's segment counts (appended to with atomics)
+__device__ __forceinline__ void sah_make_child(int node, int begin, int count, const float* clo, const float* chi, SahSeg* __restrict__ segs,
+                                               int* __restrict__ slot_of, int* __restrict__ next_large, int* __restrict__ next_small,
+                                               SahLists* __restrict__ next) {
+    if (count < 2) return;
+    SahSeg sg;
+    sg.begin = begin; sg.count = count;
+    for (int a = 0; a < 3; ++a) { sg.clo[a] = clo[a]; sg.chi[a] = chi[a]; }
+    segs[node] = sg;
+    if (count > SAH_SMALL) { const int k = atomicAdd(&next->n_large, 1); next_large[k] = node; slot_of[node] = k; } // its bins next level
+    else next_small[atomicAdd(&next->n_small, 1)] = node;
+}
+// One thread per large segment: the cheapest of the 3 x (SAH_BINS - 1) planes (scene_lower.cpp split()), the node record, the children.
+__global__ void sah_eval_kernel(const int* __restrict__ large, int n_large, const SahBin* __restrict__ bins, SahSeg* __restrict__ segs,
+                                SahSplit* __restrict__ split, BvhNode* __restrict__ out, int* __restrict__ slot_of, int* __restrict__ next_large,
+                                int* __restrict__ next_small, SahLists* __restrict__ next) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_large) return;
+    const int s = large[k];
+    const SahSeg sg = segs[s];
+    const SahBin* bs = bins + size_t(k) * 3 * SAH_BINS;
+    float best = INFINITY;
+    int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; ++a) {
+        if (!(sg.chi[a] - sg.clo[a] > 0.f)) continue;
+        float r_area[SAH_BINS];
+        uint32_t r_cnt[SAH_BINS];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t cnt = 0;
+        for (int b = SAH_BINS - 1; b > 0; --b) {
+            const SahBin q = bs[a * SAH_BINS + b];
+            if (q.count) for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], dec_f(q.lo[c])); hi[c] = fmaxf(hi[c], dec_f(q.hi[c])); }
+            cnt += q.count;
+            r_area[b] = box_area(lo, hi); r_cnt[b] = cnt;
+        }
+        for (int c = 0; c < 3; ++c) { lo[c] = INFINITY; hi[c] = -INFINITY; }
+        cnt = 0;
+        for (int b = 0; b < SAH_BINS - 1; ++b) {
+            const SahBin q = bs[a * SAH_BINS + b];
+            if (q.count) for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], dec_f(q.lo[c])); hi[c] = fmaxf(hi[c], dec_f(q.hi[c])); }
+            cnt += q.count;
+            if (cnt == 0 || r_cnt[b + 1] == 0) continue;
+            const float cost = box_area(lo, hi) * float(cnt) + r_area[b + 1] * float(r_cnt[b + 1]);
+            if (cost < best) { best = cost; best_axis = a; best_bin = b; }
+        }
+    }
+    SahSplit sp;
+    float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY}, rlo[3] = {INFINITY, INFINITY, INFINITY},
+          rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float lclo[3] = {INFINITY, INFINITY, INFINITY}, lchi[3] = {-INFINITY, -INFINITY, -INFINITY}, rclo[3] = {INFINITY, INFINITY, INFINITY},
+          rchi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int nl = 0;
+    if (best_axis >= 0) {
+        for (int b = 0; b < SAH_BINS; ++b) {
+            const SahBin q = bs[best_axis * SAH_BINS + b];
+            if (!q.count) continue;
+            const bool left = b <= best_bin;
+            for (int c = 0; c < 3; ++c) {
+                if (left) { llo[c] = fminf(llo[c], dec_f(q.lo[c])); lhi[c] = fmaxf(lhi[c], dec_f(q.hi[c])); lclo[c] = fminf(lclo[c], dec_f(q.clo[c])); lchi[c] = fmaxf(lchi[c], dec_f(q.chi[c])); }
+                else { rlo[c] = fminf(rlo[c], dec_f(q.lo[c])); rhi[c] = fmaxf(rhi[c], dec_f(q.hi[c])); rclo[c] = fminf(rclo[c], dec_f(q.clo[c])); rchi[c] = fmaxf(rchi[c], dec_f(q.chi[c])); }
+            }
+            if (left) nl += int(q.count);
+        }
+        sp.axis = best_axis; sp.bin = best_bin; sp.nl = nl; sp.median = 0;
+    } else {
+        // every centroid in one bin on every axis (coincident centroids): halve by position; the children's boxes and centroid
+        // bounds are the parent's (conservative: boxes only cull)
+        const SahBin q0 = bs[0];
+        (void)q0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < SAH_BINS; ++b) {
+                const SahBin q = bs[a * SAH_BINS + b];
+                if (!q.count) continue;
+                for (int c = 0; c < 3; ++c) { llo[c] = fminf(llo[c], dec_f(q.lo[c])); lhi[c] = fmaxf(lhi[c], dec_f(q.hi[c])); }
+            }
+        for (int c = 0; c < 3; ++c) { rlo[c] = llo[c]; rhi[c] = lhi[c]; lclo[c] = rclo[c] = sg.clo[c]; lchi[c] = rchi[c] = sg.chi[c]; }
+        nl = sg.count / 2;
+        sp.axis = 0; sp.bin = 0; sp.nl = nl; sp.median = 1;
+    }
+    split[s] = sp;
+    const int nr = sg.count - nl;
+    BvhNode nd;
+    for (int c = 0; c < 3; ++c) { nd.lo0[c] = llo[c]; nd.hi0[c] = lhi[c]; nd.lo1[c] = rlo[c]; nd.hi1[c] = rhi[c]; }
+    nd.child0 = nl > 1 ? s + 1 : CHILD_EMPTY;  // a single leaf's code is filled in by the partition kernel
+    nd.child1 = nr > 1 ? s + nl : CHILD_EMPTY;
+    nd.pad0 = nd.pad1 = 0;
+    out[s] = nd;
+    sah_make_child(s + 1, sg.begin, nl, lclo, lchi, segs, slot_of, next_large, next_small, next);
+    sah_make_child(s + nl, sg.begin + nl, nr, rclo, rchi, segs, slot_of, next_large, next_small, next);
+}
+__global__ void sah_flag_kernel(const BuildPrim* __restrict__ prims, const int* __restrict__ seg, int n, const SahSeg* __restrict__ segs,
+                                const SahSplit* __restrict__ split, uint32_t* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = seg[i];
+    uint32_t f = 0;
+    if (s >= 0) {
+        const SahSplit sp = split[s];
+        const SahSeg sg = segs[s];
+        if (sp.median) f = (i - sg.begin) < sp.nl;
+        else {
+            const BuildPrim p = prims[i];
+            f = sah_bin_of(0.5f * (p.lo[sp.axis] + p.hi[sp.axis]), sg.clo[sp.axis], sg.chi[sp.axis]) <= sp.bin;
+        }
+    }
+    flag[i] = f;
+}
+__global__ void sah_partition_kernel(const BuildPrim* __restrict__ prims, const int* __restrict__ seg, int n, const SahSeg* __restrict__ segs,
+                                     const SahSplit* __restrict__ split, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scanned,
+                                     BuildPrim* __restrict__ prims_out, int* __restrict__ seg_out, BvhNode* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = seg[i];
+    if (s < 0) { seg_out[i] = -1; return; } // (the output array still holds this position's owner of two levels ago)
+    const SahSplit sp = split[s];
+    const SahSeg sg = segs[s];
+    const bool left = flag[i] != 0u;
+    const int lrank = int(scanned[i] - scanned[sg.begin]);
+    const int at = left ? sg.begin + lrank : sg.begin + sp.nl + ((i - sg.begin) - lrank);
+    const BuildPrim p = prims[i];
+    prims_out[at] = p;
+    const int side_count = left ? sp.nl : sg.count - sp.nl;
+    const int child = left ? s + 1 : s + sp.nl;
+    seg_out[at] = side_count > SAH_SMALL ? child : -1; // small segments go by their own list, single leaves are finished
+    if (side_count == 1) { if (left) out[s].child0 = p.leaf; else out[s].child1 = p.leaf; }
+}
+// One wave per small segment (2 .. SAH_SMALL leaves, one per lane): exact sweep on the three axes.
+__global__ void sah_small_kernel(const int* __restrict__ small, int n_small, const BuildPrim* __restrict__ prims, SahSeg* __restrict__ segs,
+                                 BuildPrim* __restrict__ prims_out, BvhNode* __restrict__ out, int* __restrict__ next_small, SahLists* __restrict__ next) {
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (w >= n_small) return;
+    const int s = small[w];
+    const int begin = segs[s].begin, count = segs[s].count;
+    const bool on = lane < count;
+    BuildPrim p;
+    if (on) p = prims[begin + lane];
+    else { for (int a = 0; a < 3; ++a) { p.lo[a] = INFINITY; p.hi[a] = -INFINITY; } p.leaf = CHILD_EMPTY; p.pad = 0; }
+    float c[3];
+    for (int a = 0; a < 3; ++a) c[a] = on ? 0.5f * (p.lo[a] + p.hi[a]) : INFINITY;
+    float best = INFINITY;
+    int best_axis = 0;
+    float bl[6], br[6]; // the best candidate's two boxes
+    for (int k = 0; k < 3; ++k) { bl[k] = br[k] = INFINITY; bl[3 + k] = br[3 + k] = -INFINITY; }
+    for (int a = 0; a < 3; ++a) {
+        float l[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}, r[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int nl = 0;
+        for (int j = 0; j < count; ++j) {
+            const float cj = __shfl(c[a], j, 64);
+            const bool in_left = cj < c[a] || (cj == c[a] && j <= lane);
+            for (int k = 0; k < 3; ++k) {
+                const float lo = __shfl(p.lo[k], j, 64), hi = __shfl(p.hi[k], j, 64);
+                if (in_left) { l[k] = fminf(l[k], lo); l[3 + k] = fmaxf(l[3 + k], hi); }
+                else { r[k] = fminf(r[k], lo); r[3 + k] = fmaxf(r[3 + k], hi); }
+            }
+            nl += in_left;
+        }
+        const int nr = count - nl;
+        const float cost = (on && nr > 0) ? box_area(l, l + 3) * float(nl) + box_area(r, r + 3) * float(nr) : INFINITY;
+        if (cost < best) { best = cost; best_axis = a; for (int k = 0; k < 6; ++k) { bl[k] = l[k]; br[k] = r[k]; } }
+    }
+    // the wave's cheapest candidate: (cost, axis, lane) lexicographically, so that ties do not depend on anything but the data
+    float wc = best;
+    int wa = best_axis, wl = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(wc, off, 64);
+        const int oa = __shfl_xor(wa, off, 64), ol = __shfl_xor(wl, off, 64);
+        if (oc < wc || (oc == wc && (oa < wa || (oa == wa && ol < wl)))) { wc = oc; wa = oa; wl = ol; }
+    }
+    // (count >= 2: the candidate of the leaf that comes first on an axis always has a right side, so wc is finite unless a box is not)
+    const float ca = wa == 0 ? c[0] : (wa == 1 ? c[1] : c[2]);
+    const float cw = __shfl(ca, wl, 64);
+    const bool in_left = on && (ca < cw || (ca == cw && lane <= wl));
+    const unsigned long long lm = __ballot(in_left), rm = __ballot(on && !in_left);
+    int nl = __popcll(lm), nr = __popcll(rm);
+    float lbox[6], rbox[6];
+    for (int k = 0; k < 6; ++k) { lbox[k] = __shfl(bl[k], wl, 64); rbox[k] = __shfl(br[k], wl, 64); }
+    if (!(wc < INFINITY) || nl == 0 || nr == 0) { // boxes that are not finite: halve by position, both children take the union
+        nl = count / 2; nr = count - nl;
+        float u[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int j = 0; j < count; ++j)
+            for (int k = 0; k < 3; ++k) { u[k] = fminf(u[k], __shfl(p.lo[k], j, 64)); u[3 + k] = fmaxf(u[3 + k], __shfl(p.hi[k], j, 64)); }
+        for (int k = 0; k < 6; ++k) lbox[k] = rbox[k] = u[k];
+    }
+    const bool med = !(wc < INFINITY) || __popcll(lm) == 0 || __popcll(rm) == 0;
+    const bool go_left = med ? (on && lane < nl) : in_left;
+    const unsigned long long glm = __ballot(go_left), grm = __ballot(on && !go_left), below = (1ull << lane) - 1ull;
+    if (on) prims_out[go_left ? begin + __popcll(glm & below) : begin + nl + __popcll(grm & below)] = p;
+    const int first_l = __ffsll((long long)glm) - 1, first_r = __ffsll((long long)grm) - 1;
+    const int leaf_l = __shfl(p.leaf, max(first_l, 0), 64), leaf_r = __shfl(p.leaf, max(first_r, 0), 64);
+    if (lane == 0) {
+        BvhNode nd;
+        for (int k = 0; k < 3; ++k) { nd.lo0[k] = lbox[k]; nd.hi0[k] = lbox[3 + k]; nd.lo1[k] = rbox[k]; nd.hi1[k] = rbox[3 + k]; }
+        nd.child0 = nl > 1 ? s + 1 : leaf_l;
+        nd.child1 = nr > 1 ? s + nl : leaf_r;
+        nd.pad0 = nd.pad1 = 0;
+        out[s] = nd;
+        if (nl > 1) { SahSeg sg; sg.begin = begin; sg.count = nl; for (int a = 0; a < 3; ++a) { sg.clo[a] = 0.f; sg.chi[a] = 0.f; } segs[s + 1] = sg; next_small[atomicAdd(&next->n_small, 1)] = s + 1; }
+        if (nr > 1) { SahSeg sg; sg.begin = begin + nl; sg.count = nr; for (int a = 0; a < 3; ++a) { sg.clo[a] = 0.f; sg.chi[a] = 0.f; } segs[s + nl] = sg; next_small[atomicAdd(&next->n_small, 1)] = s + nl; }
+    }
+}
+
 // ---- binary tree -> 4-wide records
 struct Slot { float lo[3], hi[3]; int32_t child; };
 __device__ __forceinline__ double slot_area(const Slot& s) { // as scene_lower.cpp slot_area: the same doubles, the same pick
@@ -273,7 +560,7 @@ struct DeviceFree { // frees on the device the buffer lives on
 };
 } // namespace
 
-int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& tree, double* kernel_ms, std::string& err) {
+int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, bool sah, DeviceTree& tree, double* kernel_ms, std::string& err) {
     const size_t n = prims.size();
     if (n < 2 || n >= (size_t(1) << 26)) { err = "lbvh_build: needs 2 .. 2^26-1 leaves"; return -1; }
     int rc = 0;
@@ -303,8 +590,18 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& tree
     NodeBox* d_box = nullptr;
     BvhNode *d_out = nullptr, *d_out2 = nullptr;
     int* d_pos = nullptr;
-    void *d_temp = nullptr, *d_temp2 = nullptr;
-    size_t temp_bytes = 0, temp2_bytes = 0;
+    void *d_temp = nullptr, *d_temp2 = nullptr, *d_temp3 = nullptr;
+    size_t temp_bytes = 0, temp2_bytes = 0, temp3_bytes = 0;
+    // binned SAH
+    BuildPrim *d_pa = nullptr, *d_pb = nullptr;
+    int *d_sa = nullptr, *d_sb = nullptr, *d_slot = nullptr, *d_list[4] = {nullptr, nullptr, nullptr, nullptr}; // lists: large a/b, small a/b
+    SahSeg* d_segs = nullptr;
+    SahSplit* d_split = nullptr;
+    SahBin* d_bins = nullptr;
+    SahLists* d_next = nullptr;
+    uint32_t *d_flag = nullptr, *d_scan = nullptr;
+    int sah_levels = 0;
+    const size_t max_large = n / size_t(SAH_SMALL + 1) + 2;
     // collapse
     int *d_heads = nullptr, *d_count = nullptr;
     uint32_t *d_is_head = nullptr, *d_rank = nullptr, *d_need = nullptr;
@@ -338,6 +635,25 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& tree
         LBVH_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
         LBVH_TRY(rocprim::exclusive_scan(nullptr, temp2_bytes, d_is_head, d_rank, 0u, size_t(n_inner), rocprim::plus<uint32_t>(), hipStream_t(0)));
         LBVH_TRY(hipMalloc(&d_temp2, std::max<size_t>(temp2_bytes, 16)));
+        if (sah) {
+            LBVH_TRY(hipMalloc((void**)&d_pa, n * sizeof(BuildPrim)));
+            LBVH_TRY(hipMalloc((void**)&d_pb, n * sizeof(BuildPrim)));
+            LBVH_TRY(hipMalloc((void**)&d_sa, n * 4));
+            LBVH_TRY(hipMalloc((void**)&d_sb, n * 4));
+            LBVH_TRY(hipMalloc((void**)&d_slot, n * 4));
+            LBVH_TRY(hipMalloc((void**)&d_list[0], max_large * 4));
+            LBVH_TRY(hipMalloc((void**)&d_list[1], max_large * 4));
+            LBVH_TRY(hipMalloc((void**)&d_list[2], (n / 2 + 2) * 4));
+            LBVH_TRY(hipMalloc((void**)&d_list[3], (n / 2 + 2) * 4));
+            LBVH_TRY(hipMalloc((void**)&d_segs, n * sizeof(SahSeg)));
+            LBVH_TRY(hipMalloc((void**)&d_split, n * sizeof(SahSplit)));
+            LBVH_TRY(hipMalloc((void**)&d_bins, max_large * 3 * SAH_BINS * sizeof(SahBin)));
+            LBVH_TRY(hipMalloc((void**)&d_next, sizeof(SahLists)));
+            LBVH_TRY(hipMalloc((void**)&d_flag, n * 4));
+            LBVH_TRY(hipMalloc((void**)&d_scan, n * 4));
+            LBVH_TRY(rocprim::exclusive_scan(nullptr, temp3_bytes, d_flag, d_scan, 0u, n, rocprim::plus<uint32_t>(), hipStream_t(0)));
+            LBVH_TRY(hipMalloc(&d_temp3, std::max<size_t>(temp3_bytes, 16)));
+        }
         LBVH_TRY(hipEventCreate(&e0));
         LBVH_TRY(hipEventCreate(&e1));
         t_alloc = wall_ms();
@@ -345,6 +661,44 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& tree
         t_up = wall_ms();
 
         LBVH_TRY(hipEventRecord(e0, 0));
+        if (sah) {
+            // level 0: the root segment over all leaves, with the centroid bounds the host has already
+            SahSeg root;
+            root.begin = 0; root.count = int(n);
+            for (int a = 0; a < 3; ++a) { root.clo[a] = cmin[a]; root.chi[a] = cmax[a]; }
+            const int zero = 0;
+            LBVH_TRY(hipMemcpyAsync(d_segs, &root, sizeof(root), hipMemcpyHostToDevice, 0));
+            LBVH_TRY(hipMemcpyAsync(d_slot, &zero, 4, hipMemcpyHostToDevice, 0));
+            int n_large = n > size_t(SAH_SMALL) ? 1 : 0, n_small = 1 - n_large;
+            LBVH_TRY(hipMemcpyAsync(d_list[n_large ? 0 : 2], &zero, 4, hipMemcpyHostToDevice, 0));
+            LBVH_TRY(hipMemsetAsync(d_sa, n_large ? 0 : 0xFF, n * 4, 0)); // every position in segment 0 (large) or none (small)
+            LBVH_TRY(hipMemcpyAsync(d_pa, d_prims, n * sizeof(BuildPrim), hipMemcpyDeviceToDevice, 0));
+            int cur = 0; // which of the ping-pong arrays / lists is the level's input
+            while (n_large > 0 || n_small > 0) {
+                if (++sah_levels > 4096) { err = "lbvh_build: the SAH build did not converge"; rc = -4; goto done; }
+                BuildPrim *pin = cur ? d_pb : d_pa, *pout = cur ? d_pa : d_pb;
+                int *sin = cur ? d_sb : d_sa, *sout = cur ? d_sa : d_sb;
+                int *large_in = d_list[cur], *large_out = d_list[cur ^ 1], *small_in = d_list[2 + cur], *small_out = d_list[2 + (cur ^ 1)];
+                LBVH_TRY(hipMemsetAsync(d_next, 0, sizeof(SahLists), 0));
+                if (n_large > 0) {
+                    const int n_bins = n_large * 3 * SAH_BINS;
+                    hipLaunchKernelGGL(sah_bins_init_kernel, dim3((n_bins + 255) / 256), dim3(256), 0, 0, d_bins, n_bins);
+                    hipLaunchKernelGGL(sah_bin_kernel, dim3(nb), dim3(256), 0, 0, pin, sin, int(n), d_segs, d_slot, d_bins);
+                    hipLaunchKernelGGL(sah_eval_kernel, dim3((n_large + 63) / 64), dim3(64), 0, 0, large_in, n_large, d_bins, d_segs, d_split, d_out2, d_slot,
+                                       large_out, small_out, d_next);
+                    hipLaunchKernelGGL(sah_flag_kernel, dim3(nb), dim3(256), 0, 0, pin, sin, int(n), d_segs, d_split, d_flag);
+                    LBVH_TRY(rocprim::exclusive_scan(d_temp3, temp3_bytes, d_flag, d_scan, 0u, n, rocprim::plus<uint32_t>(), hipStream_t(0)));
+                    hipLaunchKernelGGL(sah_partition_kernel, dim3(nb), dim3(256), 0, 0, pin, sin, int(n), d_segs, d_split, d_flag, d_scan, pout, sout, d_out2);
+                }
+                if (n_small > 0)
+                    hipLaunchKernelGGL(sah_small_kernel, dim3((n_small + 3) / 4), dim3(256), 0, 0, small_in, n_small, pin, d_segs, pout, d_out2, small_out, d_next);
+                SahLists h_next;
+                LBVH_TRY(hipMemcpy(&h_next, d_next, sizeof(h_next), hipMemcpyDeviceToHost));
+                if (size_t(h_next.n_large) > max_large || size_t(h_next.n_small) > n / 2 + 2) { err = "lbvh_build: SAH segment lists overflowed"; rc = -4; goto done; }
+                n_large = h_next.n_large; n_small = h_next.n_small;
+                cur ^= 1;
+            }
+        } else {
         LBVH_TRY(hipMemsetAsync(d_done, 0, (n - 1) * 4, 0));
         hipLaunchKernelGGL(morton_kernel, dim3(nb), dim3(256), 0, 0, d_prims, uint32_t(n), cmin[0], cmin[1], cmin[2], scale[0], scale[1],
                            scale[2], d_keys, d_order);
@@ -361,6 +715,7 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& tree
         }
         hipLaunchKernelGGL(preorder_kernel, dim3(nb), dim3(256), 0, 0, d_children, d_node_parent, n_inner, d_pos);
         hipLaunchKernelGGL(relayout_kernel, dim3(nb), dim3(256), 0, 0, d_out, d_pos, n_inner, 0, d_out2);
+        }
 
         // ---- collapse: heads level by level (root first), numbering, records, stack bound
         LBVH_TRY(hipMemsetAsync(d_is_head, 0, size_t(n_inner) * 4, 0));
@@ -399,7 +754,8 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& tree
         LBVH_TRY(hipEventElapsedTime(&ms, e0, e1));
         if (kernel_ms) *kernel_ms += ms;
         t_kernels = wall_ms();
-        LBVH_TRY(hipMemcpy(&h_levels, d_levels, 4, hipMemcpyDeviceToHost));
+        if (sah) h_levels = sah_levels; // one level of inner nodes per round
+        else LBVH_TRY(hipMemcpy(&h_levels, d_levels, 4, hipMemcpyDeviceToHost));
         LBVH_TRY(hipMemcpy(&h_need, d_need, 4, hipMemcpyDeviceToHost)); // record 0 = the root
         tree = DeviceTree();
         tree.nodes4 = std::shared_ptr<void>(d_out4, DeviceFree{device});
@@ -411,13 +767,15 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& tree
         tree.levels = uint32_t(h_levels);
         tree.device = device;
         if (getenv("RTTNW_DEBUG_LOWER"))
-            fprintf(stderr, "[lbvh] %zu leaves -> %u 4-wide records in %zu levels: centroid bounds + allocations %.1f ms, upload %.1f ms, kernels %.1f ms (device %.2f); nothing downloaded\n",
-                    n, n_heads, level_off.size() - 1, t_alloc, t_up - t_alloc, t_kernels - t_up, ms);
+            fprintf(stderr, "[lbvh] %s, %zu leaves -> %u 4-wide records in %zu levels: centroid bounds + allocations %.1f ms, upload %.1f ms, kernels %.1f ms (device %.2f); nothing downloaded\n",
+                    sah ? ("binned SAH, " + std::to_string(sah_levels) + " rounds").c_str() : "Karras hierarchy", n, n_heads, level_off.size() - 1, t_alloc, t_up - t_alloc, t_kernels - t_up, ms);
     }
 done:
     for (void* p : {(void*)d_prims, (void*)d_keys, (void*)d_keys2, (void*)d_order, (void*)d_order2, (void*)d_children, (void*)d_node_parent,
                     (void*)d_done, (void*)d_levels, (void*)d_box, (void*)d_out, (void*)d_out2, (void*)d_pos, d_temp, d_temp2, (void*)d_heads,
-                    (void*)d_count, (void*)d_is_head, (void*)d_rank, (void*)d_need, (void*)d_out4})
+                    (void*)d_count, (void*)d_is_head, (void*)d_rank, (void*)d_need, (void*)d_out4, d_temp3, (void*)d_pa, (void*)d_pb, (void*)d_sa, (void*)d_sb,
+                    (void*)d_slot, (void*)d_list[0], (void*)d_list[1], (void*)d_list[2], (void*)d_list[3], (void*)d_segs, (void*)d_split, (void*)d_bins,
+                    (void*)d_next, (void*)d_flag, (void*)d_scan})
         if (p) (void)hipFree(p);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

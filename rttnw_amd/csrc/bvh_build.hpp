@@ -53,7 +53,8 @@ int device_tree_download(const DeviceTree& tree, Bvh4Node* out4, BvhNode* out2, 
 
 // The HIP implementation (bvh_build.hip); runs on the current device, synchronous.  `kernel_ms` (optional) accumulates the
 // device time of the build kernels + sort + collapse.
-int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, DeviceTree& out, double* kernel_ms, std::string& err);
+// (`sah`: the binned-SAH hierarchy instead of the linear one, RTTNW_BVH_DEVICE_SAH)
+int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, bool sah, DeviceTree& out, double* kernel_ms, std::string& err);
 int device_tree_rebase(DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& err);
 
 } // namespace rt

@@ -197,7 +197,7 @@ int rttnw_scene_commit(rttnw_scene* s) {
     if (s->committed) return RTTNW_OK; // idempotent
     std::string err;
     rt::DeviceBvhApi device_builder;
-    const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
+    const bool on_device = s->bvh_builder != RTTNW_BVH_HOST_SAH;
     if (on_device)
         if (int brc = rt::device_bvh_builder(s, device_builder, err)) return fail(brc, err.c_str());
     const auto t0 = std::chrono::steady_clock::now();
@@ -213,7 +213,7 @@ int rttnw_scene_commit(rttnw_scene* s) {
 
 int rttnw_scene_set_bvh_builder(rttnw_scene* s, uint32_t builder) {
     if (int rc = check_open(s)) return rc;
-    if (builder != RTTNW_BVH_HOST_SAH && builder != RTTNW_BVH_DEVICE_LBVH) return fail(RTTNW_ERR_INVALID, "unknown BVH builder");
+    if (builder != RTTNW_BVH_HOST_SAH && builder != RTTNW_BVH_DEVICE_LBVH && builder != RTTNW_BVH_DEVICE_SAH) return fail(RTTNW_ERR_INVALID, "unknown BVH builder");
     s->bvh_builder = builder;
     return RTTNW_OK;
 }

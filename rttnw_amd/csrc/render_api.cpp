@@ -49,7 +49,7 @@ int device_bvh_builder(::rttnw_scene* s, DeviceBvhApi& out, std::string& err) {
         return RTTNW_ERR_HIP;
     }
     out.build = [s](const std::vector<BuildPrim>& prims, DeviceTree& tree, std::string& e) {
-        return lbvh_build_device_tree(prims, tree, &s->build_kernel_ms, e);
+        return lbvh_build_device_tree(prims, s->bvh_builder == RTTNW_BVH_DEVICE_SAH, tree, &s->build_kernel_ms, e);
     };
     out.rebase = [](DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& e) { return device_tree_rebase(tree, base4, base2, e); };
     return 0;
@@ -125,7 +125,7 @@ int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
             const double t0 = std::min(s->flat.time0, cam->open_time), t1 = std::max(s->flat.time1, cam->close_time);
             std::string err;
             DeviceBvhApi device_builder;
-            const bool on_device = s->bvh_builder == RTTNW_BVH_DEVICE_LBVH;
+            const bool on_device = s->bvh_builder != RTTNW_BVH_HOST_SAH;
             if (on_device)
                 if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
             FlatScene wider;

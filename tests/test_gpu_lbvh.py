@@ -1,8 +1,8 @@
-"""Device-side BVH build: rttnw_scene_set_bvh_builder(RTTNW_BVH_DEVICE_LBVH).
+"""Device-side BVH build: rttnw_scene_set_bvh_builder(RTTNW_BVH_DEVICE_LBVH | RTTNW_BVH_DEVICE_SAH).
 
 The tree only decides WHICH records a ray tests, never what a test returns, and exact ties are resolved by list
-order, so a render through the device-built linear BVH must equal the render through the host SAH tree bit for
-bit — in f64 and in f32.  Plus structural checks of the node records the kernels wrote.
+order, so a render through a device-built tree — the linear BVH or the binned-SAH one — must equal the render through
+the host SAH tree bit for bit, in f64 and in f32.  Plus structural checks of the node records the kernels wrote.
 """
 import ctypes as C
 
@@ -27,14 +27,18 @@ def nodes_of(gpu, sc):
     return util.nodes_of(gpu, sc)
 
 
+DEVICE_BUILDERS = pytest.mark.parametrize("builder", [abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH], ids=["lbvh", "dsah"])
+
+
 @pytest.mark.parametrize("case", SCENES, ids=[c[0] for c in SCENES])
 @pytest.mark.parametrize("precision", [abi.F64, abi.F32], ids=["f64", "f32"])
-def test_lbvh_render_equals_sah_render(gpu, scenes_lib, earth, case, precision):
+@DEVICE_BUILDERS
+def test_lbvh_render_equals_sah_render(gpu, scenes_lib, earth, case, precision, builder):
     name, param, w, h, spp = case
     s_sah, setup = util.build(gpu, scenes_lib, name, earth, param)
-    s_lbvh, _ = util.build(gpu, scenes_lib, name, earth, param, bvh=abi.BVH_DEVICE_LBVH)
+    s_lbvh, _ = util.build(gpu, scenes_lib, name, earth, param, bvh=builder)
     bi = s_lbvh.build_info()
-    assert bi.builder == abi.BVH_DEVICE_LBVH and bi.n_prims == s_sah.build_info().n_prims
+    assert bi.builder == builder and bi.n_prims == s_sah.build_info().n_prims
     cam, p = util.params_for(setup, w, h, spp, precision=precision, seed=5, collect_counters=1)
     lin_a, rgba_a, st_a = render.render_host(s_sah, cam, p)
     lin_b, rgba_b, st_b = render.render_host(s_lbvh, cam, p)
@@ -43,9 +47,10 @@ def test_lbvh_render_equals_sah_render(gpu, scenes_lib, earth, case, precision):
     assert st_a.rays == st_b.rays  # the same paths; node / primitive counts differ with the tree
 
 
-def test_lbvh_structure(gpu, scenes_lib):
-    n_spheres = 5000
-    sc, _ = util.build(gpu, scenes_lib, "spheres_1m", None, n_spheres, bvh=abi.BVH_DEVICE_LBVH)
+@DEVICE_BUILDERS
+@pytest.mark.parametrize("n_spheres", [5000, 70000])
+def test_lbvh_structure(gpu, scenes_lib, builder, n_spheres):
+    sc, _ = util.build(gpu, scenes_lib, "spheres_1m", None, n_spheres, bvh=builder)
     bi = sc.build_info()
     assert bi.device_ms > 0 and bi.n_prims == n_spheres + 1  # + the area light
     nodes, root = nodes_of(gpu, sc)
@@ -77,24 +82,31 @@ def test_lbvh_structure(gpu, scenes_lib):
     leaves4, need, seen4 = util.check_wide_tree(n4, root4)
     assert len(seen4) == len(n4) == bi.n_nodes and len(leaves4) == bi.n_prims
     assert need + 1 == bi.stack_depth and bi.stack_depth <= 3 * ((depth_max + 1) // 2) + 1  # three pending children per wide level at most
+    # the build is deterministic: atomics only ever feed order-independent sums, minima and maxima, and lists whose order nothing depends on
+    sc2, _ = util.build(gpu, scenes_lib, "spheres_1m", None, n_spheres, bvh=builder)
+    nodes2, _ = nodes_of(gpu, sc2)
+    n4b, _ = util.nodes_of(gpu, sc2, wide=True)
+    assert nodes.tobytes() == nodes2.tobytes() and n4.tobytes() == n4b.tobytes()
 
 
-def test_lbvh_small_and_empty_worlds(gpu):
-    # 0 and 1 objects never reach the device builder; 2 objects is its smallest tree
-    for n in (0, 1, 2, 3):
+@DEVICE_BUILDERS
+def test_lbvh_small_and_empty_worlds(gpu, builder):
+    # 0 and 1 objects never reach the device builder; 2 objects is its smallest tree; 64 / 65 straddle the SAH builder's
+    # wave-per-segment limit
+    for n in (0, 1, 2, 3, 64, 65, 130):
         sc = S.Scene(gpu, 1)
-        sc.set_bvh_builder(abi.BVH_DEVICE_LBVH)
+        sc.set_bvh_builder(builder)
         red = sc.lambertian(sc.solid(0.8, 0.2, 0.2))
         world = sc.list()
         for k in range(n):
-            sc.push(world, sc.sphere((2.5 * k, 0.0, -5.0), 1.0, red))
+            sc.push(world, sc.sphere((2.5 * (k % 7), 2.5 * (k // 49), -5.0 - 2.5 * ((k // 7) % 7)), 1.0, red))
         sc.set_world(world)
         sc.commit()
         ref = S.Scene(gpu, 1)
         red = ref.lambertian(ref.solid(0.8, 0.2, 0.2))
         world = ref.list()
         for k in range(n):
-            ref.push(world, ref.sphere((2.5 * k, 0.0, -5.0), 1.0, red))
+            ref.push(world, ref.sphere((2.5 * (k % 7), 2.5 * (k // 49), -5.0 - 2.5 * ((k // 7) % 7)), 1.0, red))
         ref.set_world(world)
         ref.commit()
         cam = abi.CameraDesc()
@@ -114,14 +126,16 @@ def test_builder_choice_is_frozen_by_commit(gpu):
     assert gpu.scene_set_bvh_builder(sc.handle, abi.BVH_DEVICE_LBVH) == -2  # RTTNW_ERR_STATE
     sc2 = S.Scene(gpu, 1)
     assert gpu.scene_set_bvh_builder(sc2.handle, 7) == -1  # RTTNW_ERR_INVALID
+    assert gpu.scene_set_bvh_builder(sc2.handle, abi.BVH_DEVICE_SAH) == 0
 
 
-def test_full_size_config5_invariants(gpu, scenes_lib):
+@DEVICE_BUILDERS
+def test_full_size_config5_invariants(gpu, scenes_lib, builder):
     """BASELINE config 5 at its full size (10^6 spheres, 1024x1024) is beyond the oracle's reference-shaped builder, so
     check size-independent properties: the device-built tree and the host tree render the same image bit for bit,
     a run repeats exactly, and the partition over 8 ranks reassembles to the single-rank image."""
     s_sah, setup = util.build(gpu, scenes_lib, "spheres_1m", None, 0)
-    s_lbvh, _ = util.build(gpu, scenes_lib, "spheres_1m", None, 0, bvh=abi.BVH_DEVICE_LBVH)
+    s_lbvh, _ = util.build(gpu, scenes_lib, "spheres_1m", None, 0, bvh=builder)
     assert s_sah.build_info().n_prims == 1000001 and gpu.debug_scene_nodes(s_lbvh.handle, None, 0, None) == 1000000
     assert 330000 <= s_lbvh.build_info().n_nodes <= 520000                       # 4-wide records: a third to a half of the binary nodes
     cam, p = util.params_for(setup, 1024, 1024, 2, precision=abi.F32, seed=7)

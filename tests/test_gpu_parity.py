@@ -31,7 +31,7 @@ def gpu_render(gpu, sc, cam, p):
     return lin, rgba, st
 
 
-@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH], ids=["sah", "lbvh"])
+@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH], ids=["sah", "lbvh", "dsah"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_T1_f64_vs_golden(gpu, scenes_lib, earth, case, bvh):
     """Both BVH builders against the ORACLE's golden images (the device-built linear BVH meets the oracle directly,
@@ -288,7 +288,7 @@ def test_chunk_schedule_boundaries_and_sample_offsets(gpu, oracle, scenes_lib):
 
 
 @pytest.mark.parametrize("name,n_pairs", [("cornell_box", 120), ("final_scene", 160), ("smoke_cornell_box", 60), ("random_scene", 60)])
-@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH], ids=["sah", "lbvh"])
+@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH], ids=["sah", "lbvh", "dsah"])
 def test_per_bounce_records_equal_oracle(gpu, oracle, scenes_lib, earth, name, n_pairs, bvh):
     """SURVEY section 4's second tier: rttnw_debug_probe_path (one lane walks one sample's path on the DEVICE and dumps
     every world.hit()) against rto_probe_path — t, p, normal, front_face, material and (u, v) of every bounce of 400
@@ -438,7 +438,7 @@ def test_render_multi_equals_single_render(gpu, scenes_lib, earth, precision):
         render.render_multi(sc, cam, p, [gpu.device_count()])                      # no such device
 
 
-@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH], ids=["sah", "lbvh"])
+@pytest.mark.parametrize("bvh", [abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH], ids=["sah", "lbvh", "dsah"])
 @pytest.mark.parametrize("shape", sorted(__import__("graph_shapes").SHAPES))
 def test_graph_shapes_the_trait_objects_allow(gpu, oracle, shape, bvh):
     """Instances inside instances, five wrappers on one object, a medium inside a transformed group, List / BvhTree medium

@@ -18,7 +18,8 @@ d=json.loads(sys.stdin.read())
 print('headline', d['value'], d['roofline']['bound'], d['roofline']['frac'], 'hbm_alg', d['roofline']['hbm_algorithmic']['frac'], 'f32', d['f32_kernels']['value'], 'cpu', d['cpu_baseline']['value'])
 for k in ('cornell_box','spheres_1m'):
     r=d[k]; print(k, r['value'], r['roofline']['bound'], r['roofline']['frac'], '| f32', r['f32_kernels']['value'], r['f32_kernels']['roofline']['bound'], r['f32_kernels']['roofline']['frac'], r['f32_kernels']['roofline'].get('traffic_frac_of_hbm_peak'))"
-python bench.py --workload spheres_1m --bvh lbvh --steps 3 --warmup 1 --cpu-seconds 0 --no-other --precision f32 > $O/bench_spheres_1m_lbvh_f32.json 2>/dev/null
+python bench.py --workload spheres_1m --bvh lbvh --steps 3 --warmup 1 --cpu-seconds 0 --no-other --no-sub --precision f32 > $O/bench_spheres_1m_lbvh_f32.json 2>/dev/null
+python bench.py --workload spheres_1m --bvh dsah --steps 3 --warmup 1 --cpu-seconds 0 --no-other --no-sub --precision f32 > $O/bench_spheres_1m_dsah_f32.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt_f64 -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --no-other --no-sub > $R/$O/kt_f64.log 2>&1

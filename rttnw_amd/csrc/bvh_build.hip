@@ -187,7 +187,7 @@ __global__ void relayout_kernel(const BvhNode* __restrict__ in, const int* __res
 //   * partitions the leaves stably (a scan of the "goes left" flags over all positions), and
 //   * splits every SMALL segment by an exact sweep, one wave per segment: lane i tries "everything up to leaf i's centroid goes
 //     left" on each axis, the wave takes the cheapest candidate.
-constexpr int SAH_BINS = 16;
+constexpr int SAH_BINS = 32; // (as the host builder: 16 bins cost final_scene 2.8 % more node visits)
 constexpr int SAH_SMALL = 64;
 __device__ __forceinline__ uint32_t enc_f(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float dec_f(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e); }

@@ -119,6 +119,35 @@ def test_lbvh_small_and_empty_worlds(gpu, builder):
         assert np.array_equal(a, b), n
 
 
+@DEVICE_BUILDERS
+def test_coincident_and_nested_leaves(gpu, builder):
+    """Leaves the builders cannot separate by centroid: 150 spheres with ONE centre (radii differ: nested shells), beside 40
+    copies of one sphere — more than a wave's worth, so the SAH builder's large-segment path meets an extent of zero on every
+    axis and has to halve by position.  The render must still equal the host tree's (the later list item wins exact ties)."""
+    def world(sc):
+        mats = [sc.lambertian(sc.solid(0.2 + 0.1 * (k % 7), 0.5, 0.9 - 0.1 * (k % 5))) for k in range(6)]
+        glass = sc.dielectric(1.5)
+        w = sc.list()
+        for k in range(150):
+            sc.push(w, sc.sphere((0.0, 0.0, -6.0), 0.5 + 0.01 * k, glass if k % 3 == 0 else mats[k % 6]))
+        for k in range(40):
+            sc.push(w, sc.sphere((4.0, 0.0, -6.0), 1.0, mats[k % 6]))
+        sc.set_world(w)
+        sc.commit()
+    a, b = S.Scene(gpu, 1), S.Scene(gpu, 1)
+    b.set_bvh_builder(builder)
+    world(a); world(b)
+    cam = abi.CameraDesc()
+    cam.lookfrom[:] = (2.0, 0.5, 3.0); cam.lookat[:] = (2.0, 0.0, -6.0); cam.view_up[:] = (0.0, 1.0, 0.0)
+    cam.vertical_fov = 50.0; cam.aspect_ratio = 1.0; cam.aperture = 0.0; cam.focus_distance = 1.0
+    cam.open_time = 0.0; cam.close_time = 1.0
+    for precision in (abi.F64, abi.F32):
+        p = S.make_params(48, 48, 4, background=(0.7, 0.8, 1.0), precision=precision)
+        x, _, _ = render.render_host(a, cam, p)
+        y, _, _ = render.render_host(b, cam, p)
+        assert np.array_equal(x, y) and np.isfinite(x).all() and x.max() > 0
+
+
 def test_builder_choice_is_frozen_by_commit(gpu):
     sc = S.Scene(gpu, 1)
     sc.set_world(sc.list())

@@ -880,6 +880,7 @@ struct Lowering {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         const auto t_start = now();
         lower_textures_materials();
+        const auto t_mats = now();
         if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
         std::vector<Item> top;
         top_items = &top;
@@ -934,7 +935,7 @@ struct Lowering {
         // one sentinel plus the pending children of the instance's tree.  +1 spare.
         fs.stack_depth = top_need + (any_tree ? 1u + inst_need : 0u) + 1u;
         if (timing)
-            fprintf(stderr, "[lower] collect %.1f ms, top tree (%zu items) %.1f ms, 4-wide collapse (%zu -> %zu records) %.1f ms\n", ms(t_start, t_collected),
+            fprintf(stderr, "[lower] textures + materials %.1f ms, collect %.1f ms, top tree (%zu items) %.1f ms, 4-wide collapse (%zu -> %zu records) %.1f ms\n", ms(t_start, t_mats), ms(t_mats, t_collected),
                     top.size(), ms(t_collected, t_built), size_t(fs.total_nodes2()), size_t(fs.total_nodes4()), ms(t_built, now()));
         for (const auto& in : fs.insts) fs.needs_general = fs.needs_general || in.n_ops > FAST_INSTANCE_OPS;
         for (const auto& md : fs.media) fs.needs_general = fs.needs_general || md.b_count > 1 || md.n_outer > 0;

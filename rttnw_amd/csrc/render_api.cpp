@@ -7,6 +7,7 @@
 
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <mutex>
 
 namespace rt {
 
@@ -282,6 +283,7 @@ struct MultiComms { // one communicator set per distinct list of devices, kept f
     std::vector<ncclComm_t> comms;
 };
 static std::vector<MultiComms*> g_comms;
+static std::mutex g_comms_mutex; // (rttnw_render_multi may be called from several host threads, each with its own scene)
 
 static DeviceState* state_on(::rttnw_scene* s, int device, std::string& err) {
     if (s->device && s->device->device == device) return s->device;
@@ -372,6 +374,7 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
     const char* force_env = getenv("RTTNW_MULTI_FORCE_RCCL");
     const bool force_rccl = force_env && force_env[0] == '1';
     if (distinct.size() > 1 || force_rccl) {
+        std::unique_lock<std::mutex> comms_lock(g_comms_mutex);
         if (!g_rccl.load(err)) { set_last_error("render_multi: " + err); return RTTNW_ERR_HIP; }
         MultiComms* mc = nullptr;
         for (MultiComms* c : g_comms)
@@ -385,6 +388,7 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
             g_comms.push_back(mc); // kept for the life of the process: communicator set-up costs ~100 ms; freed by the OS at exit
             if (getenv("RTTNW_DEBUG_MULTI")) fprintf(stderr, "[render_multi] RCCL communicators over %zu device(s)\n", distinct.size());
         }
+        comms_lock.unlock();
         ncclResult_t nr = g_rccl.GroupStart();
         uint32_t n_sent = 0;
         for (uint32_t r = 0; r < ngpu && nr == ncclSuccess; ++r) {

@@ -1,4 +1,7 @@
-// bvh_build.hip — linear BVH on the device: Morton keys -> radix sort -> Karras hierarchy -> bottom-up fit.
+// bvh_build.hip — BVH construction on the device.  Two hierarchies over the same leaves, one 4-wide collapse after either:
+//   * RTTNW_BVH_DEVICE_LBVH: linear BVH — Morton keys -> radix sort -> Karras hierarchy -> bottom-up fit (steps 1-5 below);
+//   * RTTNW_BVH_DEVICE_SAH: the host builder's binned surface-area heuristic as level-synchronous kernels (the "binned SAH on
+//     the device" section further down): slower to build (10.6 against 1.4 ms for 10^6 leaves), renders like the host's tree.
 //
 //   1. morton_kernel   63-bit Morton key of every leaf's centroid (21 bits per axis over the centroid bounds)
 //   2. rocprim::radix_sort_pairs (key, leaf index)

@@ -2,9 +2,9 @@
 //
 // The reference builds its tree on the CPU, recursively, one random axis per level and a full sort per level
 // (BvhTree::from / build, hittable.rs:300-353); the library's default is the host binned-SAH builder of
-// scene_lower.cpp.  This is the alternative for large or frequently rebuilt scenes: a linear BVH (Morton order +
-// Karras 2012 hierarchy + bottom-up box fit) built by HIP kernels, about two orders of magnitude faster to
-// build, somewhat slower to traverse.  Which tree is used never changes a result: the closest hit does not
+// scene_lower.cpp.  These are the alternatives for large or frequently rebuilt scenes, built by HIP kernels: a linear BVH
+// (Morton order + Karras 2012 hierarchy + bottom-up box fit: two orders of magnitude faster to build than the host's, 4-7 %
+// slower to traverse) and the binned-SAH tree (level-synchronous kernels: ten times faster to build, traverses like the host's).  Which tree is used never changes a result: the closest hit does not
 // depend on topology and exact ties are resolved by the records' sequence numbers (rt_types.hpp).
 #pragma once
 #include "rt_types.hpp"

@@ -596,8 +596,7 @@ struct DeviceFree { // frees on the device the buffer lives on
 };
 } // namespace
 
-int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, bool sah, DeviceTree& tree, double* kernel_ms, std::string& err) {
-    const size_t n = prims.size();
+int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centroid_bounds, bool sah, DeviceTree& tree, double* kernel_ms, std::string& err) {
     if (n < 2 || n >= (size_t(1) << 26)) { err = "lbvh_build: needs 2 .. 2^26-1 leaves"; return -1; }
     int rc = 0;
     const auto wall0 = std::chrono::steady_clock::now();
@@ -605,12 +604,16 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, bool sah, Device
     double t_alloc = 0, t_up = 0, t_kernels = 0;
     // centroid bounds on the host (the leaves come from the host anyway)
     float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (const BuildPrim& p : prims)
-        for (int a = 0; a < 3; ++a) {
-            const float c = 0.5f * (p.lo[a] + p.hi[a]);
-            cmin[a] = std::min(cmin[a], c);
-            cmax[a] = std::max(cmax[a], c);
-        }
+    if (centroid_bounds) {
+        for (int a = 0; a < 3; ++a) { cmin[a] = centroid_bounds[a]; cmax[a] = centroid_bounds[3 + a]; }
+    } else {
+        for (size_t i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
+                cmin[a] = std::min(cmin[a], c);
+                cmax[a] = std::max(cmax[a], c);
+            }
+    }
     float scale[3];
     for (int a = 0; a < 3; ++a) {
         const float ext = cmax[a] - cmin[a];
@@ -693,7 +696,7 @@ int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, bool sah, Device
         LBVH_TRY(hipEventCreate(&e0));
         LBVH_TRY(hipEventCreate(&e1));
         t_alloc = wall_ms();
-        LBVH_TRY(hipMemcpy(d_prims, prims.data(), n * sizeof(BuildPrim), hipMemcpyHostToDevice));
+        LBVH_TRY(hipMemcpy(d_prims, prims, n * sizeof(BuildPrim), hipMemcpyHostToDevice));
         t_up = wall_ms();
 
         LBVH_TRY(hipEventRecord(e0, 0));

@@ -43,8 +43,9 @@ struct DeviceTree {
 
 // The device builder as the lowering sees it (scene_lower.cpp is plain C++: it calls through these).
 struct DeviceBvhApi {
-    // build a tree over prims (size >= 2) on the current device
-    std::function<int(const std::vector<BuildPrim>& prims, DeviceTree& out, std::string& err)> build;
+    // build a tree over prims[0, n) (n >= 2) on the current device; centroid_bounds (optional): lo[3], hi[3] of the leaves' box
+    // centres as the builders compute them (0.5f * (lo + hi) in f32) — a caller that walks the leaves anyway saves the builder a pass
+    std::function<int(const BuildPrim* prims, size_t n, const float* centroid_bounds, DeviceTree& out, std::string& err)> build;
     // add base4 to the inner child indices of the tree's 4-wide records (and remember base4 / base2 in the tree)
     std::function<int(DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& err)> rebase;
 };
@@ -54,7 +55,7 @@ int device_tree_download(const DeviceTree& tree, Bvh4Node* out4, BvhNode* out2, 
 // The HIP implementation (bvh_build.hip); runs on the current device, synchronous.  `kernel_ms` (optional) accumulates the
 // device time of the build kernels + sort + collapse.
 // (`sah`: the binned-SAH hierarchy instead of the linear one, RTTNW_BVH_DEVICE_SAH)
-int lbvh_build_device_tree(const std::vector<BuildPrim>& prims, bool sah, DeviceTree& out, double* kernel_ms, std::string& err);
+int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centroid_bounds, bool sah, DeviceTree& out, double* kernel_ms, std::string& err);
 int device_tree_rebase(DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& err);
 
 } // namespace rt

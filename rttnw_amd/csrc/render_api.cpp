@@ -49,8 +49,8 @@ int device_bvh_builder(::rttnw_scene* s, DeviceBvhApi& out, std::string& err) {
         err = "no HIP device available (the device BVH builder has no CPU fallback)";
         return RTTNW_ERR_HIP;
     }
-    out.build = [s](const std::vector<BuildPrim>& prims, DeviceTree& tree, std::string& e) {
-        return lbvh_build_device_tree(prims, s->bvh_builder == RTTNW_BVH_DEVICE_SAH, tree, &s->build_kernel_ms, e);
+    out.build = [s](const BuildPrim* prims, size_t n, const float* centroid_bounds, DeviceTree& tree, std::string& e) {
+        return lbvh_build_device_tree(prims, n, centroid_bounds, s->bvh_builder == RTTNW_BVH_DEVICE_SAH, tree, &s->build_kernel_ms, e);
     };
     out.rebase = [](DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& e) { return device_tree_rebase(tree, base4, base2, e); };
     return 0;

@@ -36,7 +36,7 @@ namespace rt {
 template <typename T> struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    int upload(const std::vector<T>& v) {
+    template <typename A> int upload(const std::vector<T, A>& v) {
         release();
         n = v.size();
         const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);

@@ -139,6 +139,7 @@ struct Item {
     int32_t seq = 0; // position in the reference's depth-first traversal of the world List
     int32_t world_copy = -1; // spheres only: index into Lowering::world_spheres (the record to emit is that world-space copy)
 };
+using ItemVec = RecVec<Item>; // (resize() does not initialise: collect() fills a big flat list's items in parallel)
 // A sphere of a rigidly transformed group, in world space (collect(), "spheres of transformed groups")
 struct WorldSphere { double c[3], r; int32_t home, inst; };
 
@@ -146,7 +147,7 @@ struct Lowering {
     const SceneGraph& g;
     FlatScene& fs;
     std::string& err;
-    std::vector<int32_t> tex_index, mat_index; // graph id -> flat index
+    RecVec<int32_t> tex_index, mat_index; // graph id -> flat index
     int rc = 0;
     const DeviceBvhApi* builder = nullptr; // the device builder, or null: host binned SAH
     size_t max_leaf = 4; // records per leaf of the host SAH build (lower_scene picks it)
@@ -194,10 +195,11 @@ struct Lowering {
     // ---- record emission
     // The records of items[0, n) — one per item, instances excepted — appended to their kinds' arrays in item order, in
     // parallel: idx_out[i] = the record index of item i (an instance's own index for instances).
-    void emit_all(const std::vector<Item>& items, std::vector<uint32_t>& idx_out) {
+    void emit_all(const ItemVec& items, std::vector<uint32_t>& idx_out, bool defer_writes = false) {
         const size_t n = items.size();
         idx_out.resize(n);
         if (n < 16384) {
+            defer_writes = false;
             for (size_t i = 0; i < n; ++i) idx_out[i] = items[i].kind == PRIM_INSTANCE ? uint32_t(items[i].obj) : emit(items[i]);
             return;
         }
@@ -217,14 +219,22 @@ struct Lowering {
             for (int k = 0; k < 4; ++k) start[c][k] += start[c - 1][k];
         fs.spheres.resize(start[n_chunks][0]); fs.sphere_mat.resize(start[n_chunks][0]); fs.sphere_seq.resize(start[n_chunks][0]);
         fs.moving.resize(start[n_chunks][1]); fs.rects.resize(start[n_chunks][2]); fs.boxes.resize(start[n_chunks][3]);
-        parallel_for(n_chunks, 1, [&](size_t a, size_t b) {
+        parallel_for(n_chunks, 1, [&](size_t a, size_t b) { // where every record goes ...
             for (size_t c = a; c < b; ++c) {
                 std::array<uint32_t, 4> at = start[c];
                 for (size_t i = c * grain; i < std::min(n, (c + 1) * grain); ++i) {
                     const Item& it = items[i];
-                    idx_out[i] = it.kind == PRIM_INSTANCE ? uint32_t(it.obj) : emit_at(it, at[it.kind]++);
+                    idx_out[i] = it.kind == PRIM_INSTANCE ? uint32_t(it.obj) : at[it.kind]++;
                 }
             }
+        });
+        if (defer_writes) return; // ... and (write_records(), possibly on another thread beside the device build) the records themselves
+        write_records(items, idx_out);
+    }
+    void write_records(const ItemVec& items, const std::vector<uint32_t>& idx) {
+        parallel_for(items.size(), 8192, [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; ++i)
+                if (items[i].kind != PRIM_INSTANCE) emit_at(items[i], idx[i]);
         });
     }
     uint32_t emit(const Item& it) {
@@ -306,7 +316,7 @@ struct Lowering {
     static constexpr size_t PAR_SPLIT_MIN = 32768; // smallest range whose halves are worth two threads
     static constexpr size_t PAR_SCAN_MIN = 131072; // smallest range whose own passes (bounds, bins) are shared out
 
-    int32_t split(std::vector<Item>& items, size_t lo, size_t hi, uint32_t depth, Box3& out_box) {
+    int32_t split(ItemVec& items, size_t lo, size_t hi, uint32_t depth, Box3& out_box) {
         const size_t n = hi - lo;
         Box3 box, cbox;
         bool same_kind = true;
@@ -425,7 +435,7 @@ struct Lowering {
         return int32_t(mid);
     }
     // child code (node index or leaf bits) of the subtree `id` of split(); rec[i] = the record (or instance) index of item i
-    int32_t number(const std::vector<Item>& items, const std::vector<uint32_t>& rec, int32_t id, uint32_t depth, uint32_t& max_depth) {
+    int32_t number(const ItemVec& items, const std::vector<uint32_t>& rec, int32_t id, uint32_t depth, uint32_t& max_depth) {
         max_depth = std::max(max_depth, depth);
         if (id < 0) {
             const size_t lo = size_t(~id);
@@ -442,7 +452,7 @@ struct Lowering {
         nd.child0 = c0; nd.child1 = c1; nd.pad0 = nd.pad1 = 0;
         return me;
     }
-    int32_t build(std::vector<Item>& items, uint32_t& max_depth, Box3& out_box) {
+    int32_t build(ItemVec& items, uint32_t& max_depth, Box3& out_box) {
         topo.assign(items.size() + 1, Topo());
         leaf_n.assign(items.size() + 1, 0u);
         auto T0 = std::chrono::steady_clock::now();
@@ -463,7 +473,7 @@ struct Lowering {
     // Build a BVH whose root is always a node record.  Returns the root index; `depth_out` = levels of inner nodes on
     // the longest root-to-leaf path (what bounds the traversal stack: one pending sibling per inner level).
     static constexpr int32_t DEVICE_ROOT = 0x40000000; // build_root's result for a tree the device builder made: DEVICE_ROOT + its index in fs.device_trees
-    int32_t build_root(std::vector<Item>& items, uint32_t& depth_out, Box3& box_out) {
+    int32_t build_root(ItemVec& items, uint32_t& depth_out, Box3& box_out) {
         uint32_t md = 0;
         if (items.empty()) {
             BvhNode nd{};
@@ -476,23 +486,43 @@ struct Lowering {
         }
         if (builder && items.size() >= 2) {
             // external builder (device LBVH): every item is a one-record leaf; records are emitted in item order
-            std::vector<BuildPrim> prims(items.size());
+            RecVec<BuildPrim> prims(items.size()); // (not initialised: every leaf is written below)
             std::vector<uint32_t> idx;
-            emit_all(items, idx);
+            const bool beside = items.size() >= 16384; // a big list: its records are written by host threads WHILE the device builds the tree
+            emit_all(items, idx, beside);
+            // the leaves, and in the same pass their bounds and the bounds of their centres (which the builder would otherwise walk
+            // the leaves for once more): min / max merged under a mutex, order-independent
+            float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY}, cb[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            std::mutex merge;
             parallel_for(items.size(), 8192, [&](size_t a, size_t b) {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, c[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 for (size_t i = a; i < b; ++i) {
-                    set_box(prims[i].lo, prims[i].hi, items[i].box);
-                    prims[i].leaf = make_leaf(items[i].kind, 1, idx[i]);
-                    prims[i].pad = 0;
+                    BuildPrim& q = prims[i];
+                    set_box(q.lo, q.hi, items[i].box);
+                    q.leaf = make_leaf(items[i].kind, 1, idx[i]);
+                    q.pad = 0;
+                    for (int k = 0; k < 3; ++k) {
+                        lo[k] = std::min(lo[k], q.lo[k]); hi[k] = std::max(hi[k], q.hi[k]);
+                        const float ck = 0.5f * (q.lo[k] + q.hi[k]);
+                        c[k] = std::min(c[k], ck); c[3 + k] = std::max(c[3 + k], ck);
+                    }
+                }
+                std::lock_guard<std::mutex> g(merge);
+                for (int k = 0; k < 3; ++k) {
+                    blo[k] = std::min(blo[k], lo[k]); bhi[k] = std::max(bhi[k], hi[k]);
+                    cb[k] = std::min(cb[k], c[k]); cb[3 + k] = std::max(cb[3 + k], c[3 + k]);
                 }
             });
-            box_out = Box3();
-            for (const BuildPrim& q : prims) // (the root's box is only used for a wrapping instance's bounds: the f32 boxes cover the f64 ones)
-                for (int k = 0; k < 3; ++k) { box_out.lo[k] = std::min(box_out.lo[k], double(q.lo[k])); box_out.hi[k] = std::max(box_out.hi[k], double(q.hi[k])); }
+            box_out = Box3(); // (the root's box is only used for a wrapping instance's bounds: the f32 boxes cover the f64 ones)
+            for (int k = 0; k < 3; ++k) { box_out.lo[k] = double(blo[k]); box_out.hi[k] = double(bhi[k]); }
             fs.n_prims_in_bvh += uint32_t(items.size());
             DeviceTree tree;
             std::string berr;
-            if (int brc = builder->build(prims, tree, berr)) { fail(brc, berr); depth_out = 1; return 0; }
+            std::thread writer;
+            if (beside) writer = std::thread([&] { write_records(items, idx); });
+            const int brc = builder->build(prims.data(), prims.size(), cb, tree, berr);
+            if (writer.joinable()) writer.join();
+            if (brc) { fail(brc, berr); depth_out = 1; return 0; }
             depth_out = tree.levels;
             fs.device_trees.push_back(std::move(tree));
             return DEVICE_ROOT + int32_t(fs.device_trees.size() - 1); // a handle: the tree's place in the node array is known only at the end (run())
@@ -550,7 +580,7 @@ struct Lowering {
     struct Chain { int32_t n = 0; InstanceRec<double>::Op ops[MAX_INSTANCE_OPS]; };
     int32_t next_seq = 0;
     int nesting = 0; // recursion guard: a list that (transitively) contains itself
-    std::vector<Item>* top_items = nullptr;
+    ItemVec* top_items = nullptr;
     std::vector<WorldSphere> world_spheres;
     bool move_spheres = true;         // RTTNW_WORLD_SPHERES=0 keeps them in their groups' trees (experiments)
 
@@ -582,7 +612,7 @@ struct Lowering {
         return false;
     }
 
-    void collect(int32_t id, std::vector<Item>& out, const Chain& outer) {
+    void collect(int32_t id, ItemVec& out, const Chain& outer) {
         if (rc) return;
         struct Guard { int& n; Guard(int& x) : n(x) { ++n; } ~Guard() { --n; } } guard(nesting);
         if (nesting > 64) { fail(ERR_UNSUPPORTED, "scene graph nests deeper than 64 levels (cycle?)"); return; }
@@ -594,37 +624,35 @@ struct Lowering {
         case GraphObj::CUBE_K: out.push_back({PRIM_BOX, id, bounds_of(o), next_seq++}); break;
         case GraphObj::LIST_K:
         case GraphObj::BVH_K: {
-            // a big flat list of plain leaves (10^6 spheres): its items in parallel — same Items, same sequence numbers
+            // a big flat list of plain leaves (10^6 spheres): its items in parallel — same Items, same sequence numbers.  ONE pass:
+            // the items are written on the assumption that every member is a plain leaf, which the same pass verifies; a list that
+            // holds anything else is walked member by member as usual (what was written is dropped)
             const size_t n = o.items.size();
-            bool flat = n >= 16384;
-            if (flat) {
+            if (n >= 16384) {
+                const size_t base = out.size();
+                const int32_t seq0 = next_seq;
+                out.resize(base + n);
                 std::atomic<bool> all_leaves{true};
                 parallel_for(n, 8192, [&](size_t a, size_t b) {
                     for (size_t i = a; i < b; ++i) {
-                        const GraphObj::Kind k = g.objs[o.items[i]].kind;
-                        if (k != GraphObj::SPHERE_K && k != GraphObj::MOVING_K && k != GraphObj::RECT_K && k != GraphObj::CUBE_K) { all_leaves = false; return; }
+                        const int32_t it = o.items[i];
+                        const GraphObj& q = g.objs[it];
+                        uint32_t kind;
+                        switch (q.kind) {
+                        case GraphObj::SPHERE_K: kind = PRIM_SPHERE; break;
+                        case GraphObj::MOVING_K: kind = PRIM_MOVING_SPHERE; break;
+                        case GraphObj::RECT_K: kind = PRIM_RECT; break;
+                        case GraphObj::CUBE_K: kind = PRIM_BOX; break;
+                        default: all_leaves = false; return;
+                        }
+                        Item item{kind, it, bounds_of(q), seq0 + int32_t(i)};
+                        out[base + i] = item;
                     }
                 });
-                flat = all_leaves;
+                if (all_leaves) { next_seq += int32_t(n); break; }
+                out.resize(base);
             }
-            if (!flat) {
-                for (int32_t it : o.items) collect(it, out, outer);
-                break;
-            }
-            const size_t base = out.size();
-            const int32_t seq0 = next_seq;
-            out.resize(base + n);
-            next_seq += int32_t(n);
-            parallel_for(n, 8192, [&](size_t a, size_t b) {
-                for (size_t i = a; i < b; ++i) {
-                    const int32_t it = o.items[i];
-                    const GraphObj& q = g.objs[it];
-                    const uint32_t kind = q.kind == GraphObj::SPHERE_K ? PRIM_SPHERE : q.kind == GraphObj::MOVING_K ? PRIM_MOVING_SPHERE
-                                          : q.kind == GraphObj::RECT_K ? PRIM_RECT : PRIM_BOX;
-                    Item item{kind, it, bounds_of(q), seq0 + int32_t(i)};
-                    out[base + i] = item;
-                }
-            });
+            for (int32_t it : o.items) collect(it, out, outer);
             break;
         }
         case GraphObj::TRANSLATE_K:
@@ -636,7 +664,7 @@ struct Lowering {
             if (!append_ops(full, own)) return;
             InstanceRec<double> in;
             chain_to_inst(full, in);
-            std::vector<Item> sub;
+            ItemVec sub;
             collect(inner, sub, full);
             if (rc) return;
             // Spheres of transformed groups: Translate and YRotate are rigid (the forward half of YRotate::hit is a proper
@@ -648,7 +676,7 @@ struct Lowering {
             const int32_t inst_index = int32_t(fs.insts.size()); // of the record pushed below
             bool moved = false;
             if (move_spheres) {
-                std::vector<Item> keep;
+                ItemVec keep;
                 for (const Item& it : sub) {
                     // (the copy's material slot holds where its record is made: 20 bits of sphere index, 9 of chain index)
                     if (it.kind != PRIM_SPHERE || inst_index > MAT_HOME_INST_MAX || fs.spheres.size() >= MAT_HOME_SPHERE_MAX) { keep.push_back(it); continue; }
@@ -734,13 +762,14 @@ struct Lowering {
         // Texture and material records in graph-id order.  Scenes give every sphere its own material (and colour: 3 x 10^6 graph
         // objects for spheres_1m), so both passes run in parallel over id chunks: count, prefix, fill.
         const size_t n_obj = g.objs.size(), grain = 16384, n_chunks = (n_obj + grain - 1) / grain;
-        tex_index.assign(n_obj, -1);
-        mat_index.assign(n_obj, -1);
+        tex_index.resize(n_obj); // (not initialised by resize: the counting pass below writes the -1s, in parallel)
+        mat_index.resize(n_obj);
         std::vector<uint32_t> tex_start(n_chunks + 1, 0), mat_start(n_chunks + 1, 0);
         parallel_for(n_chunks, 1, [&](size_t ca, size_t cb) {
             for (size_t c = ca; c < cb; ++c) {
                 uint32_t nt = 0, nm = 0;
                 for (size_t id = c * grain; id < std::min(n_obj, (c + 1) * grain); ++id) {
+                    tex_index[id] = -1; mat_index[id] = -1;
                     const GraphObj::Kind k = g.objs[id].kind;
                     nt += k <= GraphObj::TEX_IMAGE_K;
                     nm += k == GraphObj::MAT_K;
@@ -882,7 +911,7 @@ struct Lowering {
         lower_textures_materials();
         const auto t_mats = now();
         if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
-        std::vector<Item> top;
+        ItemVec top;
         top_items = &top;
         collect(g.world, top, Chain{});
         if (rc) return rc;

@@ -7,6 +7,8 @@
 
 #include <cstdint>
 #include <string>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace rt {
@@ -37,6 +39,18 @@ struct SceneGraph {
 };
 
 // ---------------------------------------------------------------- lowered scene (f64 master copy)
+// A vector whose resize() leaves the new elements UNINITIALISED: the big record arrays (10^6 spheres, materials, items) are sized
+// once and then filled by host threads in parallel; value-initialising them first is a sequential pass over hundreds of
+// megabytes of fresh pages (20-30 ms of a 10^6-sphere commit).  Element types are trivially copyable and destructible.
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U>&) noexcept {}
+    template <typename U> void construct(U*) noexcept {} // resize(): nothing — the caller writes every element
+    template <typename U, typename A0, typename... A> void construct(U* p, A0&& a0, A&&... a) { ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+template <typename T> using RecVec = std::vector<T, NoInitAlloc<T>>;
+
 struct FlatScene {
     std::vector<BvhNode> nodes;   // the builders' binary trees (kept for inspection: rttnw_debug_scene_nodes); not uploaded
     std::vector<Bvh4Node> nodes4; // what the kernels walk: the same trees collapsed to 4-wide records
@@ -49,18 +63,18 @@ struct FlatScene {
     uint32_t n_host4 = 0, n_host2 = 0;
     uint32_t total_nodes4() const { uint32_t n = n_host4; for (const auto& t : device_trees) n += t.count4; return n; }
     uint32_t total_nodes2() const { uint32_t n = n_host2; for (const auto& t : device_trees) n += t.count2; return n; }
-    std::vector<SphereRec<double>> spheres;
-    std::vector<int32_t> sphere_mat;
-    std::vector<int32_t> sphere_seq;
-    std::vector<MovingSphereRec<double>> moving;
-    std::vector<RectRec<double>> rects;
-    std::vector<BoxRec<double>> boxes;
+    RecVec<SphereRec<double>> spheres;
+    RecVec<int32_t> sphere_mat;
+    RecVec<int32_t> sphere_seq;
+    RecVec<MovingSphereRec<double>> moving;
+    RecVec<RectRec<double>> rects;
+    RecVec<BoxRec<double>> boxes;
     std::vector<InstanceRec<double>> insts;
     std::vector<MediumRec<double>> media;
     std::vector<int32_t> medium_refs; // boundary primitives of the media (MediumRec::b_first / b_count)
     double time0 = 0.0, time1 = 1.0;  // shutter interval the moving spheres' boxes were built for (BvhTree::from_time, hittable.rs:261)
-    std::vector<MaterialRec<double>> mats;
-    std::vector<TextureRec<double>> texs;
+    RecVec<MaterialRec<double>> mats;
+    RecVec<TextureRec<double>> texs;
     std::vector<ImageRec> images;
     std::vector<uint32_t> texels;
     std::vector<double> perlin_vec;   // [n][256][3]

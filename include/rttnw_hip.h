@@ -136,7 +136,7 @@ int rttnw_scene_set_world(rttnw_scene* s, rttnw_id world_list);
  *                          1.4 ms for 10^6 leaves (commit 50 ms), 4-7 % slower traversal; needs a device at commit (no CPU fallback)
  *   RTTNW_BVH_DEVICE_SAH   the binned-SAH build as level-synchronous HIP kernels (binned planes for segments of more than 64
  *                          leaves, an exact sweep by one wave for smaller ones): the host builder's traversal speed at a
- *                          tenth of its build time (11 ms for 10^6 leaves, commit 65 ms); needs a device at commit
+ *                          tenth of its build time (8.5 ms for 10^6 leaves, commit 63 ms); needs a device at commit
  * Images do not depend on the choice: the closest hit is topology independent and exact ties are resolved by
  * list order (tests/test_gpu_lbvh.py). */
 #define RTTNW_BVH_HOST_SAH 0u

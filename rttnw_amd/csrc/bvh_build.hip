@@ -218,8 +218,8 @@ __global__ void sah_bins_init_kernel(SahBin* __restrict__ bins, int n_bins) {
 // seg[i]: the large segment (node) position i belongs to, or < 0 (a small segment's, or finished).  The positions of a
 // segment are contiguous, so a block of 256 positions (the top levels) or a wave of 64 (segments of a few hundred leaves) mostly
 // lies in ONE segment: its leaves are binned in LDS — the block's bins, or the wave's own — and only the bins they touched
-// go out as global atomics (a tenth of the atomics of the direct form for segments of 65-1000 leaves: 1.8 -> 0.3 ms per level
-// of 10^6 leaves); a wave that straddles segments bins straight into global memory.
+// go out as global atomics (a tenth of the atomics of binning straight into global memory for segments of 65-1000 leaves: 1.8 ->
+// 0.3 ms per level of 10^6 leaves).
 constexpr int SAH_BIN_WORDS = 3 * SAH_BINS * 13;
 __device__ __forceinline__ bool sah_word_is_min(int w) { return (w >= 1 && w <= 3) || (w >= 7 && w <= 9); } // lo / clo: atomicMin
 __device__ __forceinline__ void sah_bins_clear(uint32_t* b, int lane, int lanes) {
@@ -241,33 +241,35 @@ template <typename P> __device__ __forceinline__ void sah_bin_add(P q, const Bui
 }
 __global__ __launch_bounds__(256) void sah_bin_kernel(const BuildPrim* __restrict__ prims, const int* __restrict__ seg, int n, const SahSeg* __restrict__ segs,
                                                        const int* __restrict__ slot_of, SahBin* __restrict__ bins) {
+    // a large segment has more than 64 leaves, so the 64 positions of a wave belong to at most TWO large segments (and to small or
+    // finished ones, which are not binned): two sets of bins per wave serve every case without a global atomic per leaf
     __shared__ uint32_t block_bins[SAH_BIN_WORDS];
-    __shared__ uint32_t wave_bins[4][SAH_BIN_WORDS];
+    __shared__ uint32_t wave_bins[4][2][SAH_BIN_WORDS];
     const int i = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int s = i < n ? seg[i] : -1;
     const int b0 = blockIdx.x * blockDim.x, b1 = b0 + int(blockDim.x) - 1;
     const int bf = seg[min(n - 1, b0)], bl = seg[min(n - 1, b1)];
     const bool block_uniform = bf >= 0 && bf == bl && b1 < n; // (the same in every thread)
-    const int wf = __shfl(s, 0, 64), wl = __shfl(s, 63, 64);
-    const bool wave_uniform = !block_uniform && wf >= 0 && wf == wl;
+    // the wave's (up to) two large segments: that of its first binned lane, and that of its last
+    const unsigned long long act = __ballot(s >= 0);
+    const int sa = act ? __shfl(s, __ffsll((long long)act) - 1, 64) : -1, sb = act ? __shfl(s, 63 - __clzll((long long)act), 64) : -1;
     if (block_uniform) sah_bins_clear(block_bins, threadIdx.x, blockDim.x);
-    else if (wave_uniform) sah_bins_clear(wave_bins[wib], lane, 64);
+    else if (act) { sah_bins_clear(wave_bins[wib][0], lane, 64); if (sb != sa) sah_bins_clear(wave_bins[wib][1], lane, 64); }
     __syncthreads();
     if (s >= 0) {
         const BuildPrim p = prims[i];
         const SahSeg sg = segs[s];
         float c[3];
         for (int a = 0; a < 3; ++a) c[a] = 0.5f * (p.lo[a] + p.hi[a]);
-        for (int a = 0; a < 3; ++a) {
-            const int b = sah_bin_of(c[a], sg.clo[a], sg.chi[a]);
-            if (block_uniform) sah_bin_add(block_bins + (a * SAH_BINS + b) * 13, p, c);
-            else if (wave_uniform) sah_bin_add(wave_bins[wib] + (a * SAH_BINS + b) * 13, p, c);
-            else sah_bin_add(reinterpret_cast<uint32_t*>(bins + (size_t(slot_of[s]) * 3 + a) * SAH_BINS + b), p, c);
-        }
+        uint32_t* mine = block_uniform ? block_bins : wave_bins[wib][s == sa ? 0 : 1];
+        for (int a = 0; a < 3; ++a) sah_bin_add(mine + (a * SAH_BINS + sah_bin_of(c[a], sg.clo[a], sg.chi[a])) * 13, p, c);
     }
     __syncthreads();
     if (block_uniform) sah_bins_flush(block_bins, reinterpret_cast<uint32_t*>(bins + size_t(slot_of[bf]) * 3 * SAH_BINS), threadIdx.x, blockDim.x);
-    else if (wave_uniform) sah_bins_flush(wave_bins[wib], reinterpret_cast<uint32_t*>(bins + size_t(slot_of[wf]) * 3 * SAH_BINS), lane, 64);
+    else if (act) {
+        sah_bins_flush(wave_bins[wib][0], reinterpret_cast<uint32_t*>(bins + size_t(slot_of[sa]) * 3 * SAH_BINS), lane, 64);
+        if (sb != sa) sah_bins_flush(wave_bins[wib][1], reinterpret_cast<uint32_t*>(bins + size_t(slot_of[sb]) * 3 * SAH_BINS), lane, 64);
+    }
 }
 struct SahLists { int n_large, n_small; }; // the NEXT level's segment counts (appended to with atomics)
 __device__ __forceinline__ void sah_make_child(int node, int begin, int count, const float* clo, const float* chi, SahSeg* __restrict__ segs,

@@ -176,7 +176,8 @@ typedef struct rttnw_params {
                             ~1/32 of the samples as single-sample chunks so that a render ends on short items).  The
                             per-pixel sum is ONE chain of chunk sums added in chunk order — a function of spp and
                             spp_chunk alone: not of the image size, the number of GPUs, or how the library splits a
-                            long render into launches to keep its chunk-sum workspace within 4 GiB per GPU. */
+                            long render into launches to keep its chunk-sum workspace within a twelfth of the GPU's memory
+                            (4 .. 24 GiB; RTTNW_CHUNK_SUM_BUDGET=<bytes> overrides). */
     uint32_t tile_rank;  /* this GPU's rank in the tile partition (0 for a single GPU) */
     uint32_t tile_world; /* number of GPUs sharing the framebuffer (>= 1) */
     uint32_t collect_counters; /* 1: run the counting kernel variant and fill rttnw_stats (2: plus per-record-kind timing, 3: plus walk-length histograms; debugging) */

@@ -77,6 +77,7 @@ int device_state_create(DeviceState*& out, std::string& err) {
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, d->device);
     if (e != hipSuccess) { err = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); device_release(d); return RTTNW_ERR_HIP; }
     d->num_cus = prop.multiProcessorCount;
+    d->chunk_budget = std::min<uint64_t>(24ull << 30, std::max<uint64_t>(4ull << 30, uint64_t(prop.totalGlobalMem) / 12));
     e = hipMalloc((void**)&d->job_counter, sizeof(unsigned long long) + sizeof(DeviceCounters));
     if (e == hipSuccess) e = hipEventCreate(&d->ev0);
     if (e == hipSuccess) e = hipEventCreate(&d->ev1);

@@ -175,6 +175,7 @@ template <typename R> struct DeviceScene {
 struct DeviceState {
     int device = -1;
     int num_cus = 0;
+    uint64_t chunk_budget = 0; // bytes of chunk sums a launch may hold on this device (rt_types.hpp launch_chunks): total HBM / 12, 4 .. 24 GiB
     DeviceScene<float> s32;
     DeviceScene<double> s64;
     // workspace, grown on demand and kept

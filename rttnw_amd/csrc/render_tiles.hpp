@@ -28,11 +28,23 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     rc.sample_begin = p->sample_begin;
     rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
     // The render's chunk schedule (a function of spp alone) and how many of its chunks one launch traces (rt_types.hpp
-    // launch_chunks: the chunk sums of a launch stay within the 1 GB workspace; the resolve step continues every pixel's
+    // launch_chunks: the chunk sums of a launch stay within the device's budget; the resolve step continues every pixel's
     // chain, so the image does not depend on the split).
     plan_chunks(rc, p->spp, p->spp_chunk);
     const uint32_t total_chunks = rc.n_chunks;
-    const uint32_t per_launch = launch_chunks(uint64_t(rc.my_tiles) * 64, 3 * sizeof(R), total_chunks);
+    // (if the device cannot give the workspace — other tenants of its memory — the budget is halved, down to 1 GiB: more launches, same image)
+    uint32_t per_launch = 0;
+    for (uint64_t budget = d->chunk_budget;; budget /= 2) {
+        per_launch = launch_chunks(uint64_t(rc.my_tiles) * 64, 3 * sizeof(R), total_chunks, budget);
+        const size_t want = std::max<size_t>(size_t(rc.my_tiles) * 64 * std::min(per_launch, total_chunks), 1) * 3 * sizeof(R);
+        if (d->partial_bytes >= want && d->partial) break;
+        if (d->partial) { (void)hipFree(d->partial); d->partial = nullptr; d->partial_bytes = 0; }
+        const hipError_t e = hipMalloc(&d->partial, std::max<size_t>(want, 16));
+        if (e == hipSuccess) { d->partial_bytes = want; break; }
+        (void)hipGetLastError(); // clear the sticky out-of-memory
+        d->partial = nullptr;
+        if (budget <= (1ull << 30) || getenv("RTTNW_CHUNK_SUM_BUDGET")) { set_last_error(std::string("render: no memory for the chunk sums: ") + hipGetErrorString(e)); return RTTNW_ERR_HIP; }
+    }
 
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,

@@ -239,30 +239,33 @@ inline void plan_chunks(RenderConsts& rc, uint32_t spp, uint32_t user_chunk) {
     rc.n_chunks = rc.n_main + (spp - rc.n_main * 4u);
 }
 // Launches.  The chunk sums wait in a workspace until the resolve step has added them to the running sums; a rank keeps
-// at most CHUNK_SUM_BUDGET bytes of them, so a long render is traced in LAUNCHES over consecutive chunk ranges, each
-// followed by its resolve step, of near-equal size and a multiple of the 16 chunks a job group spans (job_decode).
-// Because the resolve step CONTINUES the pixel's chain, the image does not depend on the split: any budget renders bit
-// for bit the same image (round 2 had "passes" with their own schedules and up to 16 GB of sums).
-// Why 4 GiB and not less: a launch ends with its lanes running dry one by one — a wave waits for the longest of its 64
-// last jobs, and a job is 4 samples x ~6.5 bounces x ~115 us per bounce round of a wave that shares its SIMD with three
-// others — about 10 ms per boundary on final_scene.  Measured with a 1 GiB workspace (5 launches of the headline frame):
-// f64 1139 against 1250 Msamples/s, f32 1563 against 1642.  At 4 GiB the headline frame (4.2 GB of f64 sums) is one
-// launch, spp 5000 six of ~430 ms, and one rank's share of 1600 x 1600 x 10000 five.
-constexpr uint64_t CHUNK_SUM_BUDGET = 4ull << 30; // bytes of chunk sums a rank holds at once (1.4 % of its HBM)
-// RTTNW_CHUNK_SUM_BUDGET=<bytes> overrides it (tests: many launches on small images; the image must not change)
-inline uint64_t chunk_sum_budget() {
+// at most a BUDGET of them, so a render beyond it is traced in LAUNCHES over consecutive chunk ranges, each followed by its
+// resolve step, of near-equal size and a multiple of the 16 chunks a job group spans (job_decode).  Because the resolve step
+// CONTINUES the pixel's chain, the image does not depend on the split: any budget renders bit for bit the same image (round 2
+// had "passes" with their own schedules).
+// The budget is a pure speed / memory knob, and launches cost: a launch ends with its lanes running dry one by one — a lane takes
+// no new job when the launch has none left, so every wave spends its last ~26 bounce rounds with fewer and fewer live lanes —
+// about 10 ms per boundary on final_scene (five launches of the headline frame: f64 1139 against 1250 Msamples/s; two launches
+// in flight on two streams do not help: the next kernel's workgroups take the free CUs but do not refill those lanes).  So the
+// budget follows the memory the device has (render_common.hpp device_chunk_budget: a twelfth of its HBM, 4 .. 24 GiB — 24 GiB on
+// an MI355X): every BASELINE configuration is ONE launch (800 x 800 spp 5000 and a rank's share of 1600 x 1600 spp 10000 hold
+// 19.6 GiB of f64 sums: 2.5 % faster than six launches at 4 GiB), the whole 1600 x 1600 x 10000 frame on one GPU seven.
+// CHUNK_SUM_BUDGET is the fallback where no device is asked (the host test build); RTTNW_CHUNK_SUM_BUDGET=<bytes> overrides either
+// (tests: many launches on small images; a caller who wants the memory back).
+constexpr uint64_t CHUNK_SUM_BUDGET = 4ull << 30;
+inline uint64_t chunk_sum_budget(uint64_t device_budget = 0) {
 #if !defined(__HIP_DEVICE_COMPILE__)
     if (const char* e = getenv("RTTNW_CHUNK_SUM_BUDGET")) {
         const unsigned long long v = strtoull(e, nullptr, 10);
         if (v) return v;
     }
 #endif
-    return CHUNK_SUM_BUDGET;
+    return device_budget ? device_budget : CHUNK_SUM_BUDGET;
 }
-inline uint32_t launch_chunks(uint64_t rank_tile_pixels, uint64_t bytes_per_sum, uint32_t total_chunks) {
+inline uint32_t launch_chunks(uint64_t rank_tile_pixels, uint64_t bytes_per_sum, uint32_t total_chunks, uint64_t device_budget = 0) {
     if (total_chunks <= 1) return 1;
     const uint64_t per_chunk = (rank_tile_pixels ? rank_tile_pixels : 1) * (bytes_per_sum ? bytes_per_sum : 1);
-    uint64_t k = chunk_sum_budget() / per_chunk;
+    uint64_t k = chunk_sum_budget(device_budget) / per_chunk;
     // job indices are 32-bit (a launch has ceil(K / 16) * 16 * rank_tile_pixels of them)
     const uint64_t by_index = ((1ull << 32) - 1) / (rank_tile_pixels ? rank_tile_pixels : 1);
     if (by_index < 32) k = 1; else if (k > by_index - 16) k = by_index - 16;

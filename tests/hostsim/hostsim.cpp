@@ -272,13 +272,14 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
 }
 // Chunk schedule and launch split of a render (rt_types.hpp plan_chunks / launch_chunks + rt_core.hpp plan_jobs) as a rank that
 // owns rank_tiles 8x8 tiles sees it: out = {spp_chunk, n_main, n_chunks of the whole render, chunks per launch, launches, n_jobs
-// of the first launch}; returns 0, or -1 when the job count of a launch does not fit.
-int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t rank_tiles, uint32_t bytes_per_sum, uint32_t* out) {
+// of the first launch}; device_budget: the device's chunk-sum budget in bytes (render_common.hpp DeviceState::chunk_budget), 0 = the
+// fallback constant; returns 0, or -1 when the job count of a launch does not fit.
+int hostsim_plan(uint32_t spp, uint32_t user_chunk, uint32_t rank_tiles, uint32_t bytes_per_sum, uint64_t device_budget, uint32_t* out) {
     RenderConsts rc{};
     rc.my_tiles = rank_tiles;
     rc.spp = spp;
     plan_chunks(rc, spp, user_chunk);
-    const uint32_t total = rc.n_chunks, per_launch = launch_chunks(uint64_t(rank_tiles) * 64, bytes_per_sum, total);
+    const uint32_t total = rc.n_chunks, per_launch = launch_chunks(uint64_t(rank_tiles) * 64, bytes_per_sum, total, device_budget);
     out[0] = rc.spp_chunk; out[1] = rc.n_main; out[2] = total; out[3] = per_launch; out[4] = (total + per_launch - 1) / per_launch;
     rc.n_chunks = std::min(per_launch, total);
     const bool ok = plan_jobs(rc);

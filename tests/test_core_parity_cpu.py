@@ -163,18 +163,18 @@ def test_chunk_schedule_and_launch_split(hostsim):
     """plan_chunks / launch_chunks / plan_jobs (rt_types.hpp) for small, ordinary and very large renders: the chunks partition
     [0, spp) exactly and end on single-sample chunks, the schedule depends on spp ALONE (not on the image or on how many tiles
     a rank owns — so the per-pixel chain, hence the image, is the same for any tile_world), the chunk sums of one launch stay
-    within the 4 GiB workspace, job indices of a launch below 2^32, and a launch takes whole job groups (16 chunks) wherever
+    within the budget (the 4 GiB fallback, a device's, a shrunk one), job indices of a launch below 2^32, and a launch takes whole job groups (16 chunks) wherever
     the budget allows one."""
     out = (C.c_uint32 * 6)()
-    budget = 4 * 2**30
+    hostsim.lib.hostsim_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32)]
     cases = [(1, 1), (5, 10), (31, 10), (32, 10), (33, 10), (1000, 10000), (5000, 10000), (8000, 1250), (10000, 5000),
              (10000, 40000), (100000, 40000), (7, 40000), (1000000, 160000), (1000, 4000000)]
     for spp, tiles in cases:
         for bytes_per_sum in (12, 24):
             schedules = set()
-            for world in (1, 2, 3, 4, 8):
+            for world, budget in ((1, 4 * 2**30), (2, 24 * 2**30), (3, 4 * 2**30), (4, 2**30), (8, 24 * 2**30)):  # (the fallback, an MI355X's, a shrunk one)
                 my_tiles = -(-tiles // world)
-                assert hostsim.lib.hostsim_plan(spp, 0, my_tiles, bytes_per_sum, out) == 0, (spp, tiles, world)
+                assert hostsim.lib.hostsim_plan(spp, 0, my_tiles, bytes_per_sum, 0 if budget == 4 * 2**30 else budget, out) == 0, (spp, tiles, world)
                 chunk, n_main, n_chunks, per_launch, launches, n_jobs = list(out)
                 schedules.add((chunk, n_main, n_chunks))
                 assert launches == -(-n_chunks // per_launch) and 1 <= per_launch <= n_chunks
@@ -184,13 +184,18 @@ def test_chunk_schedule_and_launch_split(hostsim):
             assert len(schedules) == 1, (spp, tiles, schedules)
             assert chunk == 4 and n_main * 4 + (n_chunks - n_main) == spp, (spp, list(out))
             assert n_chunks - n_main >= min(spp, max(1, spp // 32))                  # always tapered
-    assert hostsim.lib.hostsim_plan(40, 7, 100, 12, out) == 0 and list(out)[:3] == [7, 6, 6]   # explicit chunking is uniform
-    # BASELINE configs: the headline frame (800x800 spp 1000) is ONE launch in f64 (4.2 GB of sums) and f32; spp 5000 in f64: six
-    # launches of 240 chunks; 1600x1600 spp 10000 in f64: one rank of 8 six launches, the whole frame on one GPU 43 of 64 chunks
-    assert hostsim.lib.hostsim_plan(1000, 0, 10000, 24, out) == 0 and list(out)[2:5] == [274, 274, 1]
-    assert hostsim.lib.hostsim_plan(5000, 0, 10000, 24, out) == 0 and list(out)[3:5] == [240, 6]
-    assert hostsim.lib.hostsim_plan(10000, 0, 5000, 24, out) == 0 and list(out)[3:5] == [464, 6]
-    assert hostsim.lib.hostsim_plan(10000, 0, 40000, 24, out) == 0 and list(out)[3:5] == [64, 43]
+    assert hostsim.lib.hostsim_plan(40, 7, 100, 12, 0, out) == 0 and list(out)[:3] == [7, 6, 6]   # explicit chunking is uniform
+    # BASELINE configs in f64.  With the fallback budget of 4 GiB: the headline frame (800x800 spp 1000, 4.2 GB of sums) is ONE launch,
+    # spp 5000 six launches of 240 chunks, one rank of 8 of 1600x1600 spp 10000 six, the whole frame on one GPU 43 of 64 chunks.
+    assert hostsim.lib.hostsim_plan(1000, 0, 10000, 24, 0, out) == 0 and list(out)[2:5] == [274, 274, 1]
+    assert hostsim.lib.hostsim_plan(5000, 0, 10000, 24, 0, out) == 0 and list(out)[3:5] == [240, 6]
+    assert hostsim.lib.hostsim_plan(10000, 0, 5000, 24, 0, out) == 0 and list(out)[3:5] == [464, 6]
+    assert hostsim.lib.hostsim_plan(10000, 0, 40000, 24, 0, out) == 0 and list(out)[3:5] == [64, 43]
+    # With an MI355X's 24 GiB (a twelfth of its HBM): every one of them is ONE launch but the whole 1600x1600 frame on one GPU (seven)
+    mi355x = 24 * 2**30
+    assert hostsim.lib.hostsim_plan(5000, 0, 10000, 24, mi355x, out) == 0 and list(out)[3:5] == [1367, 1]
+    assert hostsim.lib.hostsim_plan(10000, 0, 5000, 24, mi355x, out) == 0 and list(out)[3:5] == [2734, 1]
+    assert hostsim.lib.hostsim_plan(10000, 0, 40000, 24, mi355x, out) == 0 and list(out)[4] == 7
 
 
 def test_core_chain_equals_oracle(hostsim, oracle, scenes_lib):

@@ -655,28 +655,30 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
     uint32_t n_heads = 0, h_need = 0;
     {
         LBVH_TRY(hipGetDevice(&device));
+        // both hierarchies: the leaves, the pre-ordered binary records, the collapse's arrays
         LBVH_TRY(hipMalloc((void**)&d_prims, n * sizeof(BuildPrim)));
-        LBVH_TRY(hipMalloc((void**)&d_keys, n * 8));
-        LBVH_TRY(hipMalloc((void**)&d_keys2, n * 8));
-        LBVH_TRY(hipMalloc((void**)&d_order, n * 4));
-        LBVH_TRY(hipMalloc((void**)&d_order2, n * 4));
-        LBVH_TRY(hipMalloc((void**)&d_children, (n - 1) * sizeof(int2)));
-        LBVH_TRY(hipMalloc((void**)&d_node_parent, (n - 1) * 4));
-        LBVH_TRY(hipMalloc((void**)&d_done, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_levels, (n - 1) * 4));
-        LBVH_TRY(hipMalloc((void**)&d_box, (n - 1) * sizeof(NodeBox)));
-        LBVH_TRY(hipMalloc((void**)&d_out, (n - 1) * sizeof(BvhNode)));
         LBVH_TRY(hipMalloc((void**)&d_out2, (n - 1) * sizeof(BvhNode)));
-        LBVH_TRY(hipMalloc((void**)&d_pos, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_heads, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_count, 4));
         LBVH_TRY(hipMalloc((void**)&d_is_head, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_rank, (n - 1) * 4));
-        LBVH_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 63, hipStream_t(0)));
-        LBVH_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
         LBVH_TRY(rocprim::exclusive_scan(nullptr, temp2_bytes, d_is_head, d_rank, 0u, size_t(n_inner), rocprim::plus<uint32_t>(), hipStream_t(0)));
         LBVH_TRY(hipMalloc(&d_temp2, std::max<size_t>(temp2_bytes, 16)));
-        if (sah) {
+        if (!sah) {
+            LBVH_TRY(hipMalloc((void**)&d_keys, n * 8));
+            LBVH_TRY(hipMalloc((void**)&d_keys2, n * 8));
+            LBVH_TRY(hipMalloc((void**)&d_order, n * 4));
+            LBVH_TRY(hipMalloc((void**)&d_order2, n * 4));
+            LBVH_TRY(hipMalloc((void**)&d_children, (n - 1) * sizeof(int2)));
+            LBVH_TRY(hipMalloc((void**)&d_node_parent, (n - 1) * 4));
+            LBVH_TRY(hipMalloc((void**)&d_done, (n - 1) * 4));
+            LBVH_TRY(hipMalloc((void**)&d_box, (n - 1) * sizeof(NodeBox)));
+            LBVH_TRY(hipMalloc((void**)&d_out, (n - 1) * sizeof(BvhNode)));
+            LBVH_TRY(hipMalloc((void**)&d_pos, (n - 1) * 4));
+            LBVH_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, d_keys, d_keys2, d_order, d_order2, n, 0, 63, hipStream_t(0)));
+            LBVH_TRY(hipMalloc(&d_temp, std::max<size_t>(temp_bytes, 16)));
+        } else {
             LBVH_TRY(hipMalloc((void**)&d_pa, n * sizeof(BuildPrim)));
             LBVH_TRY(hipMalloc((void**)&d_pb, n * sizeof(BuildPrim)));
             LBVH_TRY(hipMalloc((void**)&d_sa, n * 4));

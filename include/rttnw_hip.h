@@ -131,12 +131,12 @@ rttnw_id rttnw_constant_medium(rttnw_scene* s, rttnw_id boundary, double density
 int rttnw_scene_set_world(rttnw_scene* s, rttnw_id world_list);
 /* Which builder `rttnw_scene_commit` uses for the flat BVHs (before commit; default RTTNW_BVH_HOST_SAH).  Replaces the
  * reference's BvhTree::from / build (hittable.rs:300-353: recursive, random axis per level, full sort per level).
- *   RTTNW_BVH_HOST_SAH     binned surface-area-heuristic build on the host (parallel): best traversal, ~0.1 s for 10^6 leaves
+ *   RTTNW_BVH_HOST_SAH     binned surface-area-heuristic build on the host (parallel): best traversal, 0.1 s for 10^6 leaves (commit 165 ms)
  *   RTTNW_BVH_DEVICE_LBVH  linear BVH built by HIP kernels (Morton order, Karras hierarchy, bottom-up fit):
- *                          1.4 ms for 10^6 leaves (commit 50 ms), 4-7 % slower traversal; needs a device at commit (no CPU fallback)
+ *                          1.4 ms for 10^6 leaves (commit 35 ms), 4-7 % slower traversal; needs a device at commit (no CPU fallback)
  *   RTTNW_BVH_DEVICE_SAH   the binned-SAH build as level-synchronous HIP kernels (binned planes for segments of more than 64
  *                          leaves, an exact sweep by one wave for smaller ones): the host builder's traversal speed at a
- *                          tenth of its build time (8.5 ms for 10^6 leaves, commit 63 ms); needs a device at commit
+ *                          tenth of its build time (8.5 ms for 10^6 leaves, commit 43 ms); needs a device at commit
  * Images do not depend on the choice: the closest hit is topology independent and exact ties are resolved by
  * list order (tests/test_gpu_lbvh.py). */
 #define RTTNW_BVH_HOST_SAH 0u

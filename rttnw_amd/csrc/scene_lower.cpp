@@ -22,6 +22,9 @@
 #include <atomic>
 #include <mutex>
 #include <thread>
+#include <sys/mman.h>
+#include <cstdlib>
+#include <new>
 
 namespace rt {
 
@@ -86,6 +89,19 @@ void make_camera(const double lookfrom[3], const double lookat[3], const double 
     c.open_time = open_time;
     c.close_time = close_time;
 }
+
+void* big_block_alloc(size_t bytes) {
+    if (bytes < (size_t(4) << 20)) {
+        void* p = std::malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+        return p;
+    }
+    void* p = nullptr;
+    if (posix_memalign(&p, size_t(2) << 20, bytes) != 0 || !p) throw std::bad_alloc();
+    (void)madvise(p, bytes, MADV_HUGEPAGE); // advice only: where transparent huge pages are off, nothing changes
+    return p;
+}
+void big_block_free(void* p, size_t) { std::free(p); }
 
 namespace {
 

@@ -90,18 +90,18 @@ void make_camera(const double lookfrom[3], const double lookat[3], const double 
     c.close_time = close_time;
 }
 
-void* big_block_alloc(size_t bytes) {
-    if (bytes < (size_t(4) << 20)) {
-        void* p = std::malloc(bytes ? bytes : 1);
-        if (!p) throw std::bad_alloc();
-        return p;
-    }
+constexpr size_t BIG_BLOCK = size_t(4) << 20;
+void* big_block_alloc(size_t bytes, size_t align) {
+    if (bytes < BIG_BLOCK) return ::operator new(bytes ? bytes : 1, std::align_val_t(align)); // (record types are aligned to 16 or 32 bytes)
     void* p = nullptr;
     if (posix_memalign(&p, size_t(2) << 20, bytes) != 0 || !p) throw std::bad_alloc();
     (void)madvise(p, bytes, MADV_HUGEPAGE); // advice only: where transparent huge pages are off, nothing changes
     return p;
 }
-void big_block_free(void* p, size_t) { std::free(p); }
+void big_block_free(void* p, size_t bytes, size_t align) {
+    if (bytes < BIG_BLOCK) ::operator delete(p, std::align_val_t(align));
+    else std::free(p);
+}
 
 namespace {
 

@@ -44,14 +44,14 @@ struct SceneGraph {
 // megabytes of fresh pages (20-30 ms of a 10^6-sphere commit).  Element types are trivially copyable and destructible.
 // Big blocks (>= 4 MiB) are 2 MiB-aligned and advised as transparent huge pages: the first touch of 250 MB of fresh 4 KiB pages by
 // 32 host threads is 65 000 page faults taken one at a time.
-void* big_block_alloc(size_t bytes);
-void big_block_free(void* p, size_t bytes);
+void* big_block_alloc(size_t bytes, size_t align);
+void big_block_free(void* p, size_t bytes, size_t align);
 template <typename T> struct NoInitAlloc : std::allocator<T> {
     template <typename U> struct rebind { using other = NoInitAlloc<U>; };
     NoInitAlloc() = default;
     template <typename U> NoInitAlloc(const NoInitAlloc<U>&) noexcept {}
-    T* allocate(size_t n) { return static_cast<T*>(big_block_alloc(n * sizeof(T))); }
-    void deallocate(T* p, size_t n) noexcept { big_block_free(p, n * sizeof(T)); }
+    T* allocate(size_t n) { return static_cast<T*>(big_block_alloc(n * sizeof(T), alignof(T))); }
+    void deallocate(T* p, size_t n) noexcept { big_block_free(p, n * sizeof(T), alignof(T)); }
     template <typename U> void construct(U*) noexcept {} // resize(): nothing — the caller writes every element
     template <typename U, typename A0, typename... A> void construct(U* p, A0&& a0, A&&... a) { ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
 };

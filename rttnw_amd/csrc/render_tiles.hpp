@@ -89,6 +89,13 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             const uint32_t n4 = s->flat.total_nodes4();
             const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) <= 160 * 1024;
             rc.lds_nodes = want_lds ? n4 : 0u;
+            // the scene's Perlin tables ride along in LDS when they fit behind the stacks (trace_kernel_plain)
+            const size_t n_perlin = s->flat.perlin_vec.size() / 768u;
+            size_t perlin_bytes = lds_perlin_bytes(n_perlin, sizeof(R));
+            if (want_lds && n_perlin > 0 && n_perlin < 256 && n4 <= LDS_NODES_MASK && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes <= 160 * 1024)
+                rc.lds_nodes |= uint32_t(n_perlin) << LDS_PERLIN_SHIFT;
+            else
+                perlin_bytes = 0;
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
             const bool gen = s->flat.needs_general; // rare graph shapes: the instantiation that carries their code
             const void* kernel =
@@ -96,7 +103,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                                   : (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false>))
                          : (count ? (gen ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, false>)
                                   : (gen ? (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, false, TRACE_BLOCK, false, false>));
-            const size_t lds_bytes = lds_form_bytes(want_lds ? n4 : 0u, rc.stack_depth, uint32_t(block));
+            const size_t lds_bytes = lds_form_bytes(want_lds ? n4 : 0u, rc.stack_depth, uint32_t(block)) + perlin_bytes;
             if (lds_bytes > 160 * 1024) { set_last_error("render: traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
             HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
             int blocks_per_cu = 0;

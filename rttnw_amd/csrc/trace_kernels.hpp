@@ -387,7 +387,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 template <typename R, bool COUNT, int BLOCK, bool LDSN, bool GENERAL>
 // (the 256-thread form — nodes in global memory — asks for at least 3 waves/SIMD like the decoupled kernel: its f64 code,
 // allowed 256 VGPRs, ran at 2: a 20 000-sphere scene 29.9 -> 13.7 ms per 67 Msamples)
-__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plain(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+__global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plain(SceneView<R> sc_arg, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters, int32_t* __restrict__ spill) {
@@ -397,8 +397,20 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
     typename std::conditional<LDSN, LdsStackNodes<BLOCK>, LdsStack<BLOCK>>::type stack;
     stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * blockDim.x + threadIdx.x));
     stack.spill_stride = gridDim.x * blockDim.x;
+    SceneView<R> sc = sc_arg; // (the LDS form redirects the Perlin tables below)
     if constexpr (LDSN) {
-        const uint32_t n = rc.lds_nodes;
+        const uint32_t n = rc.lds_nodes & LDS_NODES_MASK, n_perlin = rc.lds_nodes >> LDS_PERLIN_SHIFT;
+        if (n_perlin) {
+            // The Perlin tables (noise.rs:40-47: 256 vectors + three permutations, 6.75 KB in f64) behind the stacks: a turbulence
+            // value is 7 octaves x 8 corners of dependent table reads, made for the one or two lanes of a wave that hit a noise
+            // texture while the others wait — from LDS instead of L2: final_scene f64 1284 -> 1315 Msamples/s, f32 1756 -> 1774.
+            R* pv = reinterpret_cast<R*>(lds_stack + n * (4u * BVH4_USED_SIXTEENTHS) + (LDS_STACK_ENTRIES + 1u) * BLOCK);
+            uint32_t* pp = reinterpret_cast<uint32_t*>(pv + 768u * n_perlin);
+            for (uint32_t i = threadIdx.x; i < 768u * n_perlin; i += blockDim.x) pv[i] = sc_arg.perlin_vec[i];
+            for (uint32_t i = threadIdx.x; i < 192u * n_perlin; i += blockDim.x) pp[i] = reinterpret_cast<const uint32_t*>(sc_arg.perlin_perm)[i];
+            sc.perlin_vec = pv;
+            sc.perlin_perm = reinterpret_cast<const uint8_t*>(pp);
+        }
         const int4* src = reinterpret_cast<const int4*>(sc.nodes);
         int4* dst = reinterpret_cast<int4*>(lds_stack);
         for (uint32_t i = threadIdx.x; i < n * 8u; i += blockDim.x)

@@ -39,7 +39,7 @@ template <typename T> struct DevBuf {
     template <typename A> int upload(const std::vector<T, A>& v) {
         release();
         n = v.size();
-        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 31) / 32 * 32; // (the LDS staging of small record arrays copies whole 32-byte units)
         HIP_TRY(hipMalloc((void**)&p, bytes));
         if (n) HIP_TRY(hipMemcpy(p, v.data(), n * sizeof(T), hipMemcpyHostToDevice));
         return 0;

@@ -96,6 +96,19 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                 rc.lds_nodes |= uint32_t(n_perlin) << LDS_PERLIN_SHIFT;
             else
                 perlin_bytes = 0;
+            // ... and so do the record arrays of the leaf steps, each if it still fits (chains, rectangles, moving spheres, cubes)
+            for (int k = 0; k < 4; ++k) rc.lds_recs[k] = 0;
+            if (want_lds) {
+                perlin_bytes = lds_pad32(perlin_bytes);
+                const size_t counts[4] = {s->flat.insts.size(), s->flat.rects.size(), s->flat.moving.size(), s->flat.boxes.size()};
+                const size_t sizes[4] = {sizeof(InstanceRec<R>), sizeof(RectRec<R>), sizeof(MovingSphereRec<R>), sizeof(BoxRec<R>)};
+                for (int k = 0; k < 4; ++k) {
+                    const size_t bytes = lds_pad32(counts[k] * sizes[k]);
+                    if (counts[k] == 0 || lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes + bytes > 160 * 1024) continue;
+                    rc.lds_recs[k] = uint32_t(counts[k]);
+                    perlin_bytes += bytes;
+                }
+            }
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
             const bool gen = s->flat.needs_general; // rare graph shapes: the instantiation that carries their code
             const void* kernel =

@@ -76,7 +76,8 @@ constexpr uint32_t LDS_STACK_ENTRIES = RT_LDS_STACK_ENTRIES;
 // LDS bytes of the lane-owns-path kernel's resident form: node records (without their pad) + the lanes' stacks.
 // RenderConsts::lds_nodes of the LDS form: the node count, and above it how many Perlin tables follow the stacks in LDS
 constexpr uint32_t LDS_NODES_MASK = 0x00FFFFFFu, LDS_PERLIN_SHIFT = 24u;
-inline size_t lds_perlin_bytes(size_t n_tables, size_t real_bytes) { return n_tables * 768u * (real_bytes + 1u); } // [n][256][3] reals + [n][3][256] bytes
+RT_HD size_t lds_perlin_bytes(size_t n_tables, size_t real_bytes) { return n_tables * 768u * (real_bytes + 1u); } // [n][256][3] reals + [n][3][256] bytes
+RT_HD size_t lds_pad32(size_t bytes) { return (bytes + 31u) / 32u * 32u; } // staged arrays start on 32-byte boundaries and are copied in whole 32-byte units
 inline size_t lds_form_bytes(uint32_t n_nodes4, uint32_t stack_depth, uint32_t block) {
     (void)stack_depth; // the LDS part of a stack has a fixed size (+ 1: the spare slot of the branch-free pushes)
     return size_t(n_nodes4) * 16 * BVH4_USED_SIXTEENTHS + size_t(LDS_STACK_ENTRIES + 1) * block * sizeof(int32_t);
@@ -218,6 +219,7 @@ struct RenderConsts {
     uint32_t lds_nodes; // lane-owns-path kernel: number of BVH nodes resident in LDS (0 = nodes read from global memory) | Perlin tables in LDS << 24
     uint64_t seed;
     uint64_t sample_begin; // index of the first sample of this launch (rttnw_params::sample_begin + the pass's offset)
+    uint32_t lds_recs[4];  // LDS form: how many insts / rects / moving / boxes records follow the Perlin tables in LDS (0: that array is read from global memory)
 };
 
 // A pixel's samples are split into CHUNKS; a job = (pixel, chunk) folds its samples sequentially (main.rs:211-216) and

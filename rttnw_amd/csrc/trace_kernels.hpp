@@ -411,6 +411,24 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
             sc.perlin_vec = pv;
             sc.perlin_perm = reinterpret_cast<const uint8_t*>(pp);
         }
+        {
+            // The record arrays a LEAF step reads, where they are small enough to follow (the host decides, render_tiles.hpp):
+            // transform chains, rectangles, moving spheres, cubes.  An instance leaf is two dependent record reads (the chain, then
+            // the wrapped record) in the middle of the walk loop: cornell_box f64 1557 -> 1617 Msamples/s with all of them in LDS.
+            uint32_t* at = reinterpret_cast<uint32_t*>(lds_stack + n * (4u * BVH4_USED_SIXTEENTHS) + (LDS_STACK_ENTRIES + 1u) * BLOCK) +
+                           uint32_t(lds_pad32(lds_perlin_bytes(n_perlin, sizeof(R)))) / 4u;
+            auto stage = [&](const void* src, uint32_t bytes) -> const void* {
+                uint32_t* dst = at;
+                const uint32_t words = uint32_t(lds_pad32(bytes)) / 4u;
+                for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = reinterpret_cast<const uint32_t*>(src)[i];
+                at += words;
+                return dst;
+            };
+            if (rc.lds_recs[0]) sc.insts = static_cast<const InstanceRec<R>*>(stage(sc_arg.insts, rc.lds_recs[0] * uint32_t(sizeof(InstanceRec<R>))));
+            if (rc.lds_recs[1]) sc.rects = static_cast<const RectRec<R>*>(stage(sc_arg.rects, rc.lds_recs[1] * uint32_t(sizeof(RectRec<R>))));
+            if (rc.lds_recs[2]) sc.moving = static_cast<const MovingSphereRec<R>*>(stage(sc_arg.moving, rc.lds_recs[2] * uint32_t(sizeof(MovingSphereRec<R>))));
+            if (rc.lds_recs[3]) sc.boxes = static_cast<const BoxRec<R>*>(stage(sc_arg.boxes, rc.lds_recs[3] * uint32_t(sizeof(BoxRec<R>))));
+        }
         const int4* src = reinterpret_cast<const int4*>(sc.nodes);
         int4* dst = reinterpret_cast<int4*>(lds_stack);
         for (uint32_t i = threadIdx.x; i < n * 8u; i += blockDim.x)

@@ -97,7 +97,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             else
                 perlin_bytes = 0;
             // ... and so do the record arrays of the leaf steps, each if it still fits (chains, rectangles, moving spheres, cubes)
-            for (int k = 0; k < 4; ++k) rc.lds_recs[k] = 0;
+            for (int k = 0; k < 6; ++k) rc.lds_recs[k] = 0;
             if (want_lds) {
                 perlin_bytes = lds_pad32(perlin_bytes);
                 const size_t counts[4] = {s->flat.insts.size(), s->flat.rects.size(), s->flat.moving.size(), s->flat.boxes.size()};
@@ -107,6 +107,13 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                     if (counts[k] == 0 || lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes + bytes > 160 * 1024) continue;
                     rc.lds_recs[k] = uint32_t(counts[k]);
                     perlin_bytes += bytes;
+                }
+                {
+                    const size_t bytes = lds_pad32(s->flat.sphere_mat.size() * 4);
+                    if (!s->flat.sphere_mat.empty() && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes + bytes <= 160 * 1024) {
+                        rc.lds_recs[4] = uint32_t(s->flat.sphere_mat.size());
+                        perlin_bytes += bytes;
+                    }
                 }
             }
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;

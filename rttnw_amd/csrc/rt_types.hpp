@@ -219,7 +219,7 @@ struct RenderConsts {
     uint32_t lds_nodes; // lane-owns-path kernel: number of BVH nodes resident in LDS (0 = nodes read from global memory) | Perlin tables in LDS << 24
     uint64_t seed;
     uint64_t sample_begin; // index of the first sample of this launch (rttnw_params::sample_begin + the pass's offset)
-    uint32_t lds_recs[4];  // LDS form: how many insts / rects / moving / boxes records follow the Perlin tables in LDS (0: that array is read from global memory)
+    uint32_t lds_recs[6];  // LDS form: how many insts / rects / moving / boxes / sphere_mat / (spare) records follow the Perlin tables in LDS (0: that array is read from global memory)
 };
 
 // A pixel's samples are split into CHUNKS; a job = (pixel, chunk) folds its samples sequentially (main.rs:211-216) and

@@ -428,6 +428,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
             if (rc.lds_recs[1]) sc.rects = static_cast<const RectRec<R>*>(stage(sc_arg.rects, rc.lds_recs[1] * uint32_t(sizeof(RectRec<R>))));
             if (rc.lds_recs[2]) sc.moving = static_cast<const MovingSphereRec<R>*>(stage(sc_arg.moving, rc.lds_recs[2] * uint32_t(sizeof(MovingSphereRec<R>))));
             if (rc.lds_recs[3]) sc.boxes = static_cast<const BoxRec<R>*>(stage(sc_arg.boxes, rc.lds_recs[3] * uint32_t(sizeof(BoxRec<R>))));
+            // (and the spheres' material slots: the first link of the chain material -> texture -> table at every sphere hit: +0.4 %)
+            if (rc.lds_recs[4]) sc.sphere_mat = static_cast<const int32_t*>(stage(sc_arg.sphere_mat, rc.lds_recs[4] * 4u));
         }
         const int4* src = reinterpret_cast<const int4*>(sc.nodes);
         int4* dst = reinterpret_cast<int4*>(lds_stack);

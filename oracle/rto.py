@@ -25,6 +25,7 @@ _PROBES = [
     ("probe_path", C.c_int, [abi.scene_p, C.POINTER(CameraDesc), C.POINTER(Params), C.c_uint32, C.c_uint32, C.c_uint32,
                              _dp, C.c_uint32]),
     ("builder", C.c_void_p, []),
+    ("scene_set_bvh_builder", C.c_int, [abi.scene_p, C.c_uint32]),
     ("probe_camera", C.c_int, [C.POINTER(CameraDesc), _dp]),
     ("probe_camera_ray", C.c_int, [C.POINTER(CameraDesc), C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                                    C.c_uint64, _dp]),
@@ -49,6 +50,10 @@ _PROBES = [
 ]
 
 _binding = None
+
+# rto_scene_set_bvh_builder (ORACLE-ONLY; `bvh=` of rttnw_amd.scene.build reaches it through the oracle binding): which
+# topology BvhTree::hit hangs on.  The reference's builder is O(n^2 log n); MEDIAN_SPLIT is for config 5's 10^6 spheres.
+BVH_REFERENCE, BVH_MEDIAN_SPLIT = 0, 1
 
 
 def build():

@@ -581,6 +581,43 @@ struct BvhTree : Hittable { // hittable.rs:248-373
         return false;
     }
     bool bounding_box(double, double, Bound& out) const override { out = bound; return true; }
+
+    // ---- second builder, ORACLE-ONLY (rto_scene_set_bvh_builder(scene, 1)); no counterpart in the reference --------------
+    // The reference's builder above re-sorts the whole remaining vector at every node (hittable.rs:300-303): O(n^2 log n), it
+    // cannot make config 5's tree of 10^6 spheres.  Closest-hit results do not depend on the tree's topology (SURVEY Q12:
+    // BvhTree::hit, :356-368, returns the nearest hit of its two sides whatever they hold; an exact tie between two DIFFERENT
+    // objects has measure zero in the sphere cloud), so for big lists the oracle may hang the same `hit` on another
+    // topology: a plain recursive median split along the longest axis of the node's box.  A node is still a BvhTree with the
+    // reference's `hit`; a range of one object is the object itself.  tests/test_oracle_kat.py holds this builder against
+    // the reference-shaped one (bit-identical images at 3 000 spheres) before anything is pinned to it.
+    struct Item { Bound box; HittablePtr obj; };
+    BvhTree(HittablePtr l, HittablePtr r, const Bound& b) : left(std::move(l)), right(std::move(r)), bound(b) {}
+    static HittablePtr median_split(std::vector<Item>& items, size_t lo, size_t hi) {
+        if (hi - lo == 1) return items[lo].obj;
+        Bound all = items[lo].box;
+        for (size_t k = lo + 1; k < hi; ++k) all = all.surrounding(items[k].box);
+        int axis = 0;
+        for (int d = 1; d < 3; ++d)
+            if (all.max[d] - all.min[d] > all.max[axis] - all.min[axis]) axis = d;
+        const size_t mid = lo + (hi - lo) / 2;
+        std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi, [axis](const Item& x, const Item& y) {
+            return x.box.min[axis] + x.box.max[axis] < y.box.min[axis] + y.box.max[axis];
+        });
+        HittablePtr l = median_split(items, lo, mid), r = median_split(items, mid, hi);
+        return std::make_shared<BvhTree>(std::move(l), std::move(r), all);
+    }
+    static HittablePtr build_median_split(const std::vector<HittablePtr>& objects, double t0, double t1) {
+        std::vector<Item> items(objects.size());
+        for (size_t k = 0; k < objects.size(); ++k) {
+            items[k].obj = objects[k];
+            if (!objects[k]->bounding_box(t0, t1, items[k].box)) std::fprintf(stderr, "No bounding box in BvhTree constructor\n");
+        }
+        HittablePtr root = median_split(items, 0, items.size());
+        if (items.size() == 1) { // a one-object list still gets its node, like the reference's span == 1 (hittable.rs:271-274)
+            return std::make_shared<BvhTree>(root, root, items[0].box);
+        }
+        return root;
+    }
 };
 
 struct Translate : Hittable { // hittable.rs:594-629
@@ -786,6 +823,7 @@ struct rttnw_scene {
     std::vector<Obj> objs;
     std::shared_ptr<List> world;
     uint32_t n_noise = 0, n_bvh = 0, n_media = 0;
+    uint32_t bvh_builder = 0; // 0: the reference's builder (hittable.rs:265-321); 1: BvhTree::build_median_split (oracle-only, big lists)
 };
 
 namespace {
@@ -929,11 +967,20 @@ rttnw_id rto_bvh_tree(rttnw_scene* s, rttnw_id list) {
     auto& items = s->objs[list].list->list;
     if (items.empty()) return fail(RTTNW_ERR_INVALID, "bvh_tree: empty list");
     SceneRng rng(s->seed, STREAM_BVH + s->n_bvh++);
+    s->objs[list].consumed = true;
+    if (s->bvh_builder == 1) return push_hit(s, BvhTree::build_median_split(items, 0., 1.));
     std::vector<HittablePtr> objects = items; // BvhTree::from consumes the list (hittable.rs:254-258)
     size_t n = objects.size();
     auto tree = std::make_shared<BvhTree>(objects, 0, n, 0., 1., rng);
-    s->objs[list].consumed = true;
     return push_hit(s, tree);
+}
+// ORACLE-ONLY switch (not part of include/rttnw_hip.h's builder table, whose entry of this name selects the PRODUCT's builders):
+// which topology rto_bvh_tree hangs BvhTree::hit on.  0 = the reference's builder, 1 = median split for lists the
+// reference's O(n^2 log n) builder cannot do.  Call before the lists are turned into trees.
+int rto_scene_set_bvh_builder(rttnw_scene* s, uint32_t which) {
+    if (!s || which > 1) return fail(RTTNW_ERR_INVALID, "set_bvh_builder: 0 (reference-shaped) or 1 (median split)");
+    s->bvh_builder = which;
+    return RTTNW_OK;
 }
 rttnw_id rto_translate(rttnw_scene* s, rttnw_id item, const double off[3]) {
     auto h = get_hit(s, item);

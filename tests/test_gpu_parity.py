@@ -185,6 +185,53 @@ def test_spheres_stress_scene_matches_oracle(gpu, oracle, scenes_lib):
     assert (np.abs(lin - lo).max(axis=2) <= T1_ABS).mean() >= 0.999
 
 
+def test_config5_spheres_1m_at_its_size_vs_oracle(gpu, oracle, scenes_lib):
+    """BASELINE configs[4] AT ITS SIZE against the oracle: 10^6 spheres, 1024x1024, spp 256.  The reference's own builder cannot
+    make this tree (hittable.rs:265-321 is O(n^2 log n)), so the oracle hangs the reference's BvhTree::hit (:356-368) on a median-
+    split topology (rto.BVH_MEDIAN_SPLIT; tests/test_oracle_kat.py proves that builder bit-identical to the reference-shaped one
+    at 3 000 spheres — topology is result-free) and renders three 32x32 windows of the same frame, same keys: the
+    centre of the cloud, an off-centre patch, and one across the cloud's silhouette.
+      * the product's tree is the deep one: traversal-stack bound > 16, i.e. beyond the 12 (f64) / 16 (f32) entries the decoupled
+        kernel keeps in LDS — the global spill strip is in play — and the decoupled kernel is what runs (stats.reserved == 1);
+      * F64 kernels, T1: linear within 1e-9 on >= 99.5 % of the window pixels, RGBA8 identical on >= 99.5 %; the remainder
+        (a rounding-induced flip of one of a pixel's 256 samples: here a flip is a grazed sphere hit or missed, so a flipped sample is
+        another path and moves its pixel by up to ~1/256) is LISTED (printed: count, max |delta|) and must stay inside the pixel's own
+        6 sigma / sqrt(spp) + 1/256;
+      * F32 kernels, T2 on the same windows: every pixel within 6 sigma_hat / sqrt(spp) + 1/256 on >= 99.8 %, window means within 1 %."""
+    w = h = 1024
+    spp = 256
+    sg, setup = util.build(gpu, scenes_lib, "spheres_1m")
+    bi = sg.build_info()
+    assert bi.n_prims >= 1000000 and bi.stack_depth > 16, (bi.n_prims, bi.stack_depth)
+    so, _ = util.build(oracle, scenes_lib, "spheres_1m", bvh=rto.BVH_MEDIAN_SPLIT)
+    cam, p64 = util.params_for(setup, w, h, spp, precision=abi.F64)
+    lin64, rgba64, st64 = gpu_render(gpu, sg, cam, p64)
+    assert st64.samples == w * h * spp and st64.reserved == 1 and np.isfinite(lin64).all()
+    _, p32 = util.params_for(setup, w, h, spp, precision=abi.F32)
+    lin32, rgba32, st32 = gpu_render(gpu, sg, cam, p32)
+    assert st32.samples == w * h * spp and st32.reserved == 1 and np.isfinite(lin32).all()
+    n_px = n_close = n_same = n_bound32 = 0
+    for (x0, y0) in [(496, 496), (200, 700), (24, 512)]:
+        lo, ro, var, _ = rto.render_window(so, cam, p64, x0, y0, x0 + 32, y0 + 32, want_var=True)
+        assert lo.max() > 0
+        bound = 6.0 * np.sqrt(np.maximum(var, 0.0) / spp) + 1.0 / 256
+        g = lin64[y0:y0 + 32, x0:x0 + 32]
+        d = np.abs(g - lo).max(axis=2)
+        flipped = d > T1_ABS
+        print("spheres_1m f64 window (%d, %d): %d of 1024 pixels beyond 1e-9, max |delta| %.3g; rgba8 differs on %d"
+              % (x0, y0, int(flipped.sum()), d.max(), int((rgba64[y0:y0 + 32, x0:x0 + 32] != ro).any(axis=2).sum())))
+        assert (np.abs(g - lo) <= bound).all(), (x0, y0, d.max())
+        n_close += int((~flipped).sum())
+        n_same += int((rgba64[y0:y0 + 32, x0:x0 + 32] == ro).all(axis=2).sum())
+        g32 = lin32[y0:y0 + 32, x0:x0 + 32]
+        n_bound32 += int((np.abs(g32 - lo) <= bound).all(axis=2).sum())
+        rel = np.abs(g32.mean(axis=(0, 1)) - lo.mean(axis=(0, 1))) / lo.mean(axis=(0, 1))
+        assert rel.max() <= 0.01, (x0, y0, rel)
+        n_px += 1024
+    assert n_close / n_px >= 0.995 and n_same / n_px >= 0.995, (n_close / n_px, n_same / n_px)
+    assert n_bound32 / n_px >= 0.998, n_bound32 / n_px
+
+
 def test_full_size_invariants(gpu, scenes_lib, earth):
     """BASELINE sizes are beyond the oracle's reach in a test, so check size-independent properties on the
     headline config (final_scene 800x800): determinism across the partition, the light patch saturates,

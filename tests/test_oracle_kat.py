@@ -375,3 +375,25 @@ def test_rng(oracle):
     z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
     z ^= z >> 31
     assert z == 0xE220A8397B1DCDAF
+
+
+# The oracle's second BVH builder (rto_scene_set_bvh_builder(scene, 1): median split, for config 5's 10^6 spheres, which the
+# reference's O(n^2 log n) builder — hittable.rs:265-321, the oracle's default — cannot make) hangs the SAME BvhTree::hit
+# (hittable.rs:356-368) on another topology.  Closest-hit results do not depend on topology, so the two must
+# render bit-identical images; only the node / record counts differ.  Proven here before anything is pinned to it.
+@pytest.mark.parametrize("name,param,w,h,spp", [("spheres_1m", 3000, 64, 64, 4), ("spheres_1m", 1, 24, 24, 2), ("final_scene", 0, 48, 48, 4)])
+def test_median_split_builder_renders_the_reference_builders_image(oracle, scenes_lib, earth, name, param, w, h, spp):
+    import util
+    from oracle import rto
+    e = earth if name == "final_scene" else None
+    sa, setup = util.build(oracle, scenes_lib, name, e, param)
+    sb, _ = util.build(oracle, scenes_lib, name, e, param, bvh=rto.BVH_MEDIAN_SPLIT)
+    cam, p = util.params_for(setup, w, h, spp, spp_chunk=2, collect_counters=1, seed=5)
+    la, ra, sta = rto.render(sa, cam, p)
+    lb, rb, stb = rto.render(sb, cam, p)
+    assert np.array_equal(la, lb) and np.array_equal(ra, rb)
+    assert sta.rays == stb.rays and la.max() > 0
+    if param == 3000:
+        assert stb.nodes_visited < sta.nodes_visited / 4  # (the degenerate builder's tree is what costs the reference its time)
+    with pytest.raises(abi.RttnwError):
+        sa.set_bvh_builder(2)

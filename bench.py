@@ -55,7 +55,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 N_SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (same table)
-VALU_CYCLES = {"f32": 2.0, "f64": 4.0}   # cycles per wave64 VALU instruction: f32 2 (SIMD-32, per-instruction table), f64 at half rate (78.6 vs 157.3 TFLOP/s)
+VALU_CYCLES = {"f32": 2.0, "f64": 4.0, "f64strict": 4.0}   # cycles per wave64 VALU instruction: f32 2 (SIMD-32, per-instruction table), f64 at half rate (78.6 vs 157.3 TFLOP/s)
 NODE_VISIT_BYTES = 32.0  # ONE 32-B accounting record per node visit, whatever a record physically holds
 PROFILE_ROUND = "r03"
 KERNEL_SOURCES = ["rttnw_amd/csrc/trace_kernels.hpp", "rttnw_amd/csrc/render_tiles.hpp", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp",
@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: final_scene (800x800 spp=1000) on one GPU, final_scene_1600 (spp = 1250 x N) on N > 1")
-    ap.add_argument("--precision", default="f64", choices=["f32", "f64"])
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64", "f64strict"],
+                    help="f64 (default, the reported arithmetic), f32 (throughput mode), f64strict (RTTNW_F64_STRICT: nothing contracted)")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (per GPU)")
     ap.add_argument("--size", type=int, default=0, help="override width = height")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
@@ -159,6 +160,8 @@ def main():
         raise RuntimeError("bench: no HIP device (no CPU fallback in the product path)")
     scenes = library.scenes()
     earth = S.load_earth()
+
+    PRECISION_NAMES = {abi.F32: "f32", abi.F64: "f64", abi.F64_STRICT: "f64strict"}
 
     class Workload:
         """One named workload resident on the device: scene built and committed, timing and counting helpers."""
@@ -231,7 +234,7 @@ def main():
 
         def roofline(self, prec, kernel_ms):
             per, form = self.counted(prec)
-            pname = "f32" if prec == abi.F32 else "f64"
+            pname = PRECISION_NAMES[prec]
             secs = kernel_ms * 1e-3
 
             # SURVEY 8(d) to the letter: 32 B per node visit + 32 B per primitive test + 4 B per texel + 16 B / spp
@@ -272,8 +275,9 @@ def main():
             # the instantiation that ran, as rocprofv3's kernel trace names it (<R, COUNT, BLOCK, LDS nodes, GENERAL>; the bench
             # scenes have none of the rare graph shapes of the GENERAL instantiations)
             rname = "float" if prec == abi.F32 else "double"
-            kernel = ("rt::trace_kernel<%s, false, false>" % rname if form != 0 else
-                      "rt::trace_kernel_plain<%s, false, %s, false>" % (rname, "1024, true" if lds_resident else "256, false"))
+            ns = "rt::ieee_strict" if prec == abi.F64_STRICT else "rt::contracted"   # (rt_core.hpp: the two builds of the arithmetic)
+            kernel = ("%s::trace_kernel<%s, false, false>" % (ns, rname) if form != 0 else
+                      "%s::trace_kernel_plain<%s, false, %s, false>" % (ns, rname, "1024, true" if lds_resident else "256, false"))
             common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
                       "per_sample": {k: round(v, 3) for k, v in per.items()},
                       "grays_per_s": round(per["rays"] * self.samples_rank / secs / 1e9, 3) if secs > 0 else None,  # world.hit() calls / s
@@ -297,7 +301,7 @@ def main():
         def record(self, prec, steps, warmup):
             ms, kms = self.timed(prec, steps, warmup)
             return {"workload": "%s %dx%d spp=%d" % (self.scene_name, self.W, self.H, self.spp),
-                    "dtype": "f32" if prec == abi.F32 else "f64",
+                    "dtype": "f32" if prec == abi.F32 else "f64", "precision": PRECISION_NAMES[prec],
                     "value": round(self.samples_total / (ms * 1e-3) / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(ms, 3),
                     "steps": steps, "warmup": warmup, "roofline": self.roofline(prec, kms)}
 
@@ -308,7 +312,7 @@ def main():
 
     workload = args.workload or ("final_scene" if world == 1 else "final_scene_1600")
     wl = Workload(workload, args.spp, args.size)
-    precision = abi.F32 if args.precision == "f32" else abi.F64
+    precision = {"f32": abi.F32, "f64": abi.F64, "f64strict": abi.F64_STRICT}[args.precision]
 
     # ---- timed region (the reported precision)
     ms_per_step, kernel_ms = wl.timed(precision, args.steps, args.warmup)
@@ -318,7 +322,7 @@ def main():
     # ---- the same workload through the other precision's kernels, its own multi-step timing
     other = None
     if not args.no_other:
-        oprec = abi.F32 if precision == abi.F64 else abi.F64
+        oprec = abi.F64 if precision == abi.F32 else abi.F32
         other = wl.record(oprec, max(1, min(args.steps, 5)), 1)
 
     # ---- the other single-GPU configs of BASELINE.json, timed in the same run (default N = 1 run only)
@@ -362,11 +366,11 @@ def main():
             "metric": "Msamples/sec on final_scene 800x800 spp=1000; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": 1 if share is not None else world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": "f32" if precision == abi.F32 else "f64", "precision": args.precision, "data": "synthetic",
             "config": cfg,
             "roofline": roof,
             "cpu_baseline": cpu,
-            ("f32_kernels" if precision == abi.F64 else "f64_kernels"): other,
+            ("f64_kernels" if precision == abi.F32 else "f32_kernels"): other,
         }
         out.update(subs)
         print(json.dumps(out), flush=True)

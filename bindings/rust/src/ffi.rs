@@ -26,6 +26,7 @@ pub const RTTNW_YZ: c_int = 2;
 // enum rttnw_precision
 pub const RTTNW_F64: u32 = 0;
 pub const RTTNW_F32: u32 = 1;
+pub const RTTNW_F64_STRICT: u32 = 2;
 pub const RTTNW_QUIRK_YROTATE_BACKROT: u32 = 1;
 pub const RTTNW_QUIRKS_REFERENCE: u32 = RTTNW_QUIRK_YROTATE_BACKROT;
 pub const RTTNW_BVH_HOST_SAH: u32 = 0;

@@ -62,8 +62,13 @@ enum rttnw_plane { RTTNW_XY = 0, RTTNW_XZ = 1, RTTNW_YZ = 2 };
  *              the f64 image, crop means within 0.5 %), but on scenes with small specular / refractive / fuzzy spheres
  *              (final_scene: the r = 10 cluster, glass, fuzz-1 metal) an f32 path and its f64 twin diverge after a few
  *              bounces, so RGBA8 agrees within 1 LSB on 96.7 % of the pixels at spp 1000 there (cornell_box: 99 %) —
- *              outside the >= 99 % of the parity tier (tests/test_gpu_parity.py::test_T2_at_baseline_size). */
-enum rttnw_precision { RTTNW_F64 = 0, RTTNW_F32 = 1 };
+ *              outside the >= 99 % of the parity tier (tests/test_gpu_parity.py::test_T2_at_baseline_size).
+ *   RTTNW_F64_STRICT  f64 with NOTHING contracted and every quotient an IEEE division — the operations of the reference's Rust in
+ *              its order (rustc fuses no multiply-add): every path takes the decisions of the CPU reference bit for bit, where
+ *              RTTNW_F64 (built with fused multiply-adds and shared reciprocals) agrees to rounding only — which a scene that
+ *              amplifies rounding (config 5: a million small spheres, ~100x per bounce) turns into different paths after a few
+ *              bounces.  Same device data and buffers as RTTNW_F64 (doubles); 5-10 % slower on the issue-bound scenes. */
+enum rttnw_precision { RTTNW_F64 = 0, RTTNW_F32 = 1, RTTNW_F64_STRICT = 2 };
 
 /* Bit flags for `rttnw_params.quirks`. */
 #define RTTNW_QUIRK_YROTATE_BACKROT 1u /* Q1: hittable.rs:700-705 reuses the overwritten x */

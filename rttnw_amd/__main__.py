@@ -28,7 +28,7 @@ def main(argv=None):
     ap.add_argument("scene", type=int)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--precision", default="f64", choices=["f32", "f64"], help="f64 = the reference's arithmetic (default); f32 = throughput")
+    ap.add_argument("--precision", default="f64", choices=["f32", "f64", "f64strict"], help="f64 = the reference's arithmetic (default); f32 = throughput; f64strict = f64 with nothing contracted (bit-for-bit the CPU reference's path decisions)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="image.png")
     ap.add_argument("--passes", type=int, default=1, help="render in this many passes over disjoint sample ranges, "
@@ -58,7 +58,7 @@ def main(argv=None):
     cam = CameraDesc.from_buffer_copy(setup.camera)
     cam.aspect_ratio = setup.width / setup.height
     p = make_params(w, h, args.spp or setup.spp, background=tuple(setup.background), seed=args.seed,
-                    precision=abi.F32 if args.precision == "f32" else abi.F64)
+                    precision={"f32": abi.F32, "f64": abi.F64, "f64strict": abi.F64_STRICT}[args.precision])
     if args.passes > 1:
         def show(k, linear):
             Image.fromarray(render.quantise_rgba8(linear), "RGBA").save(args.out)

@@ -10,7 +10,7 @@ ERR_NAMES = {-1: "RTTNW_ERR_INVALID", -2: "RTTNW_ERR_STATE", -3: "RTTNW_ERR_UNSU
              -4: "RTTNW_ERR_HIP", -5: "RTTNW_ERR_NOMEM"}
 
 XY, XZ, YZ = 0, 1, 2
-F64, F32 = 0, 1
+F64, F32, F64_STRICT = 0, 1, 2
 BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_DEVICE_SAH = 0, 1, 2
 QUIRK_YROTATE_BACKROT = 1
 QUIRKS_REFERENCE = QUIRK_YROTATE_BACKROT

@@ -11,6 +11,14 @@
 
 namespace rt {
 
+// One precision's launch code, by rttnw_params::precision (RTTNW_F64_STRICT: the ieee_strict build of the f64 arithmetic, rt_core.hpp).
+static int render_tiles_any(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
+                            rttnw_stats* stats, bool sync_for_stats = true, bool prepare_only = false) {
+    if (p->precision == RTTNW_F32) return render_tiles_t<float>(s, d, cam, p, d_packed, stream, stats, sync_for_stats, prepare_only);
+    if (p->precision == RTTNW_F64_STRICT) return ieee_strict::render_tiles_t<double>(s, d, cam, p, d_packed, stream, stats, sync_for_stats, prepare_only);
+    return render_tiles_t<double>(s, d, cam, p, d_packed, stream, stats, sync_for_stats, prepare_only);
+}
+
 int grow(void** p, size_t* have, size_t want) {
     if (*have >= want && *p) return 0;
     if (*p) (void)hipFree(*p);
@@ -109,7 +117,10 @@ int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
     if (!s || !cam || !p) { set_last_error("render: NULL argument"); return RTTNW_ERR_INVALID; }
     if (!s->committed || !s->device) { set_last_error("render: scene is not committed"); return RTTNW_ERR_STATE; }
     if (!p->width || !p->height || !p->spp || !p->max_depth) { set_last_error("render: empty image, spp or depth"); return RTTNW_ERR_INVALID; }
-    if (p->precision != RTTNW_F32 && p->precision != RTTNW_F64) { set_last_error("render: bad precision"); return RTTNW_ERR_INVALID; }
+    if (p->precision != RTTNW_F32 && p->precision != RTTNW_F64 && p->precision != RTTNW_F64_STRICT) { set_last_error("render: bad precision"); return RTTNW_ERR_INVALID; }
+    // (the f32 lane-owns-path kernel's folded slab test, rt_core.hpp SLAB_FMA_FOLDED, is conservative for t_min >= 0 only; a
+    // negative or NaN t_min has no meaning in main.rs:33 either)
+    if (!(p->t_min >= 0.0) || !(p->t_min < 1e300)) { set_last_error("render: t_min must be finite and >= 0"); return RTTNW_ERR_INVALID; }
     if (p->tile_world == 0 || p->tile_rank >= p->tile_world) { set_last_error("render: bad tile_rank / tile_world"); return RTTNW_ERR_INVALID; }
     // the decoupled kernel packs a pixel as px | row << 16, and the free-flight draw of medium m uses RNG slot m < 16
     if (p->width > 65535u || p->height > 65535u) { set_last_error("render: width and height are limited to 65535"); return RTTNW_ERR_UNSUPPORTED; }
@@ -160,6 +171,7 @@ int rttnw_debug_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const r
                            uint32_t sample, double* out, uint32_t max_out) {
     if (int rc = rt::validate(s, cam, p)) return rc;
     if (!out || px >= p->width || row >= p->height) { rt::set_last_error("debug_probe_path: bad arguments"); return RTTNW_ERR_INVALID; }
+    if (p->precision == RTTNW_F64_STRICT) return rt::ieee_strict::probe_path_t<double>(s, cam, p, px, row, sample, out, max_out);
     return p->precision == RTTNW_F32 ? rt::probe_path_t<float>(s, cam, p, px, row, sample, out, max_out)
                                      : rt::probe_path_t<double>(s, cam, p, px, row, sample, out, max_out);
 }
@@ -196,13 +208,12 @@ int rttnw_render_tiles_device(rttnw_scene* s, const rttnw_camera_desc* cam, cons
     if (int rc = rt::validate(s, cam, p)) return rc;
     if (!d_packed) { rt::set_last_error("render_tiles_device: d_packed is NULL"); return RTTNW_ERR_INVALID; }
     hipStream_t stream = (hipStream_t)hip_stream;
-    return p->precision == RTTNW_F32 ? rt::render_tiles_t<float>(s, s->device, cam, p, d_packed, stream, stats)
-                                     : rt::render_tiles_t<double>(s, s->device, cam, p, d_packed, stream, stats);
+    return rt::render_tiles_any(s, s->device, cam, p, d_packed, stream, stats);
 }
 
 int rttnw_untile_device(uint32_t width, uint32_t height, uint32_t world, uint32_t precision, const void* d_gathered,
                         void* d_linear_rgb, uint8_t* d_rgba8, void* hip_stream) {
-    if (!width || !height || !world || !d_gathered || (precision != RTTNW_F32 && precision != RTTNW_F64)) {
+    if (!width || !height || !world || !d_gathered || (precision != RTTNW_F32 && precision != RTTNW_F64 && precision != RTTNW_F64_STRICT)) {
         rt::set_last_error("untile_device: bad arguments");
         return RTTNW_ERR_INVALID;
     }
@@ -234,7 +245,7 @@ int rttnw_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_param
         if (e != hipSuccess) { rt::set_last_error(std::string("render: ") + hipGetErrorString(e)); return RTTNW_ERR_HIP; }
     }
     if (out_linear_rgb) {
-        if (p->precision == RTTNW_F64) {
+        if (p->precision != RTTNW_F32) {
             e = hipMemcpy(out_linear_rgb, d->linear, npx * 3 * sizeof(double), hipMemcpyDeviceToHost);
         } else {
             std::vector<float> tmp(npx * 3);
@@ -346,8 +357,7 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
         rttnw_params pr = p;
         pr.tile_rank = r;
         void* dst = (char*)st[r]->multi_packed + chunk * slot[r];
-        int rc = p.precision == RTTNW_F32 ? render_tiles_t<float>(s, st[r], cam, &pr, dst, st[r]->stream, nullptr, false, true)
-                                          : render_tiles_t<double>(s, st[r], cam, &pr, dst, st[r]->stream, nullptr, false, true);
+        int rc = render_tiles_any(s, st[r], cam, &pr, dst, st[r]->stream, nullptr, false, true);
         if (rc) return rc;
     }
     // ---- every rank traces its tiles, on its device's stream; ranks that share a device run one after the other
@@ -362,8 +372,7 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
         HIP_TRY(hipEventCreate(&ev[2 * r]));
         HIP_TRY(hipEventCreate(&ev[2 * r + 1]));
         HIP_TRY(hipEventRecord(ev[2 * r], d->stream));
-        int rc = p.precision == RTTNW_F32 ? render_tiles_t<float>(s, d, cam, &pr, dst, d->stream, stats ? &stats[r] : nullptr, false)
-                                          : render_tiles_t<double>(s, d, cam, &pr, dst, d->stream, stats ? &stats[r] : nullptr, false);
+        int rc = render_tiles_any(s, d, cam, &pr, dst, d->stream, stats ? &stats[r] : nullptr, false);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev[2 * r + 1], d->stream));
     }
@@ -429,7 +438,7 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
     HIP_TRY(hipSetDevice(root->device));
     if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, root->rgba, npx * 4, hipMemcpyDeviceToHost));
     if (out_linear_rgb) {
-        if (p.precision == RTTNW_F64) {
+        if (p.precision != RTTNW_F32) {
             HIP_TRY(hipMemcpy(out_linear_rgb, root->linear, npx * 3 * sizeof(double), hipMemcpyDeviceToHost));
         } else {
             std::vector<float> tmp(npx * 3);

@@ -215,7 +215,9 @@ template <typename R> CameraRec<R> narrow_camera(const CameraRec<double>& c) {
 void fill_layout(uint32_t w, uint32_t h, uint32_t world, rttnw_tile_layout& L);
 int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p);
 
-// The launch code of one precision (render_tiles.hpp), instantiated in render_f32.hip / render_f64.hip.
+// The launch code of one precision (render_tiles.hpp), instantiated in render_f32.hip / render_f64.hip — and, for double, a second
+// time in render_f64_strict.hip in the namespace rt::ieee_strict (rt_core.hpp: the two builds of the f64 arithmetic).
+inline namespace RT_ARITH_NS {
 template <typename R>
 int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
                    rttnw_stats* stats, bool sync_for_stats = true, bool prepare_only = false);
@@ -230,5 +232,20 @@ extern template int probe_path_t<float>(::rttnw_scene*, const rttnw_camera_desc*
 extern template int probe_path_t<double>(::rttnw_scene*, const rttnw_camera_desc*, const rttnw_params*, uint32_t, uint32_t, uint32_t, double*, uint32_t);
 extern template int untile_launch<float>(uint32_t, uint32_t, uint32_t, const void*, void*, uint8_t*, hipStream_t);
 extern template int untile_launch<double>(uint32_t, uint32_t, uint32_t, const void*, void*, uint8_t*, hipStream_t);
+} // namespace RT_ARITH_NS
+
+#if !defined(RT_STRICT_F64)
+// what render_api.cpp calls for precision RTTNW_F64_STRICT (defined by render_f64_strict.hip)
+namespace ieee_strict {
+template <typename R>
+int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
+                   rttnw_stats* stats, bool sync_for_stats, bool prepare_only);
+template <typename R>
+int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row, uint32_t sample,
+                 double* out, uint32_t max_out);
+extern template int render_tiles_t<double>(::rttnw_scene*, DeviceState*, const rttnw_camera_desc*, const rttnw_params*, void*, hipStream_t, rttnw_stats*, bool, bool);
+extern template int probe_path_t<double>(::rttnw_scene*, const rttnw_camera_desc*, const rttnw_params*, uint32_t, uint32_t, uint32_t, double*, uint32_t);
+} // namespace ieee_strict
+#endif
 
 } // namespace rt

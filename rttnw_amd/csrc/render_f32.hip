@@ -2,5 +2,7 @@
 #include "render_tiles.hpp"
 
 namespace rt {
+inline namespace RT_ARITH_NS {
 RT_INSTANTIATE_PRECISION(float)
+} // namespace RT_ARITH_NS
 } // namespace rt

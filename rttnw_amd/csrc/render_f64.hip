@@ -3,5 +3,7 @@
 #include "render_tiles.hpp"
 
 namespace rt {
+inline namespace RT_ARITH_NS {
 RT_INSTANTIATE_PRECISION(double)
+} // namespace RT_ARITH_NS
 } // namespace rt

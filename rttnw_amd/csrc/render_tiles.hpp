@@ -4,6 +4,7 @@
 #include "trace_kernels.hpp"
 
 namespace rt {
+inline namespace RT_ARITH_NS {
 
 // prepare_only: upload the scene on first use and grow every workspace buffer this render will need (blocking hipMalloc /
 // hipMemcpy / hipFree calls), launch nothing — rttnw_render_multi does that for ALL its ranks before the first launch, so
@@ -291,4 +292,5 @@ int untile_launch(uint32_t width, uint32_t height, uint32_t world, const void* d
     template int probe_path_t<R>(::rttnw_scene*, const rttnw_camera_desc*, const rttnw_params*, uint32_t, uint32_t, uint32_t, double*, uint32_t); \
     template int untile_launch<R>(uint32_t, uint32_t, uint32_t, const void*, void*, uint8_t*, hipStream_t);
 
+} // namespace RT_ARITH_NS
 } // namespace rt

@@ -15,7 +15,25 @@
 #define RT_NODE_STEPS 2 // node steps per trip round the walk loop (closest_solid)
 #endif
 
+// Two builds of the arithmetic (the f64 translation units):
+//   contracted   (default; render_f32.hip, render_f64.hip)  -ffp-contract=fast, shared-reciprocal f64 quotients (Recip / rt_div2 below):
+//                agrees with the f64 reference arithmetic to rounding;
+//   ieee_strict  (RT_STRICT_F64; render_f64_strict.hip, precision RTTNW_F64_STRICT)  -ffp-contract=off and every f64 quotient the
+//                IEEE division the reference performs: the same operations in the same order as vec3.rs / hittable.rs / material.rs,
+//                so a path takes the SAME decisions as the CPU reference bit for bit (what differs is the grouping of a pixel's sum and
+//                the last place of transcendental functions).
+// Everything that depends on the arithmetic lives in an inline namespace named after the build, so that the two f64 builds link into
+// one library without their template instantiations colliding.
+#if defined(RT_STRICT_F64)
+#define RT_ARITH_NS ieee_strict
+#define RT_SHARED_RECIPROCALS 0
+#else
+#define RT_ARITH_NS contracted
+#define RT_SHARED_RECIPROCALS 1
+#endif
+
 namespace rt {
+inline namespace RT_ARITH_NS {
 
 // ---------------------------------------------------------------- math wrappers
 RT_HD float rt_sqrt(float x) { return sqrtf(x); }
@@ -65,7 +83,7 @@ RT_HD double rt_div(double a, double b) { return a / b; }
 // rounding boundary; d = 0 gives NaN where IEEE gives inf — no hit either way in the one caller, box_t).
 RT_HD void rt_div2(float n1, float n2, float d, float& q1, float& q2) { q1 = rt_div(n1, d); q2 = rt_div(n2, d); }
 RT_HD void rt_div2(double n1, double n2, double d, double& q1, double& q2) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && RT_SHARED_RECIPROCALS
     double r = __builtin_amdgcn_rcp(d);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
@@ -85,7 +103,7 @@ template <> struct Recip<float> { float r; };
 template <> struct Recip<double> { double d, r; };
 RT_HD Recip<float> recip_of(float d) { return {rt_rcp(d)}; }
 RT_HD Recip<double> recip_of(double d) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && RT_SHARED_RECIPROCALS
     double r = __builtin_amdgcn_rcp(d);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
@@ -96,7 +114,7 @@ RT_HD Recip<double> recip_of(double d) {
 }
 RT_HD float div_by(float n, const Recip<float>& k) { return n * k.r; }
 RT_HD double div_by(double n, const Recip<double>& k) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && RT_SHARED_RECIPROCALS
     const double q = n * k.r;
     return __builtin_fma(__builtin_fma(-k.d, q, n), k.r, q);
 #else
@@ -1402,4 +1420,5 @@ inline bool plan_jobs(RenderConsts& rc) {
     return true;
 }
 
+} // namespace RT_ARITH_NS
 } // namespace rt

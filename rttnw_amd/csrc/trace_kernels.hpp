@@ -24,6 +24,7 @@
 #endif
 
 namespace rt {
+inline namespace RT_ARITH_NS {
 
 // ---------------------------------------------------------------------------------------------
 // device-side helpers
@@ -702,4 +703,5 @@ __global__ void probe_path_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConst
     tail[0] = ps.radiance.x; tail[1] = ps.radiance.y; tail[2] = ps.radiance.z; tail[3] = double(ps.bounce);
 }
 
+} // namespace RT_ARITH_NS
 } // namespace rt

@@ -193,43 +193,83 @@ def test_config5_spheres_1m_at_its_size_vs_oracle(gpu, oracle, scenes_lib):
     centre of the cloud, an off-centre patch, and one across the cloud's silhouette.
       * the product's tree is the deep one: traversal-stack bound > 16, i.e. beyond the 12 (f64) / 16 (f32) entries the decoupled
         kernel keeps in LDS — the global spill strip is in play — and the decoupled kernel is what runs (stats.reserved == 1);
-      * F64 kernels, T1: linear within 1e-9 on >= 99.5 % of the window pixels, RGBA8 identical on >= 99.5 %; the remainder
-        (a rounding-induced flip of one of a pixel's 256 samples: here a flip is a grazed sphere hit or missed, so a flipped sample is
-        another path and moves its pixel by up to ~1/256) is LISTED (printed: count, max |delta|) and must stay inside the pixel's own
-        6 sigma / sqrt(spp) + 1/256;
-      * F32 kernels, T2 on the same windows: every pixel within 6 sigma_hat / sqrt(spp) + 1/256 on >= 99.8 %, window means within 1 %."""
+      * RTTNW_F64_STRICT (nothing contracted, IEEE quotients: the reference's operations in its order), T1 with NO remainder: every
+        window pixel within 1e-12 of the oracle and RGBA8 identical — every one of the 3 x 1024 x 256 paths took the oracle's
+        decisions at every bounce, through the 443 k-node tree, its spill strip and the far-field f64 sphere tests;
+      * RTTNW_F64 (fused multiply-adds, shared reciprocals) on the same windows.  This scene is a billiard: a path's rounding
+        differences grow ~100x per bounce (free path 72 against radius 1.5), so after four or five bounces a contracted path and
+        its strict twin hit different spheres: most PIXELS hold such a sample (measured and printed: pixels beyond 1e-9, max
+        |delta|) although the two are draws of the same distribution.  Asserted: every pixel within 6 sigma_hat / sqrt(spp) + 1/256
+        of the oracle (sigma_hat: the oracle's per-pixel sample variance), window means within 1 %, RGBA8 within 1 LSB on >= 97 %;
+      * RTTNW_F32, T2 on the same windows: the same bound on >= 99.8 % of the pixels, window means within 1 %."""
     w = h = 1024
     spp = 256
     sg, setup = util.build(gpu, scenes_lib, "spheres_1m")
     bi = sg.build_info()
     assert bi.n_prims >= 1000000 and bi.stack_depth > 16, (bi.n_prims, bi.stack_depth)
     so, _ = util.build(oracle, scenes_lib, "spheres_1m", bvh=rto.BVH_MEDIAN_SPLIT)
+    out = {}
+    for name, prec in (("strict", abi.F64_STRICT), ("f64", abi.F64), ("f32", abi.F32)):
+        cam, p = util.params_for(setup, w, h, spp, precision=prec)
+        lin, rgba, st = gpu_render(gpu, sg, cam, p)
+        assert st.samples == w * h * spp and st.reserved == 1 and np.isfinite(lin).all(), name
+        out[name] = (lin, rgba)
     cam, p64 = util.params_for(setup, w, h, spp, precision=abi.F64)
-    lin64, rgba64, st64 = gpu_render(gpu, sg, cam, p64)
-    assert st64.samples == w * h * spp and st64.reserved == 1 and np.isfinite(lin64).all()
-    _, p32 = util.params_for(setup, w, h, spp, precision=abi.F32)
-    lin32, rgba32, st32 = gpu_render(gpu, sg, cam, p32)
-    assert st32.samples == w * h * spp and st32.reserved == 1 and np.isfinite(lin32).all()
-    n_px = n_close = n_same = n_bound32 = 0
+    n_px = n_bound32 = n_lsb64 = 0
     for (x0, y0) in [(496, 496), (200, 700), (24, 512)]:
         lo, ro, var, _ = rto.render_window(so, cam, p64, x0, y0, x0 + 32, y0 + 32, want_var=True)
         assert lo.max() > 0
+        crop = lambda a: a[y0:y0 + 32, x0:x0 + 32]
         bound = 6.0 * np.sqrt(np.maximum(var, 0.0) / spp) + 1.0 / 256
-        g = lin64[y0:y0 + 32, x0:x0 + 32]
+        # strict: the oracle's paths, all of them
+        ds = np.abs(crop(out["strict"][0]) - lo).max()
+        assert ds <= 1e-12 and np.array_equal(crop(out["strict"][1]), ro), (x0, y0, ds)
+        # contracted f64: the same distribution; the flipped pixels are listed
+        g = crop(out["f64"][0])
         d = np.abs(g - lo).max(axis=2)
-        flipped = d > T1_ABS
-        print("spheres_1m f64 window (%d, %d): %d of 1024 pixels beyond 1e-9, max |delta| %.3g; rgba8 differs on %d"
-              % (x0, y0, int(flipped.sum()), d.max(), int((rgba64[y0:y0 + 32, x0:x0 + 32] != ro).any(axis=2).sum())))
+        lsb = np.abs(crop(out["f64"][1])[..., :3].astype(int) - ro[..., :3].astype(int)).max(axis=2)
+        print("spheres_1m window (%d, %d): strict max |delta| %.3g; contracted f64: %d of 1024 pixels beyond 1e-9, max |delta| %.3g, rgba8 differs on %d (> 1 LSB on %d)"
+              % (x0, y0, ds, int((d > T1_ABS).sum()), d.max(), int((lsb > 0).sum()), int((lsb > 1).sum())))
         assert (np.abs(g - lo) <= bound).all(), (x0, y0, d.max())
-        n_close += int((~flipped).sum())
-        n_same += int((rgba64[y0:y0 + 32, x0:x0 + 32] == ro).all(axis=2).sum())
-        g32 = lin32[y0:y0 + 32, x0:x0 + 32]
+        rel = np.abs(g.mean(axis=(0, 1)) - lo.mean(axis=(0, 1))) / lo.mean(axis=(0, 1))
+        assert rel.max() <= 0.01, (x0, y0, rel)
+        n_lsb64 += int((lsb <= 1).sum())
+        g32 = crop(out["f32"][0])
         n_bound32 += int((np.abs(g32 - lo) <= bound).all(axis=2).sum())
         rel = np.abs(g32.mean(axis=(0, 1)) - lo.mean(axis=(0, 1))) / lo.mean(axis=(0, 1))
         assert rel.max() <= 0.01, (x0, y0, rel)
         n_px += 1024
-    assert n_close / n_px >= 0.995 and n_same / n_px >= 0.995, (n_close / n_px, n_same / n_px)
+    assert n_lsb64 / n_px >= 0.97, n_lsb64 / n_px
     assert n_bound32 / n_px >= 0.998, n_bound32 / n_px
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_box", 96, 96, 16), ("final_scene", 96, 96, 16), ("smoke_cornell_box", 64, 64, 8), ("random_scene", 64, 36, 8)])
+def test_f64_strict_takes_the_oracles_decisions(gpu, oracle, scenes_lib, earth, name, w, h, spp):
+    """RTTNW_F64_STRICT against the live oracle: with nothing contracted and IEEE quotients the kernels perform the reference's
+    operations in its order, so T1 holds with no remainder on scenes without transcendental functions in the geometry
+    (cornell_box: every pixel within 1e-13, RGBA8 identical), and with the >= 99.9 % of the contracted build elsewhere (final_scene:
+    the world-space test of the cluster's spheres and OCML-vs-glibc sin / atan2 / acos / log differ in the last place).  All three
+    kernel forms."""
+    import os
+    sg, setup = util.build(gpu, scenes_lib, name, earth)
+    so, _ = util.build(oracle, scenes_lib, name, earth)
+    cam, p = util.params_for(setup, w, h, spp, precision=abi.F64_STRICT, seed=31)
+    lo, ro, _ = rto.render(so, cam, p)
+    first = None
+    for form in ("plain", "plainglobal", "wave"):
+        os.environ["RTTNW_KERNEL"] = form
+        try:
+            lin, rgba, st = gpu_render(gpu, sg, cam, p)
+        finally:
+            del os.environ["RTTNW_KERNEL"]
+        d = np.abs(lin - lo).max(axis=2)
+        if name == "cornell_box":
+            assert d.max() <= 1e-13 and np.array_equal(rgba, ro), (form, d.max())
+        else:
+            assert (d <= T1_ABS).mean() >= 0.999 and (rgba == ro).all(axis=2).mean() >= 0.999, (name, form, d.max())
+        if first is None:
+            first = lin
+        assert np.array_equal(lin, first), form
 
 
 def test_full_size_invariants(gpu, scenes_lib, earth):

@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--sub-steps", type=int, default=3, help="timed steps of each sub-record (after one warm-up step)")
     ap.add_argument("--spp-chunk", type=int, default=0, help="samples per work item (0 = the library's tapered schedule)")
     ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "dsah"], help="BVH builder at commit: host binned SAH (default), device LBVH, device binned SAH")
+    ap.add_argument("--dump-image", default=None, metavar="PATH.npz", help="rank 0 saves the last timed step's frame (linear, rgba8): tests compare it with a single-rank render")
     ap.add_argument("--share", default=None, metavar="R/W",
                     help="trace ONE rank's share (rank R of a W-way partition) of the N = W workload on this GPU, no gather: "
                          "what each GPU of a W-GPU run does (not a bench line for the driver)")
@@ -136,6 +137,11 @@ def main():
         rank, world = share
     elif world != args.gpus:
         log("bench: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+    # RTTNW_BENCH_ONE_DEVICE=1: rehearsal of an N-rank run on a box with ONE GPU — every rank on device 0, gloo instead of RCCL (which
+    # refuses two ranks on one device) for the barriers, the max-over-ranks and the gather; everything else is the N-GPU code path
+    one_device = os.environ.get("RTTNW_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     # RTTNW_BENCH_FORCE_DIST=1: take the torch.distributed code path with a single rank too (checks the launch plumbing
     # on a 1-GPU box; the numbers are the same)
@@ -148,7 +154,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+            if one_device:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -226,9 +235,13 @@ def main():
             ms_per_step = elapsed * 1e3 / max(1, steps)
             kernel_ms = float(np.mean(kms)) if kms else 0.0
             if use_dist:
-                t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cuda")
+                t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cpu" if one_device else "cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ms_per_step, kernel_ms = float(t[0]), float(t[1])
+            if args.dump_image and rank == 0 and share is None:
+                torch.cuda.synchronize()
+                np.savez(args.dump_image, linear=r.linear.cpu().numpy(), rgba8=r.rgba8.cpu().numpy())
+                args.dump_image = None   # (the reported precision's frame only)
             del r
             return ms_per_step, kernel_ms
 
@@ -271,7 +284,8 @@ def main():
                         "note": "achieved = SQ_INSTS_VALU x SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) / kernel time: the vector "
                                 "instructions of one launch counted as full 64-lane instructions; peak = 1024 SIMDs x 2.4 GHz / cycles "
                                 "per wave64 instruction of this kernel's arithmetic"}
-            lds_resident = form == 0 and self.info.n_nodes * 112 <= 140 * 1024
+            lds_resident = (form & 2) != 0   # rttnw_stats.reserved bit 1: the launch kept the node records in LDS (the library's own choice)
+            form &= 1
             # the instantiation that ran, as rocprofv3's kernel trace names it (<R, COUNT, BLOCK, LDS nodes, GENERAL>; the bench
             # scenes have none of the rare graph shapes of the GENERAL instantiations)
             rname = "float" if prec == abi.F32 else "double"

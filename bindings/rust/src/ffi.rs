@@ -171,6 +171,7 @@ extern "C" {
     pub fn rttnw_untile_device(width: u32, height: u32, world: u32, precision: u32, d_gathered: *const c_void, d_linear_rgb: *mut c_void, d_rgba8: *mut u8, hip_stream: *mut c_void) -> c_int;
     // ---- introspection
     pub fn rttnw_abi_version() -> c_int;
+    pub fn rttnw_shutdown();
     pub fn rttnw_device_count() -> c_int;
     pub fn rttnw_last_error() -> *const c_char;
     pub fn rttnw_scene_info(s: *mut rttnw_scene, out: *mut rttnw_stats) -> c_int;

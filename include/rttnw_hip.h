@@ -203,7 +203,7 @@ typedef struct rttnw_stats {
     uint32_t n_nodes;        /* flat scene size: 4-wide node records */
     uint32_t n_prims;
     uint32_t scene_bytes;    /* bytes of node+primitive arrays resident on the device */
-    uint32_t reserved;       /* render: kernel form that ran (0 = lane-owns-path, 1 = decoupled); scene_info: stack depth */
+    uint32_t reserved;       /* render: kernel form that ran — bit 0: decoupled (else lane-owns-path), bit 1: node records resident in LDS; scene_info: stack depth */
 } rttnw_stats;
 
 /* Framebuffer partition: 8x8-pixel tiles, tile t owned by rank
@@ -255,6 +255,9 @@ int rttnw_untile_device(uint32_t width, uint32_t height, uint32_t world, uint32_
 
 int rttnw_abi_version(void);
 int rttnw_device_count(void);
+/* Releases what the library keeps for the life of the process: the RCCL communicator sets rttnw_render_multi caches per list of
+ * devices (the reference has no counterpart: rayon's pool goes with the process, main.rs:202).  Optional — the same runs at exit. */
+void rttnw_shutdown(void);
 const char* rttnw_last_error(void);
 
 /* Debug/inspection: sizes of the lowered scene (valid after commit). */

@@ -102,6 +102,7 @@ PRODUCT_FUNCS = [
     ("untile_device", C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
     ("abi_version", C.c_int, []),
+    ("shutdown", None, []),
     ("device_count", C.c_int, []),
     ("scene_info", C.c_int, [scene_p, C.POINTER(Stats)]),
     ("scene_set_bvh_builder", C.c_int, [scene_p, C.c_uint32]),

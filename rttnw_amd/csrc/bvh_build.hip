@@ -765,8 +765,8 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
         // ---- collapse: heads level by level (root first), numbering, records, stack bound
         LBVH_TRY(hipMemsetAsync(d_is_head, 0, size_t(n_inner) * 4, 0));
         {
-            const uint32_t one = 1u;
-            const int zero = 0;
+            static const uint32_t one = 1u; // (static: the source of an asynchronous copy must outlive the call)
+            static const int zero = 0;
             LBVH_TRY(hipMemcpyAsync(d_is_head, &one, 4, hipMemcpyHostToDevice, 0)); // the root (binary node 0) heads record 0
             LBVH_TRY(hipMemcpyAsync(d_heads, &zero, 4, hipMemcpyHostToDevice, 0));
         }

@@ -290,12 +290,28 @@ struct Rccl {
     }
 };
 static Rccl g_rccl;
-struct MultiComms { // one communicator set per distinct list of devices, kept for the life of the process
+struct MultiComms { // one communicator set per distinct list of devices, kept until rttnw_shutdown() / process exit
     std::vector<int> devices;
     std::vector<ncclComm_t> comms;
+    std::mutex in_use; // RCCL allows ONE thread at a time to issue operations on a communicator: held from GroupStart to GroupEnd
 };
 static std::vector<MultiComms*> g_comms;
-static std::mutex g_comms_mutex; // (rttnw_render_multi may be called from several host threads, each with its own scene)
+static std::mutex g_comms_mutex; // the list itself (rttnw_render_multi may be called from several host threads, each with its own scene)
+static bool g_comms_atexit = false;
+
+// Destroy the cached communicator sets (rttnw_shutdown; registered with atexit at the first set-up, so that a process that
+// never calls it still leaves RCCL in order — before the HIP runtime's own teardown, which atexit runs later: LIFO).
+static void destroy_comms() {
+    std::lock_guard<std::mutex> lock(g_comms_mutex);
+    for (MultiComms* c : g_comms) {
+        std::lock_guard<std::mutex> use(c->in_use);
+        for (ncclComm_t comm : c->comms)
+            if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+        c->comms.clear();
+    }
+    for (MultiComms* c : g_comms) delete c;
+    g_comms.clear();
+}
 
 static DeviceState* state_on(::rttnw_scene* s, int device, std::string& err) {
     if (s->device && s->device->device == device) return s->device;
@@ -395,9 +411,13 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
             mc->comms.resize(distinct.size());
             ncclResult_t nr = g_rccl.CommInitAll(mc->comms.data(), int(distinct.size()), distinct.data());
             if (nr != ncclSuccess) { set_last_error(std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr)); delete mc; return RTTNW_ERR_HIP; }
-            g_comms.push_back(mc); // kept for the life of the process: communicator set-up costs ~100 ms; freed by the OS at exit
+            g_comms.push_back(mc); // kept: communicator set-up costs ~100 ms; destroyed by rttnw_shutdown() or at exit
+            if (!g_comms_atexit) { g_comms_atexit = true; std::atexit(destroy_comms); }
             if (getenv("RTTNW_DEBUG_MULTI")) fprintf(stderr, "[render_multi] RCCL communicators over %zu device(s)\n", distinct.size());
         }
+        // (the list's lock is released, the set's own is taken: two host threads rendering over the SAME devices take turns on
+        // its communicators; threads over different device lists do not wait for each other)
+        std::unique_lock<std::mutex> use(mc->in_use);
         comms_lock.unlock();
         ncclResult_t nr = g_rccl.GroupStart();
         uint32_t n_sent = 0;
@@ -448,3 +468,7 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
     }
     return RTTNW_OK;
 }
+
+// Release what the library keeps for the life of the process (today: the RCCL communicator sets of rttnw_render_multi).  Scenes
+// are the caller's (rttnw_scene_destroy).  Safe to call more than once and with renders finished; also runs at exit.
+extern "C" void rttnw_shutdown(void) { rt::destroy_comms(); }

@@ -196,6 +196,7 @@ struct DeviceState {
 };
 
 int grow(void** p, size_t* have, size_t want); // a workspace buffer kept at its high-water mark (render_api.cpp)
+void debug_print_sched(const DeviceCounters& hc, bool plain, uint32_t profile, uint64_t samples); // RTTNW_DEBUG_SCHED=1 only (debug_sched.cpp)
 int device_state_create(DeviceState*& out, std::string& err);
 
 template <typename R> DeviceScene<R>& scene_of(DeviceState* d);

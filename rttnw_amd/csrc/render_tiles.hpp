@@ -34,16 +34,30 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     plan_chunks(rc, p->spp, p->spp_chunk);
     const uint32_t total_chunks = rc.n_chunks;
     // (if the device cannot give the workspace — other tenants of its memory — the budget is halved, down to 1 GiB: more launches, same image)
+    // The budget that worked is REMEMBERED (d->chunk_budget): a later render does not retry the allocation that failed, and the
+    // buffer in hand is released only once a larger one has been obtained — or, if none can be, simply used: the launch split
+    // then follows ITS size.
     uint32_t per_launch = 0;
     for (uint64_t budget = d->chunk_budget;; budget /= 2) {
         per_launch = launch_chunks(uint64_t(rc.my_tiles) * 64, 3 * sizeof(R), total_chunks, budget);
         const size_t want = std::max<size_t>(size_t(rc.my_tiles) * 64 * std::min(per_launch, total_chunks), 1) * 3 * sizeof(R);
         if (d->partial_bytes >= want && d->partial) break;
-        if (d->partial) { (void)hipFree(d->partial); d->partial = nullptr; d->partial_bytes = 0; }
-        const hipError_t e = hipMalloc(&d->partial, std::max<size_t>(want, 16));
-        if (e == hipSuccess) { d->partial_bytes = want; break; }
+        void* bigger = nullptr;
+        const hipError_t e = hipMalloc(&bigger, std::max<size_t>(want, 16));
+        if (e == hipSuccess) {
+            if (d->partial) (void)hipFree(d->partial);
+            d->partial = bigger;
+            d->partial_bytes = want;
+            if (!getenv("RTTNW_CHUNK_SUM_BUDGET")) d->chunk_budget = budget;
+            break;
+        }
         (void)hipGetLastError(); // clear the sticky out-of-memory
-        d->partial = nullptr;
+        const size_t one_group = size_t(rc.my_tiles) * 64 * std::min<uint32_t>(16u, total_chunks) * 3 * sizeof(R);
+        if (d->partial && d->partial_bytes >= one_group) { // no larger buffer to be had: split the render by the one in hand
+            per_launch = launch_chunks(uint64_t(rc.my_tiles) * 64, 3 * sizeof(R), total_chunks, d->partial_bytes);
+            if (!getenv("RTTNW_CHUNK_SUM_BUDGET")) d->chunk_budget = std::max<uint64_t>(d->partial_bytes, 1ull << 30);
+            break;
+        }
         if (budget <= (1ull << 30) || getenv("RTTNW_CHUNK_SUM_BUDGET")) { set_last_error(std::string("render: no memory for the chunk sums: ") + hipGetErrorString(e)); return RTTNW_ERR_HIP; }
     }
 
@@ -85,7 +99,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         const size_t n_jobs = rc.n_jobs;
         if (plain) {
             // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
-            // 1024 threads (4 waves/SIMD at <= 128 VGPRs) for f32, 512 threads (2 waves/SIMD, all the 256-VGPR f64 code allows)
+            // 1024 threads in both precisions (4 waves/SIMD at <= 128 VGPRs; RT_F64_BLOCK: the f64 code spills ~26 registers to get there)
             constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : RT_F64_BLOCK;
             const uint32_t n4 = s->flat.total_nodes4();
             const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) <= 160 * 1024;
@@ -200,42 +214,14 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             DeviceCounters hc;
             HIP_TRY(hipMemcpy(&hc, dc, sizeof(hc), hipMemcpyDeviceToHost));
             stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
-            if (getenv("RTTNW_DEBUG_SCHED") && plain) {
-                const double tot = double(hc.dbg[0] + hc.dbg[1] + hc.dbg[2] + hc.dbg[3]);
-                fprintf(stderr, "[plain] wave clock: hand-out %.1f%%  begin %.1f%%  walk %.1f%%  shade %.1f%% (media + hit record %.1f%%, material %.1f%%)\n", 100 * hc.dbg[0] / tot,
-                        100 * hc.dbg[1] / tot, 100 * hc.dbg[2] / tot, 100 * hc.dbg[3] / tot, 100 * hc.dbg[15] / tot, 100 * (hc.dbg[3] - hc.dbg[15]) / tot);
-                fprintf(stderr, "[plain] walk: %.1f lockstep iterations/round (%.1f with node lanes, %.1f with leaf lanes); lanes served per iteration %.1f of 64\n",
-                        double(hc.dbg[4]) / hc.dbg[9], double(hc.dbg[7]) / hc.dbg[9], double(hc.dbg[8]) / hc.dbg[9],
-                        double(hc.dbg[5] + hc.dbg[6]) / hc.dbg[4]);
-                fprintf(stderr, "[plain] walk clock: node steps %.1f%%, leaf steps %.1f%% of the walk\n", 100.0 * hc.dbg[13] / hc.dbg[2], 100.0 * hc.dbg[14] / hc.dbg[2]);
-                for (uint32_t m = 1; m < 64; ++m)
-                    if (hc.dbg[80 + m] * 200 > hc.dbg[8])
-                        fprintf(stderr, "[plain]   leaf iterations serving {%s%s%s%s%s%s}: %.1f%% of them, %.1f%% of the leaf clock, %.0f clocks each\n", m & 1 ? "sphere " : "",
-                                m & 2 ? "moving " : "", m & 4 ? "rect " : "", m & 8 ? "box " : "", m & 16 ? "instance " : "", m & 32 ? "empty " : "",
-                                100.0 * hc.dbg[80 + m] / hc.dbg[8], 100.0 * hc.dbg[16 + m] / hc.dbg[14], double(hc.dbg[16 + m]) / hc.dbg[80 + m]);
-                fprintf(stderr, "[plain]   node iterations: %.0f clocks each\n", double(hc.dbg[13]) / hc.dbg[7]);
-                if (rc.profile == 3u) { // collect_counters = 3: distribution of walk lengths, in trips
-                    fprintf(stderr, "[plain] trips per walk (lanes):");
-                    for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", hc.dbg[16 + k]);
-                    fprintf(stderr, "\n[plain] walks / mean trips by result (miss, sphere, moving, rect, box, -, in instance):");
-                    for (int k = 0; k < 7; ++k) fprintf(stderr, " %llu / %.1f", hc.dbg[152 + k], hc.dbg[152 + k] ? double(hc.dbg[144 + k]) / hc.dbg[152 + k] : 0.0);
-                    fprintf(stderr, "\n[plain] trips of the longest walk per round (waves):");
-                    for (int k = 0; k < 64; ++k) fprintf(stderr, " %llu", hc.dbg[80 + k]);
-                    fprintf(stderr, "\n");
-                }
-                fprintf(stderr, "[plain] node lanes per node iteration %.1f, leaf lanes per leaf iteration %.1f; rounds/sample %.2f, lanes alive per round %.1f; begin in %.0f%% of rounds, %.1f lanes each\n",
-                        double(hc.dbg[5]) / hc.dbg[7], double(hc.dbg[6]) / hc.dbg[8], double(hc.dbg[9]) * 64 / stats->samples,
-                        double(hc.dbg[10]) / hc.dbg[9], 100.0 * hc.dbg[11] / hc.dbg[9], hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
-            } else if (getenv("RTTNW_DEBUG_SCHED")) {
-                const double w64 = double(stats->samples) / 64.0;
-                fprintf(stderr, "[decoupled] bursts/64smp %.1f  shades/64smp %.2f (lanes %.1f)  refills/64smp %.1f (lanes %.1f)\n", hc.dbg[8] / w64, hc.dbg[9] / w64,
-                        hc.dbg[9] ? double(hc.dbg[10]) / hc.dbg[9] : 0.0, hc.dbg[11] / w64, hc.dbg[11] ? double(hc.dbg[12]) / hc.dbg[11] : 0.0);
-            }
+            if (getenv("RTTNW_DEBUG_SCHED")) debug_print_sched(hc, plain, rc.profile, stats->samples); // (debug_sched.cpp)
         }
         stats->n_nodes = s->flat.total_nodes4();
         stats->n_prims = s->flat.n_prims_in_bvh;
         stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
-        stats->reserved = plain ? 0u : 1u; // which kernel form ran: 0 lane-owns-path, 1 decoupled
+        // which kernel form ran: bit 0 = decoupled (else lane-owns-path), bit 1 = node records resident in LDS (the form bench.py's
+        // roofline calls issue-bound)
+        stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u);
     }
     return RTTNW_OK;
 }

@@ -114,8 +114,17 @@ class DeviceRenderer:
         src = self.packed
         if self.world > 1 or self.force_gather:
             import torch.distributed as dist
-            glist = list(self.gathered.unbind(0)) if self.rank == 0 else None
-            dist.gather(self.packed, glist, dst=0, group=self.group)   # RCCL: grouped send/recv into rank 0
+            if dist.get_backend(self.group) == "gloo":
+                # rehearsal of an N-rank run on ONE device (bench.py RTTNW_BENCH_ONE_DEVICE=1; RCCL refuses two ranks on a device):
+                # gloo gathers host tensors only, so the packed tiles go through the host
+                host = self.packed.cpu()
+                hlist = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(host, hlist, dst=0, group=self.group)
+                if self.rank == 0:
+                    self.gathered.copy_(self.torch.stack(hlist))
+            else:
+                glist = list(self.gathered.unbind(0)) if self.rank == 0 else None
+                dist.gather(self.packed, glist, dst=0, group=self.group)   # RCCL: grouped send/recv into rank 0
             src = self.gathered
         if self.rank == 0:
             p = self.params

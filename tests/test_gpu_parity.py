@@ -62,10 +62,20 @@ def test_T1_f64_vs_live_oracle_and_counters(gpu, oracle, hostsim, scenes_lib, ea
     # device counters: same world.hit() count as the oracle, same node/primitive reads as the host build of
     # the same traversal (on the agreeing paths; allow the rare flipped path)
     _, st_h = util.hostsim_render(hostsim, sh, cam, p)
-    assert abs(int(st.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
-    assert abs(int(st.nodes_visited) - int(st_h.nodes_visited)) <= 1e-3 * st_h.nodes_visited
-    assert abs(int(st.prims_tested) - int(st_h.prims_tested)) <= 1e-3 * st_h.prims_tested
-    assert st.texel_fetches == st_h.texel_fetches or abs(int(st.texel_fetches) - int(st_h.texel_fetches)) <= 1e-3 * st_h.texel_fetches
+    if d.max() <= T1_ABS:   # every pixel agrees, i.e. no path flipped: the counters are IDENTICAL
+        assert int(st.rays) == int(st_o.rays)
+        assert (int(st.nodes_visited), int(st.prims_tested), int(st.texel_fetches)) == (int(st_h.nodes_visited), int(st_h.prims_tested), int(st_h.texel_fetches))
+    else:                   # a flipped path: its walks differ
+        assert abs(int(st.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
+        assert abs(int(st.nodes_visited) - int(st_h.nodes_visited)) <= 1e-3 * st_h.nodes_visited
+        assert abs(int(st.prims_tested) - int(st_h.prims_tested)) <= 1e-3 * st_h.prims_tested
+        assert abs(int(st.texel_fetches) - int(st_h.texel_fetches)) <= 1e-3 * st_h.texel_fetches
+    # RTTNW_F64_STRICT performs the host build's operations exactly: the same paths, hence identical counters, always
+    _, ps = util.params_for(setup, 96, 96, 8, spp_chunk=4, precision=abi.F64_STRICT, collect_counters=1, seed=77)
+    lin_s, _, st_s = gpu_render(gpu, sg, cam, ps)
+    if name == "cornell_box":
+        assert int(st_s.rays) == int(st_o.rays)
+        assert (int(st_s.nodes_visited), int(st_s.prims_tested)) == (int(st_h.nodes_visited), int(st_h.prims_tested))
 
 
 @pytest.mark.parametrize("name,lsb_frac", [("cornell_box", 0.99), ("final_scene", 0.95)])
@@ -304,7 +314,8 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
     for form in ("plain", "plainglobal", "wave"):
         monkeypatch.setenv("RTTNW_KERNEL", form)
         lin, rgba, st = gpu_render(gpu, sc, cam, p)
-        assert st.reserved == (1 if form == "wave" else 0)
+        assert (st.reserved & 1) == (1 if form == "wave" else 0)
+        assert (st.reserved & 2) == 0 or form == "plain"   # bit 1: node records resident in LDS (the lane-owns-path kernel only)
         out[form] = (lin, rgba, st.rays, st.nodes_visited, st.prims_tested)
     for form in ("plainglobal", "wave"):
         if precision == abi.F64 or form == "plainglobal":
@@ -339,7 +350,7 @@ def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):
         lin2, rgba2, st2 = gpu_render(gpu, sc, cam, p)
     finally:
         del os.environ["RTTNW_KERNEL"]
-    assert st2.reserved == 0 and (np.abs(lin - lin2).max(axis=2) > 0).mean() <= 2e-3
+    assert (st2.reserved & 1) == 0 and (np.abs(lin - lin2).max(axis=2) > 0).mean() <= 2e-3
 
 
 def test_progressive_passes_compose(gpu, scenes_lib, earth):
@@ -605,11 +616,21 @@ def test_config2_final_scene_800_at_spp_5000(gpu, oracle, hostsim, scenes_lib, e
         part, _, _ = gpu_render(gpu, sc, cam, pk)
         total += part * 1000
     assert np.abs(total / spp - lin).max() <= 1e-12 * max(1.0, lin.max())
+    # the same frame through RTTNW_F64_STRICT (nothing contracted, IEEE quotients): what is left of the remainder there is the
+    # last place of OCML's against glibc's sin / atan2 / acos / log and the world-space test of the cluster's spheres
+    _, ps = util.params_for(setup, w, h, spp, precision=abi.F64_STRICT)
+    lin_s, rgba_s, _ = gpu_render(gpu, sc, cam, ps)
     for (x0, y0) in [(250, 560), (510, 290)]:
         lo, ro, _, _ = rto.render_window(so, cam, p, x0, y0, x0 + 48, y0 + 32)
         d = np.abs(lin[y0:y0 + 32, x0:x0 + 48] - lo).max(axis=2)
+        d_s = np.abs(lin_s[y0:y0 + 32, x0:x0 + 48] - lo).max(axis=2)
+        # the flipped pixels are LISTED (this line is the list: count and largest difference per crop and build)
+        print("final_scene 800x800 spp 5000 crop (%d, %d): RTTNW_F64 %d of 1536 pixels beyond 1e-9 (max |delta| %.3g); RTTNW_F64_STRICT %d (max %.3g)"
+              % (x0, y0, int((d > T1_ABS).sum()), d.max(), int((d_s > T1_ABS).sum()), d_s.max()))
         assert (d <= T1_ABS).mean() >= 0.97 and d.max() <= 1e-6, (x0, y0, (d <= T1_ABS).mean(), d.max())
+        assert (d_s <= T1_ABS).mean() >= 0.97 and d_s.max() <= 1e-6, (x0, y0, (d_s <= T1_ABS).mean(), d_s.max())
         assert (rgba[y0:y0 + 32, x0:x0 + 48] == ro).all(axis=2).mean() >= 0.999
+        assert (rgba_s[y0:y0 + 32, x0:x0 + 48] == ro).all(axis=2).mean() >= 0.999
 
 
 def test_config3_final_scene_1600_at_spp_10000_across_eight_ranks(gpu, oracle, hostsim, scenes_lib, earth):
@@ -641,6 +662,7 @@ def test_config3_final_scene_1600_at_spp_10000_across_eight_ranks(gpu, oracle, h
     for (x0, y0) in [(500, 1100), (1020, 580)]:
         lo, ro, _, _ = rto.render_window(so, cam, p, x0, y0, x0 + 32, y0 + 24)
         d = np.abs(one[y0:y0 + 24, x0:x0 + 32] - lo).max(axis=2)
+        print("final_scene 1600x1600 spp 10000 crop (%d, %d): %d of 768 pixels beyond 1e-9, max |delta| %.3g" % (x0, y0, int((d > T1_ABS).sum()), d.max()))
         assert (d <= T1_ABS).mean() >= 0.95 and d.max() <= 1e-6, (x0, y0, (d <= T1_ABS).mean(), d.max())
         assert (rgba[y0:y0 + 24, x0:x0 + 32] == ro).all(axis=2).mean() >= 0.999
 
@@ -701,3 +723,37 @@ def test_bench_line_through_torch_distributed_with_one_rank(gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "Msamples/s"
     assert d["config"]["workload"].startswith("final_scene 800x800 spp=16") and d["roofline"]["kernel_ms"] > 0
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu(gpu, scenes_lib, earth, tmp_path):
+    """`bench.py --gpus 2` exactly as the driver launches it for N = 2 — `python -m torch.distributed.run --nproc-per-node 2 ...` — on a
+    box with ONE GPU: RTTNW_BENCH_ONE_DEVICE=1 puts both ranks on device 0 and takes gloo for the barriers, the max-over-ranks and
+    the gather (RCCL refuses two ranks on one device); the tile partition, each rank's launches, the packed buffers, the un-tile
+    and the JSON line are the N-GPU code path.  Checked: ONE JSON line with n_gpus 2 and the weak-scaling workload (configs[3]'s
+    frame, final_scene 1600x1600, spp = per-GPU spp x 2), value consistent with ms_per_step, and the frame rank 0 assembled is
+    BIT-identical to the single-rank render of the same frame (fresh children, launched before anything touches the GPU in them).
+    No 8-GPU node has been available: this is a rehearsal of the mechanics, not a scaling measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = str(tmp_path / "frame.npz")
+    env = dict(os.environ, RTTNW_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0",
+           "--spp", "3", "--no-other", "--dump-image", dump]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["unit"] == "Msamples/s"
+    assert d["config"]["workload"].startswith("final_scene 1600x1600 spp=6"), d["config"]["workload"]
+    assert abs(d["value"] - 1600 * 1600 * 6 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
+    cam, p = util.params_for(setup, 1600, 1600, 6, precision=abi.F64, seed=1)
+    lin, rgba, _ = gpu_render(gpu, sc, cam, p)
+    got = np.load(dump)
+    assert np.array_equal(got["linear"], lin) and np.array_equal(got["rgba8"], rgba)
+

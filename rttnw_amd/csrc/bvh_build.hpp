@@ -58,4 +58,8 @@ int device_tree_download(const DeviceTree& tree, Bvh4Node* out4, BvhNode* out2, 
 int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centroid_bounds, bool sah, DeviceTree& out, double* kernel_ms, std::string& err);
 int device_tree_rebase(DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& err);
 
+// The scene's f32 4-wide records (on the current device) -> the quantised records the f64 decoupled kernel walks (rt_types.hpp
+// Bvh4QNode, bvh_quant.hpp), index for index, into d_out[0, n).  Synchronous.
+int quant4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4QNode* d_out, std::string& err);
+
 } // namespace rt

@@ -62,6 +62,7 @@ template <typename T> struct DevBuf {
 template <typename R> struct DeviceScene {
     bool ready = false;
     DevBuf<Bvh4Node> nodes;
+    DevBuf<Bvh4QNode> nodes4q;   // the same records with quantised boxes (made on first use by the f64 decoupled kernel, ensure_quant4)   // the traversal-stack bound of those trees (FlatScene::stack_depth is the 4-wide trees')
     DevBuf<SphereRec<R>> spheres;
     DevBuf<int32_t> sphere_mat, sphere_seq;
     DevBuf<MovingSphereRec<R>> moving;
@@ -105,6 +106,18 @@ template <typename R> struct DeviceScene {
                 HIP_TRY(hipMemcpy(nodes.p + t.base4, f.nodes4.data() + t.base4, size_t(t.count4) * sizeof(Bvh4Node), hipMemcpyHostToDevice));
             }
         }
+        return 0;
+    }
+
+    // The f64 decoupled kernel's node records, made on this device from the f32 ones the first time that kernel is chosen.
+    int ensure_quant4(const FlatScene& f) {
+        if (nodes4q.p) return 0;
+        const uint32_t n = f.total_nodes4();
+        HIP_TRY(hipMalloc((void**)&nodes4q.p, std::max<size_t>(n, 1) * sizeof(Bvh4QNode)));
+        nodes4q.n = n;
+        std::string err;
+        if (int rc = quant4_build_device(nodes.p, n, nodes4q.p, err)) { set_last_error(err); nodes4q.release(); return rc; }
+        view.nodes4q = nodes4q.p;
         return 0;
     }
 
@@ -153,7 +166,7 @@ template <typename R> struct DeviceScene {
             (rc = texs.upload(tx)) || (rc = images.upload(f.images)) || (rc = texels.upload(f.texels)) ||
             (rc = perlin_vec.upload(pv)) || (rc = perlin_perm.upload(f.perlin_perm)))
             return rc;
-        view.nodes = nodes.p; view.spheres = spheres.p; view.sphere_mat = sphere_mat.p; view.sphere_seq = sphere_seq.p;
+        view.nodes = nodes.p; view.nodes4q = nullptr; view.spheres = spheres.p; view.sphere_mat = sphere_mat.p; view.sphere_seq = sphere_seq.p;
         view.moving = moving.p; view.rects = rects.p; view.boxes = boxes.p; view.insts = insts.p; view.media = media.p; view.medium_refs = medium_refs.p;
         view.mats = mats.p; view.texs = texs.p; view.images = images.p; view.texels = texels.p;
         view.perlin_vec = perlin_vec.p; view.perlin_perm = perlin_perm.p;
@@ -165,7 +178,7 @@ template <typename R> struct DeviceScene {
         return 0;
     }
     void release() {
-        nodes.release(); spheres.release(); sphere_mat.release(); sphere_seq.release(); moving.release(); rects.release();
+        nodes.release(); nodes4q.release(); spheres.release(); sphere_mat.release(); sphere_seq.release(); moving.release(); rects.release();
         boxes.release(); insts.release(); media.release(); medium_refs.release(); mats.release(); texs.release(); images.release();
         texels.release(); perlin_vec.release(); perlin_perm.release();
         ready = false;

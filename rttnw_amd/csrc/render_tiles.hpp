@@ -159,6 +159,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             }
         } else {
             const bool gen = s->flat.needs_general;
+            if constexpr (wave_walks_quantised<R>())
+                if (int q4 = ds.ensure_quant4(s->flat)) return q4; // this kernel walks the quantised records: made here, on the device, once
             auto kernel = count ? (gen ? trace_kernel<R, true, true> : trace_kernel<R, true, false>) : (gen ? trace_kernel<R, false, true> : trace_kernel<R, false, false>);
             const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
             size_t grid = 1;

@@ -805,24 +805,26 @@ RT_HD void pair_swap(uint32_t& ka, int32_t& ca, uint32_t& kb, int32_t& cb) { // 
     const int32_t c0 = sw ? cb : ca, c1 = sw ? ca : cb;
     ka = k0; kb = k1; ca = c0; cb = c1;
 }
-template <typename R, typename Stack, typename Cnt>
-RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
-    Planes4 nd;
-    stack.fetch(sc, tr.node, tr.near_off, nd); // from global memory, or from LDS when the kernel keeps the tree there
-    cnt.node();
-    float lo_t, hi_t;
-    slab_range(t_min, tr.closest, lo_t, hi_t);
-    constexpr uint32_t MISS = 0xFFFFFFFFu;
-    uint32_t k[4];
-    int32_t ch[4];
-    float e[4];
-    bool h[4];
-    slab_hit4<slab_form<Stack, R>()>(nd, tr.ray.o, tr.sr, lo_t, hi_t, e, h);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        ch[c] = nd.child[c];
-        k[c] = (h[c] && ch[c] != CHILD_EMPTY) ? float_bits(e[c]) : MISS; // entry distances are positive: their bit patterns order like the values
-    }
+// ---- helpers of the step over QUANTISED records (rt_types.hpp Bvh4QNode; trav_node_step4q below) ----
+template <typename R> RT_HD float slab_inv_of(const SlabRay<R>& sr, int a) {
+    if constexpr (sizeof(R) == 8) return sr.inv[a];
+    else return a == 0 ? sr.inv.x : (a == 1 ? sr.inv.y : sr.inv.z);
+}
+RT_HD float bits_float(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+// The second half of a 4-wide node step: order the (key, child) pairs (key = the bits of the entry distance, MISS_KEY for a miss),
+// descend into the nearest hit child, push the others farthest first.
+constexpr uint32_t MISS_KEY = 0xFFFFFFFFu;
+template <typename R, typename Stack>
+RT_HD void trav_descend_sorted4(Trav<R>& tr, const Ray<R>& wray, Stack& stack, uint32_t* k, int32_t* ch) {
+    constexpr uint32_t MISS = MISS_KEY;
     pair_swap(k[0], ch[0], k[1], ch[1]); pair_swap(k[2], ch[2], k[3], ch[3]); pair_swap(k[0], ch[0], k[2], ch[2]);
     pair_swap(k[1], ch[1], k[3], ch[3]); pair_swap(k[1], ch[1], k[2], ch[2]);
     if (k[0] == MISS) { trav_pop(tr, wray, stack); return; }
@@ -842,6 +844,84 @@ RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     }
     tr.sp = sp + n_push;
     tr.node = ch[0];
+}
+template <typename R, typename Stack, typename Cnt>
+RT_HD void trav_node_step4(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
+    Planes4 nd;
+    stack.fetch(sc, tr.node, tr.near_off, nd); // from global memory, or from LDS when the kernel keeps the tree there
+    cnt.node();
+    float lo_t, hi_t;
+    slab_range(t_min, tr.closest, lo_t, hi_t);
+    constexpr uint32_t MISS = 0xFFFFFFFFu;
+    uint32_t k[4];
+    int32_t ch[4];
+    float e[4];
+    bool h[4];
+    slab_hit4<slab_form<Stack, R>()>(nd, tr.ray.o, tr.sr, lo_t, hi_t, e, h);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ch[c] = nd.child[c];
+        k[c] = (h[c] && ch[c] != CHILD_EMPTY) ? float_bits(e[c]) : MISS; // entry distances are positive: their bit patterns order like the values
+    }
+    trav_descend_sorted4(tr, wray, stack, k, ch);
+}
+// ---- the same step over a 4-wide QUANTISED record (rt_types.hpp Bvh4QNode: four 16-byte pieces instead of the f32 record's seven).
+// Plane distances: with D = org - o, A = D inv, S = step inv (step a power of two: exact), a child's plane at org + q step lies at
+//   t = q S + A,                          one v_cvt_f32_ubyte + one fma per plane.
+// Conservative as the f64 kernels' f32-record test is (a box the exact test passes always passes): D is rounded once (|e| <= 2^-24;
+// the f64 kernels subtract in double first, so no |o| 2^-24 term appears), inv is the walk's 1-ulp reciprocal of the rounded
+// direction (|e| <= 1.8e-7), A's product and the fma round once each:
+//   |t32 - t| <= 3.6e-7 |t| + 4.8e-7 |q S|  <=  3.6e-7 |t| + 1.23e-4 max_a |S_a|      (q <= 255),
+// so the entry moves down and the exit up by 4e-7 |t| + K, K = 1.5e-4 max_a |S_a| per record — a fma each: t (1 -+ 4e-7) -+ K is
+// that widening for t >= 0, and a negative entry cannot set the walk's entry (t_min >= 0 does: render_api.cpp validate), a negative
+// exit is a box behind the origin.  An axis the ray is parallel to gets NaN distances, which maxNum / minNum drop: it never culls.
+// The children are ordered exactly, by entry distance, as in trav_node_step4.
+template <typename R, typename Stack, typename Cnt>
+RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
+    uint32_t w[16]; // pieces 0-3 of the record
+    stack.fetch4q(sc, tr.node, w);
+    cnt.node();
+    float lo_t, hi_t;
+    slab_range(t_min, tr.closest, lo_t, hi_t);
+    const R oo[3] = {tr.ray.o.x, tr.ray.o.y, tr.ray.o.z};
+    float A[3], S[3];
+    uint32_t near_w[3], far_w[3]; // the four children's near / far plane bytes of axis a
+    float smax = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float inv = slab_inv_of(tr.sr, a);
+        if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
+        const bool neg = inv < 0.f;
+        const float D = float(R(bits_float(w[a])) - oo[a]);
+        A[a] = D * inv;
+        S[a] = bits_float(((w[3] >> (8 * a)) & 0xFFu) << 23) * inv;
+        smax = rt_max(smax, rt_fabs(S[a]));
+        const uint32_t l = w[4 + 2 * a], h = w[5 + 2 * a];
+        near_w[a] = neg ? h : l;
+        far_w[a] = neg ? l : h;
+    }
+    const float K = smax * 1.5e-4f;
+    uint32_t k[4];
+    int32_t ch[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ch[c] = int32_t(w[12 + c]);
+        const int sh = 8 * c;
+        const float nx = __builtin_fmaf(float((near_w[0] >> sh) & 0xFFu), S[0], A[0]), fx = __builtin_fmaf(float((far_w[0] >> sh) & 0xFFu), S[0], A[0]);
+        const float ny = __builtin_fmaf(float((near_w[1] >> sh) & 0xFFu), S[1], A[1]), fy = __builtin_fmaf(float((far_w[1] >> sh) & 0xFFu), S[1], A[1]);
+        const float nz = __builtin_fmaf(float((near_w[2] >> sh) & 0xFFu), S[2], A[2]), fz = __builtin_fmaf(float((far_w[2] >> sh) & 0xFFu), S[2], A[2]);
+        const float tn = rt_max(nz, rt_max(ny, nx)), tf = rt_min(fz, rt_min(fy, fx));
+        const float n = __builtin_fmaf(tn, 1.f - 4e-7f, -K), f = __builtin_fmaf(tf, 1.f + 4e-7f, K);
+        const float lo = rt_max(n, lo_t), hi = rt_min(f, hi_t); // maxNum / minNum: a NaN drops out
+        k[c] = (!(hi < lo) && ch[c] != CHILD_EMPTY) ? float_bits(lo) : MISS_KEY;
+    }
+    trav_descend_sorted4(tr, wray, stack, k, ch);
+}
+
+template <typename R, typename Stack, typename Cnt>
+RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
+    if constexpr (Stack::WIDE == NODES_Q8X4) trav_node_step4q(tr, sc, wray, t_min, stack, cnt); // quantised records (the f64 decoupled kernel)
+    else trav_node_step4(tr, sc, wray, t_min, stack, cnt);
 }
 
 // One step at a leaf (tr.node < 0, not TRAV_DONE): enter an instance, or test ONE primitive record.  WHOLE_LEAF tests

@@ -67,6 +67,27 @@ struct alignas(16) Bvh4Node {
 };
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 constexpr uint32_t BVH4_USED_SIXTEENTHS = 7; // 16-byte pieces of a record that carry data (the LDS copy leaves the pad out)
+
+// What the f64 DECOUPLED kernel walks (trees that live in HBM / the Infinity Cache): the same 4-wide record with QUANTISED boxes, 64
+// bytes — two records to a 128-byte line, FOUR 16-byte pieces a visit instead of seven, the tree itself unchanged (record i = 4-wide
+// record i: same children in the same slots, same stack bound).  Made from the f32 records on the device (bvh_quant.hpp).
+//   piece 0  org[3]: the lower corner of the box around the children; ex[3]: the quantisation step of axis a is 2^(ex[a] - 127)
+//   piece 1  q_lo[4], q_hi[4] of x, then of y: child c's box is [org + q_lo[c] step, org + q_hi[c] step], q_lo rounded DOWN and q_hi UP
+//            (the boxes only cull: a dequantised box contains the f32 box it was made from); an unused slot has q_lo 255, q_hi 0
+//   piece 2  q_lo[4], q_hi[4] of z;   piece 3  child[4], coded like Bvh4Node::child
+// Measured (profiles/r04/README.md): spheres_1m f64 277 -> 289 Msamples/s, RTTNW_F64_STRICT 269 -> 288, half the node bytes; the f32
+// kernel, which is bound by vector-instruction issue, LOSES 2 % to the record's per-visit set-up and keeps the f32 records; an 8-wide
+// quantised record (96 bytes, six pieces, 21 % fewer visits, twice the instructions per visit) lost 40 %.
+struct alignas(16) Bvh4QNode {
+    float org[3];
+    uint8_t ex[3];
+    uint8_t n_children;
+    uint8_t q[3][2][4]; // [axis][0 lo / 1 hi][slot]
+    uint8_t pad[8];
+    int32_t child[4];
+};
+static_assert(sizeof(Bvh4QNode) == 64, "Bvh4QNode must be 64 bytes");
+enum : int { NODES_F32X4 = 4, NODES_Q8X4 = 44 }; // what a traversal stack type walks (Stack::WIDE)
 // Traversal stack: the first LDS_STACK_ENTRIES entries of a lane live in LDS, deeper ones (a 4-wide walk can have three
 // pending children per level, but rarely has) in a per-lane strip of global memory.
 #ifndef RT_LDS_STACK_ENTRIES // (12 / 10 / 8 entries: final_scene f32 -0.4 / -1.5 / -2.5 %)
@@ -163,6 +184,7 @@ template <typename R> struct CameraRec { // Camera — camera.rs:18-29
 // Everything a lane needs, by pointer.  Same struct for HBM- and LDS-resident node/primitive arrays.
 template <typename R> struct SceneView {
     const Bvh4Node* nodes;
+    const Bvh4QNode* nodes4q; // the same trees as quantised records, index for index (the f64 decoupled kernel; else null)
     const SphereRec<R>* spheres;
     const int32_t* sphere_mat;
     const int32_t* sphere_seq; // list-order sequence numbers, read only to break exact ties in t

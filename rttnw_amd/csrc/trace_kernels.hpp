@@ -20,6 +20,9 @@
 #include "render_common.hpp"
 #include "trace_tally.hpp"
 
+#ifndef RT_WAVE_QUANT
+#define RT_WAVE_QUANT 1 // which decoupled kernels walk the quantised records (rt_types.hpp Bvh4QNode): 1 the f64 ones (measured: +4 / +7 %; f32 -2 %), 2 all, 0 none
+#endif
 #ifndef RT_F64_BLOCK
 #define RT_F64_BLOCK 1024 // threads per block of the LDS-resident f64 kernel (4 waves/SIMD at 128 VGPRs; see the Makefile's f64 flags and profiles/r03/README.md)
 #endif
@@ -37,6 +40,7 @@ inline namespace RT_ARITH_NS {
 typedef __attribute__((address_space(3))) int32_t* LdsIntPtr;    // explicit address spaces: the compiler otherwise merges
 typedef __attribute__((address_space(1))) int32_t* GlobalIntPtr; // the two halves of get() into one FLAT load
 template <uint32_t STRIDE, uint32_t ENTRIES = LDS_STACK_ENTRIES> struct LdsStack { // STRIDE = lanes sharing the LDS stack area: entry e of a lane at base[e * STRIDE]; ENTRIES kept in LDS
+    static constexpr int WIDE = NODES_F32X4;    // walks Bvh4Node records
     static constexpr int SLAB_F32 = SLAB_EXACT; // node records in global memory: the f32 kernels' exact slab test (rt_core.hpp)
     static constexpr int SPARE = int(ENTRIES); // a lane's extra LDS slot: target of the node step's masked-off stores
     LdsIntPtr base;        // &lds[threadIdx.x]
@@ -64,13 +68,18 @@ template <uint32_t STRIDE, uint32_t ENTRIES = LDS_STACK_ENTRIES> struct LdsStack
             u.q[3 + a] = rec[2u * a + 3u - near_off[a]]; // the other one of (a, a + 3)
         }
         u.q[6] = rec[6];
-#if defined(RT_EXP_EXTRA_LOADS)   // experiment: is the walk bound by the L1's rate of divergent accesses?  one more 16-byte read of the SAME line per visit (the pad: zeros)
-        {
-            const int4 extra = rec[7];
-            u.q[6].x |= extra.x; u.q[6].y |= extra.y; u.q[6].z |= extra.z; u.q[6].w |= extra.w;
-        }
-#endif
         __builtin_memcpy(&out, &u, sizeof(out));
+    }
+};
+// The f64 decoupled kernel's: walks the quantised records (rt_types.hpp Bvh4QNode) — four 16-byte reads of one line per visit.
+template <uint32_t STRIDE, uint32_t ENTRIES> struct LdsStackQuant4 : LdsStack<STRIDE, ENTRIES> {
+    static constexpr int WIDE = NODES_Q8X4;
+    template <typename R> __device__ __forceinline__ void fetch4q(const SceneView<R>& sc, int32_t i, uint32_t* w) const {
+        const int4* rec = reinterpret_cast<const int4*>(sc.nodes4q + i);
+        int4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = rec[k];
+        __builtin_memcpy(w, q, 64);
     }
 };
 // Same, with the whole node array resident in LDS in PIECE-MAJOR order: the q-th 16 bytes of node i at
@@ -142,6 +151,7 @@ template <typename R> __host__ __device__ constexpr uint32_t wave_stack_entries(
 template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
     return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (wave_stack_entries<R>() + 1u) * 64u * 4u; // stack: + the spare slot
 }
+template <typename R> __host__ __device__ constexpr bool wave_walks_quantised() { return RT_WAVE_QUANT == 2 || (RT_WAVE_QUANT == 1 && sizeof(R) == 8); }
 constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
 
 // The per-pixel sample loop of main.rs:202-229 as ONE persistent kernel in which PATHS ARE DECOUPLED FROM LANES.
@@ -194,7 +204,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
     int32_t* const hq_prim = reinterpret_cast<int32_t*>(rq_slot + QCAP);
     int32_t* const hq_inst = hq_prim + QCAP;
     uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
-    LdsStack<64, wave_stack_entries<R>()> stack{(LdsIntPtr)(reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane), (GlobalIntPtr)(spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x)), gridDim.x * TRACE_BLOCK};
+    typename std::conditional<wave_walks_quantised<R>(), LdsStackQuant4<64, wave_stack_entries<R>()>, LdsStack<64, wave_stack_entries<R>()>>::type stack;
+    stack.base = (LdsIntPtr)(reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane);
+    stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x));
+    stack.spill_stride = gridDim.x * TRACE_BLOCK;
 
     const uint32_t wave_global = blockIdx.x * (TRACE_BLOCK / 64) + wave_in_block;
     const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;

@@ -4,6 +4,7 @@
 // no CPU fallback.  Job order and per-job accumulation mirror trace_kernels.hpp's trace kernel exactly.
 #include "../../include/rttnw_hip.h"
 #include "../../rttnw_amd/csrc/rt_core.hpp"
+#include "../../rttnw_amd/csrc/bvh_quant.hpp"
 #include "../../rttnw_amd/csrc/scene_handle.hpp"
 
 #include <algorithm>
@@ -28,6 +29,7 @@ using namespace rt;
 std::atomic<int> g_max_stack{0}; // deepest traversal-stack index written since the last hostsim_max_stack() call
 
 struct HostStack { // shaped like the device's: 16 entries + a spare slot "in LDS", the rest in a spill strip
+    static constexpr int WIDE = NODES_F32X4;
     static constexpr int SLAB_F32 = SLAB_EXACT;
     static constexpr int SPARE = 16;
     int32_t lds[17];
@@ -52,6 +54,11 @@ struct HostStack { // shaped like the device's: 16 entries + a spare slot "in LD
     }
 };
 
+struct HostStack4Q : HostStack { // the f64 decoupled kernel's: walks the quantised records (bvh_quant.hpp, made on the host here)
+    static constexpr int WIDE = NODES_Q8X4;
+    template <typename R> void fetch4q(const SceneView<R>& sc, int32_t i, uint32_t* w) const { std::memcpy(w, &sc.nodes4q[i], 64); }
+};
+
 template <typename R> struct HostScene {
     std::vector<SphereRec<R>> spheres;
     std::vector<MovingSphereRec<R>> moving;
@@ -63,6 +70,12 @@ template <typename R> struct HostScene {
     std::vector<TextureRec<R>> texs;
     std::vector<R> perlin_vec;
     SceneView<R> view;
+    std::vector<Bvh4QNode> nodes4q; // HOSTSIM_QUANT=1: the f64 decoupled kernel's records, made by the same per-record function as on the device
+    void make_quant4(const FlatScene& f) {
+        nodes4q.resize(f.nodes4.size());
+        for (size_t i = 0; i < f.nodes4.size(); ++i) quant4_make(f.nodes4.data(), int32_t(i), nodes4q[i]);
+        view.nodes4q = nodes4q.data();
+    }
     explicit HostScene(const FlatScene& f) {
         for (auto& s : f.spheres) spheres.push_back({R(s.cx), R(s.cy), R(s.cz), R(s.r)});
         for (auto& m : f.moving) {
@@ -92,6 +105,7 @@ template <typename R> struct HostScene {
         for (auto& t : f.texs) texs.push_back({t.type, t.a, t.b, 0, {R(t.color[0]), R(t.color[1]), R(t.color[2])}, R(t.scale)});
         for (double v : f.perlin_vec) perlin_vec.push_back(R(v));
         view.nodes = f.nodes4.data();
+        view.nodes4q = nullptr;
         view.spheres = spheres.data(); view.sphere_mat = f.sphere_mat.data(); view.sphere_seq = f.sphere_seq.data();
         view.moving = moving.data(); view.rects = rects.data(); view.boxes = boxes.data();
         view.insts = insts.data(); view.media = media.data(); view.medium_refs = f.medium_refs.data(); view.mats = mats.data(); view.texs = texs.data();
@@ -111,10 +125,11 @@ template <typename R> CameraRec<R> narrow_camera(const CameraRec<double>& c) {
     return o;
 }
 
-template <typename R>
+template <typename R, typename StackT>
 int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear, rttnw_stats* stats,
              int n_threads) {
     HostScene<R> hs(s->flat);
+    if (StackT::WIDE == NODES_Q8X4) hs.make_quant4(s->flat);
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
                 cam->focus_distance, cam->open_time, cam->close_time, cam64);
@@ -130,7 +145,7 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
     std::atomic<uint32_t> next_row{0};
     std::vector<LaneCounters> counters(n_threads);
     auto worker = [&](int tid) {
-        HostStack stack;
+        StackT stack;
         LaneCounters& cnt = counters[tid];
         for (;;) {
             uint32_t row = next_row.fetch_add(1);
@@ -267,8 +282,13 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
         if (int rc = lower_scene(s->graph, wider, err, nullptr, std::min(s->flat.time0, cam->open_time), std::max(s->flat.time1, cam->close_time))) return rc;
         s->flat = std::move(wider);
     }
-    return p->precision == RTTNW_F32 ? render_t<float>(s, cam, p, out_linear, stats, n_threads)
-                                     : render_t<double>(s, cam, p, out_linear, stats, n_threads);
+    // HOSTSIM_QUANT=1: walk the quantised records of the f64 decoupled kernel (rt_core.hpp trav_node_step4q) instead of the f32 ones
+    const char* q = getenv("HOSTSIM_QUANT");
+    if (q && q[0] == '1')
+        return p->precision == RTTNW_F32 ? render_t<float, HostStack4Q>(s, cam, p, out_linear, stats, n_threads)
+                                         : render_t<double, HostStack4Q>(s, cam, p, out_linear, stats, n_threads);
+    return p->precision == RTTNW_F32 ? render_t<float, HostStack>(s, cam, p, out_linear, stats, n_threads)
+                                     : render_t<double, HostStack>(s, cam, p, out_linear, stats, n_threads);
 }
 // Chunk schedule and launch split of a render (rt_types.hpp plan_chunks / launch_chunks + rt_core.hpp plan_jobs) as a rank that
 // owns rank_tiles 8x8 tiles sees it: out = {spp_chunk, n_main, n_chunks of the whole render, chunks per launch, launches, n_jobs

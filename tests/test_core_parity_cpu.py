@@ -270,3 +270,22 @@ def test_ball_draw_shortcut_is_the_full_rejection_loop(hostsim):
     assert not todo.any() and np.array_equal(out64, want)
     same = np.abs(out32 - want32).max(axis=1) <= 2e-7          # f32 accepted the same candidate (all but those on the sphere's f32 skin)
     assert same.mean() > 0.9999 and ((out32.astype(np.float64) ** 2).sum(axis=1) < 1.0 + 1e-6).all()
+
+
+@pytest.mark.parametrize("name,param,w,h,spp", [("cornell_box", 0, 48, 48, 6), ("final_scene", 0, 48, 48, 6), ("spheres_1m", 30000, 64, 64, 6),
+                                                ("random_scene", 0, 64, 36, 6), ("smoke_cornell_box", 0, 40, 40, 4)])
+def test_quantised_records_never_change_an_image(hostsim, scenes_lib, earth, name, param, w, h, spp, monkeypatch):
+    """The f64 decoupled kernel walks the trees through quantised records (rt_types.hpp Bvh4QNode, made by bvh_quant.hpp from the f32
+    records; rt_core.hpp trav_node_step4q).  The host build of the same code (HOSTSIM_QUANT=1): conservative boxes only ever OPEN more
+    nodes, so the image is bit-identical in both precisions and the same world.hit() calls are made; the visits grow by a few per cent."""
+    sc, setup = util.build(hostsim, scenes_lib, name, earth, param)
+    for prec in (abi.F64, abi.F32):
+        cam, p = util.params_for(setup, w, h, spp, precision=prec, collect_counters=1, seed=9)
+        monkeypatch.delenv("HOSTSIM_QUANT", raising=False)
+        a, sta = util.hostsim_render(hostsim, sc, cam, p)
+        monkeypatch.setenv("HOSTSIM_QUANT", "1")
+        b, stb = util.hostsim_render(hostsim, sc, cam, p)
+        assert np.array_equal(a, b) and sta.rays == stb.rays
+        assert sta.nodes_visited <= stb.nodes_visited <= sta.nodes_visited * 1.25
+        assert sta.prims_tested <= stb.prims_tested
+

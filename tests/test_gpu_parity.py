@@ -325,15 +325,14 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
         if precision == abi.F64 or form == "plainglobal":
             assert np.array_equal(out[form][0], out["plain"][0]), form
             assert np.array_equal(out[form][1], out["plain"][1]), form
-            if precision == abi.F64:
+            if precision == abi.F64 and form == "plainglobal":
                 assert out[form][2:] == out["plain"][2:], form  # the same world.hit() calls, node visits and record tests
-            else:
-                # the f32 LDS-node kernel tests boxes with the conservative fma form (rt_core.hpp SLAB_FMA_FOLDED): a box a ray
-                # grazes within ~1e-6 is also opened, which never changes a hit — the same rays, a few more visits
+            elif precision == abi.F64:
+                # the f64 decoupled kernel walks the same trees through QUANTISED records (rt_types.hpp Bvh4QNode: conservative 8-bit
+                # boxes): the same world.hit() calls and — bit for bit — the same image; a few more visits and record tests behind the
+                # looser boxes (a scene with one huge and many small objects in a node, random_scene's ground sphere, is where they show)
                 assert out[form][2] == out["plain"][2], form
-                # (cornell_box: 1.1 % more record tests — rays leaving a wall graze the flat boxes of the wall's own leaf)
-                assert out[form][3] <= out["plain"][3] <= out[form][3] * 1.005, form
-                assert out[form][4] <= out["plain"][4] <= out[form][4] * 1.02, form
+                assert out["plain"][3] <= out[form][3] <= out["plain"][3] * 1.25 and out["plain"][4] <= out[form][4] <= out["plain"][4] * 1.25, (form, out[form][2:], out["plain"][2:])
         else:
             # f32 is compiled with -ffp-contract=fast: the two kernels may fuse a multiply-add differently, and a path
             # whose hit sits within an ulp of a decision goes another way (measured: 1 pixel of 4032 on final_scene)

@@ -53,7 +53,14 @@ inline uint64_t sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
     uint64_t k1 = mix64(k0 + pixel * 0xD1B54A32D192ED03ull);
     return mix64(k1 + sample * 0x8CB92BA72F3D8DD7ull);
 }
-inline uint64_t keyed_word(uint64_t key, uint32_t ctr) { return mix64(key + (uint64_t(ctr) + 1) * GAMMA); }
+// The word of a draw: the Weyl step on the sample's key, then a mixer of two multiplications by 32-bit
+// constants between three folds of the high half into the low one (the sample keys and the scene streams keep SplitMix64's finaliser).
+inline uint64_t draw_mix(uint64_t z) {
+    z ^= z >> 32; z *= 0x9E3779B1ull;
+    z ^= z >> 32; z *= 0x85EBCA6Bull;
+    z ^= z >> 32; return z;
+}
+inline uint64_t keyed_word(uint64_t key, uint32_t ctr) { return draw_mix(key + (uint64_t(ctr) + 1) * GAMMA); }
 inline double keyed_uniform(uint64_t key, uint32_t ctr) {
     return double(keyed_word(key, ctr) >> 11) * (1.0 / 9007199254740992.0); // 53 bits, [0,1) like rand's gen::<f64>()
 }
@@ -130,13 +137,16 @@ struct PathCtx {
 };
 
 // Vec3f::random_in_unit_space — vec3.rs:149-160 (rejection in the unit BALL, three uniforms per iteration).
-// Draw spec of the keyed generator for these: iteration `it` owns slots 32 + 4 it .. 32 + 4 it + 3; the word
-// of the first gives the 21 leading bits of the three uniforms, the words of the other three their remaining 32 bits.
+// Draw spec of the keyed generator for these: iteration `it` owns slots 32 + 4 it .. 32 + 4 it + 2; the word
+// of the first gives the 21 leading bits of the three uniforms, the words of the other two their remaining 32 bits each (the high
+// and the low half of the second word, the high half of the third).
 inline double ball_uniform(const PathCtx& ctx, uint32_t it, int c) {
     const uint64_t h = keyed_word(ctx.key, ctr_of(ctx.bounce + 1, SLOT_SCATTER + 4 * it));
-    const uint64_t low = keyed_word(ctx.key, ctr_of(ctx.bounce + 1, SLOT_SCATTER + 4 * it + 1 + uint32_t(c)));
+    const uint64_t second = keyed_word(ctx.key, ctr_of(ctx.bounce + 1, SLOT_SCATTER + 4 * it + 1));
+    const uint64_t third = keyed_word(ctx.key, ctr_of(ctx.bounce + 1, SLOT_SCATTER + 4 * it + 2));
     const uint64_t field = c == 0 ? h >> 43 : (c == 1 ? (h >> 22) & 0x1FFFFFull : (h >> 1) & 0x1FFFFFull);
-    return double((field << 32) | (low >> 32)) * (1.0 / 9007199254740992.0);
+    const uint64_t low = c == 0 ? second >> 32 : (c == 1 ? second & 0xFFFFFFFFull : third >> 32);
+    return double((field << 32) | low) * (1.0 / 9007199254740992.0);
 }
 inline V3 random_in_unit_space(const PathCtx& ctx) {
     for (uint32_t it = 0;; ++it) {

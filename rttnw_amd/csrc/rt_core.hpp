@@ -173,21 +173,33 @@ template <typename R> struct Ray { // ray.rs:9-27
 };
 
 // ---------------------------------------------------------------- keyed RNG (DESIGN.md "RNG")
-// U = mix64(key + (ctr+1)*GAMMA) with key = f(seed, pixel, sample): every draw is addressed by
+// U = mixd(key + (ctr+1)*GAMMA) with key = f(seed, pixel, sample): every draw is addressed by
 // (pixel, sample, bounce, slot), so results do not depend on traversal order, lane assignment,
 // work stealing or GPU count.  f64 uniform = top 53 bits, f32 uniform = top 24 bits of the SAME word.
 constexpr uint64_t RNG_GAMMA = 0x9E3779B97F4A7C15ull;
-RT_HD uint64_t mix64(uint64_t z) {
+RT_HD uint64_t mix64(uint64_t z) { // SplitMix64's finaliser: the sample keys (two per sample) and the scene streams
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
     z ^= z >> 27; z *= 0x94D049BB133111EBull;
     return z ^ (z >> 31);
+}
+// The mixer of a DRAW (round 4; ~40 of them per sample): three folds of the high word into the low one around two multiplications by
+// 32-BIT constants.  On gfx950 a 64 x 64-bit product is three quarter-rate instructions and a shift by 27-31 three more operations;
+// a product with a 32-bit constant is two, a fold by exactly 32 one xor: 4 quarter-rate + 5 full-rate instructions a draw against
+// mix64's 6 + 13 (a quarter of the f64 kernels' vector instructions were integer, the keyed hash the largest part).  The key is a
+// mix64 output and the counter enters through the Weyl step, so the weaker avalanche of a two-round 32-bit mixer is spent on
+// inputs that are already mixed; tests/test_rng_quality.py holds the draws of a path to uniformity, pairwise independence over the
+// counters a path uses, serial independence over adjacent samples and the unit-ball acceptance rate.
+RT_HD uint64_t mixd(uint64_t z) {
+    z ^= z >> 32; z *= 0x9E3779B1ull;
+    z ^= z >> 32; z *= 0x85EBCA6Bull;
+    return z ^ (z >> 32);
 }
 RT_HD uint64_t sample_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
     uint64_t k0 = mix64(seed + RNG_GAMMA);
     uint64_t k1 = mix64(k0 + pixel * 0xD1B54A32D192ED03ull);
     return mix64(k1 + sample * 0x8CB92BA72F3D8DD7ull);
 }
-RT_HD uint64_t rng_word(uint64_t key, uint32_t ctr) { return mix64(key + (uint64_t(ctr) + 1) * RNG_GAMMA); }
+RT_HD uint64_t rng_word(uint64_t key, uint32_t ctr) { return mixd(key + (uint64_t(ctr) + 1) * RNG_GAMMA); }
 template <typename R> RT_HD R uniform01(uint64_t key, uint32_t ctr);
 template <> RT_HD double uniform01<double>(uint64_t key, uint32_t ctr) {
     return double(rng_word(key, ctr) >> 11) * (1.0 / 9007199254740992.0);
@@ -220,23 +232,24 @@ RT_HD uint32_t rng_ctr(uint32_t block, uint32_t slot) { return block * 1024u + s
 // Vec3f::random_in_unit_space — vec3.rs:149-160: rejection sampling of the unit BALL:
 //     loop { v = 2 (U, U, U) - 1; if |v|^2 < 1 return v }
 // A wave runs this loop to the iteration count of its unluckiest lane — about six trips for a mean of 1.9 — and what a trip
-// costs is its 64-bit hashes (two 64-bit multiplies each: quarter-rate integer work): with one hash per uniform the loop was
+// costs is its 64-bit hashes (quarter-rate integer multiplies): with one hash per uniform the loop was
 // 12 % of the f64 kernel.  So the three uniforms of a candidate are drawn HIERARCHICALLY: one word H
-// gives the 21 leading bits of each, three more words give their remaining 32 bits,
-//     u_c = ( field_c(H) * 2^32 + (L_c >> 32) ) * 2^-53,   field_0 = H >> 43, field_1 = (H >> 22) & 0x1FFFFF, field_2 = (H >> 1) & 0x1FFFFF,
-// slots 32 + 4 i (H) and 32 + 4 i + 1 + c (L_c) of iteration i: still 53 independent uniform bits per coordinate.  H alone
+// gives the 21 leading bits of each, TWO more words (round 4: their 96 leading bits; round 3 spent three words) their remaining 32,
+//     u_c = ( field_c(H) * 2^32 + low_c ) * 2^-53,   field_0 = H >> 43, field_1 = (H >> 22) & 0x1FFFFF, field_2 = (H >> 1) & 0x1FFFFF,
+//     low_0 = L >> 32, low_1 = L & 0xFFFFFFFF, low_2 = M >> 32,
+// slots 32 + 4 i (H), 32 + 4 i + 1 (L), 32 + 4 i + 2 (M) of iteration i: still 53 independent uniform bits per coordinate.  H alone
 // pins the candidate to a cube of side 2^-20 around (x_c): |v|^2 lies within 1.7e-6 of |x_c|^2, so unless |x_c|^2 is within
 // 4e-6 of 1 the reference's test `|v|^2 < 1` is decided without the other three words — a rejected trip costs one hash
-// instead of three — and the accepted candidate's low words are fetched once, after the loop.  The sliver in between
+// instead of three — and the accepted candidate's two low words are fetched once, after the loop.  The sliver in between
 // (4e-6 of the candidates) evaluates the full candidate.  Same algorithm, same predicate on the same candidate: the oracle
 // simply evaluates every candidate in full.
 RT_HD uint32_t ball_field(uint64_t h, int c) { return c == 0 ? uint32_t(h >> 43) : (c == 1 ? uint32_t(h >> 22) & 0x1FFFFFu : uint32_t(h >> 1) & 0x1FFFFFu); }
-template <typename R> RT_HD R ball_uniform(uint32_t field, uint64_t low_word);
-template <> RT_HD double ball_uniform<double>(uint32_t field, uint64_t low_word) {
-    return double((uint64_t(field) << 32) | (low_word >> 32)) * (1.0 / 9007199254740992.0);
+template <typename R> RT_HD R ball_uniform(uint32_t field, uint32_t low);
+template <> RT_HD double ball_uniform<double>(uint32_t field, uint32_t low) {
+    return double((uint64_t(field) << 32) | uint64_t(low)) * (1.0 / 9007199254740992.0);
 }
-template <> RT_HD float ball_uniform<float>(uint32_t field, uint64_t low_word) { // the top 24 of the same 53 bits
-    const uint32_t top = (field << 3) | uint32_t(low_word >> 61);
+template <> RT_HD float ball_uniform<float>(uint32_t field, uint32_t low) { // the top 24 of the same 53 bits
+    const uint32_t top = (field << 3) | (low >> 29);
 #if defined(__HIP_DEVICE_COMPILE__)
     float f;
     asm("v_cvt_f32_u32 %0, %1" : "=v"(f) : "v"(top));
@@ -246,8 +259,9 @@ template <> RT_HD float ball_uniform<float>(uint32_t field, uint64_t low_word) {
 #endif
 }
 template <typename R> RT_HD V3<R> ball_candidate(uint64_t key, uint32_t c, uint64_t h) {
-    const V3<R> r(ball_uniform<R>(ball_field(h, 0), rng_word(key, c + 1)), ball_uniform<R>(ball_field(h, 1), rng_word(key, c + 2)),
-                  ball_uniform<R>(ball_field(h, 2), rng_word(key, c + 3)));
+    const uint64_t l = rng_word(key, c + 1), m = rng_word(key, c + 2);
+    const V3<R> r(ball_uniform<R>(ball_field(h, 0), uint32_t(l >> 32)), ball_uniform<R>(ball_field(h, 1), uint32_t(l)),
+                  ball_uniform<R>(ball_field(h, 2), uint32_t(m >> 32)));
     return R(2) * r - V3<R>(R(1), R(1), R(1));
 }
 template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bounce) {

@@ -253,13 +253,20 @@ def test_ball_draw_shortcut_is_the_full_rejection_loop(hostsim):
     hostsim.lib.hostsim_ball.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
     assert hostsim.lib.hostsim_ball(n, keys.ctypes.data, bounce, out64.ctypes.data, out32.ctypes.data) == 0
     with np.errstate(over="ignore"):
-        word = lambda ctr: mix64(keys + np.uint64(((ctr + 1) * GAMMA) & M))   # noqa: E731
+        def mixd(z):   # the mixer of a draw: folds by 32 around two products with 32-bit constants
+            z = z.copy()
+            z ^= z >> np.uint64(32); z *= np.uint64(0x9E3779B1)
+            z ^= z >> np.uint64(32); z *= np.uint64(0x85EBCA6B)
+            return z ^ (z >> np.uint64(32))
+        word = lambda ctr: mixd(keys + np.uint64(((ctr + 1) * GAMMA) & M))   # noqa: E731
         want = np.zeros((n, 3)); want32 = np.zeros((n, 3)); todo = np.ones(n, dtype=bool)
         for it in range(64):
             base = (bounce + 1) * 1024 + 32 + 4 * it
             h = word(base)
             fields = [h >> np.uint64(43), (h >> np.uint64(22)) & np.uint64(0x1FFFFF), (h >> np.uint64(1)) & np.uint64(0x1FFFFF)]
-            m = [(f << np.uint64(32)) | (word(base + 1 + c) >> np.uint64(32)) for c, f in enumerate(fields)]
+            second, third = word(base + 1), word(base + 2)
+            lows = [second >> np.uint64(32), second & np.uint64(0xFFFFFFFF), third >> np.uint64(32)]
+            m = [(f << np.uint64(32)) | lo for f, lo in zip(fields, lows)]
             v = np.stack([2.0 * (x.astype(np.float64) * 2.0**-53) - 1.0 for x in m], axis=1)
             v32 = np.stack([2.0 * ((x >> np.uint64(29)).astype(np.float64) * 2.0**-24) - 1.0 for x in m], axis=1)
             acc = todo & ((v * v).sum(axis=1) < 1.0)

@@ -317,12 +317,14 @@ def test_materials(oracle, sc):
 
     def ball(key, bounce):
         # vec3.rs:149-160 with the keyed generator's draw spec for it: iteration `it` owns slots 32 + 4 it ..
-        # + 3; the first word gives the 21 leading bits of the three uniforms, the other three words their remaining 32 bits
+        # + 2; the first word gives the 21 leading bits of the three uniforms, the halves of the other two words their remaining 32 bits
         it = 0
         while True:
             h = oracle.probe_word(key[0], key[1], key[2], bounce + 1, 32 + 4 * it)
             fields = [h >> 43, (h >> 22) & 0x1FFFFF, (h >> 1) & 0x1FFFFF]
-            lows = [oracle.probe_word(key[0], key[1], key[2], bounce + 1, 32 + 4 * it + 1 + c) >> 32 for c in range(3)]
+            second = oracle.probe_word(key[0], key[1], key[2], bounce + 1, 32 + 4 * it + 1)
+            third = oracle.probe_word(key[0], key[1], key[2], bounce + 1, 32 + 4 * it + 2)
+            lows = [second >> 32, second & 0xFFFFFFFF, third >> 32]
             r = np.array([((f << 32) | lo) * 2.0**-53 for f, lo in zip(fields, lows)])
             v = 2 * r - 1
             if v @ v < 1:

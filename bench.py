@@ -54,10 +54,19 @@ WORKLOADS = {
     "final_scene_1600": ("final_scene", 1600, 1600, 1250, 0),   # configs[3] when run on 8 GPUs (spp = 1250 x N)
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
-N_SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, max clock (same table)
-VALU_CYCLES = {"f32": 2.0, "f64": 4.0, "f64strict": 4.0}   # cycles per wave64 VALU instruction: f32 2 (SIMD-32, per-instruction table), f64 at half rate (78.6 vs 157.3 TFLOP/s)
+N_SIMDS = 1024           # 256 CUs x 4 SIMDs (same table)
+# What a wave64 vector instruction costs a SIMD in issue time, by the classes the SQ_INSTS_VALU_* counters distinguish: MEASURED on an
+# MI355X with every SIMD issuing (profiles/valu_cost.hip -> profiles/r04/valu_cost.txt, ns per instruction and SIMD at 8 waves per
+# SIMD): f32 fma / add / mul 1.18, f64 fma / add / mul 1.77 (not 2x: the f64 pipe is not what an f64 kernel waits for), integer
+# multiplies 1.73, v_mad_u64_u32 2.17, conversions / compares / selects / popcounts / 64-bit shifts / max3 1.8-1.9, plain logic 1.0,
+# f32 transcendentals 3.4, f64 rcp / sqrt 6.8.  INT32 is priced at the mean of its measured members, the unclassified rest
+# (compares, selects, moves, min / max) at 1.8.
+VALU_COST_NS = {"SQ_INSTS_VALU_FMA_F32": 1.18, "SQ_INSTS_VALU_MUL_F32": 1.18, "SQ_INSTS_VALU_ADD_F32": 1.18, "SQ_INSTS_VALU_TRANS_F32": 3.42,
+                "SQ_INSTS_VALU_FMA_F64": 1.77, "SQ_INSTS_VALU_MUL_F64": 1.77, "SQ_INSTS_VALU_ADD_F64": 1.77, "SQ_INSTS_VALU_TRANS_F64": 6.8,
+                "SQ_INSTS_VALU_INT32": 1.6, "SQ_INSTS_VALU_INT64": 2.0, "SQ_INSTS_VALU_CVT": 1.85}
+VALU_COST_OTHER_NS = 1.8
 NODE_VISIT_BYTES = 32.0  # ONE 32-B accounting record per node visit, whatever a record physically holds
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 KERNEL_SOURCES = ["rttnw_amd/csrc/trace_kernels.hpp", "rttnw_amd/csrc/render_tiles.hpp", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp",
                   "rttnw_amd/csrc/Makefile"]
 
@@ -273,17 +282,30 @@ def main():
                 traffic = round((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0)
                 traffic_src = pmc["source"]
             if pmc is not None and pmc.get("SQ_INSTS_VALU") and pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU"):
+                # The roof of a kernel bound by vector-instruction issue, from ITS OWN instruction mix: the launch's instructions by
+                # class x the measured issue cost of the class = the SIMD time the launch needs at best; peak = instructions per second
+                # at that mean cost with every lane of every instruction doing work.  achieved = instructions x lane utilisation / time.
+                # frac = issue utilisation (<= 1 by construction) x lane utilisation.
+                n_valu = pmc["SQ_INSTS_VALU"]
+                classified = {k: pmc[k] for k in VALU_COST_NS if k in pmc}
+                other = max(0.0, n_valu - sum(classified.values()))
+                issue_ns = sum(v * VALU_COST_NS[k] for k, v in classified.items()) + other * VALU_COST_OTHER_NS
+                mean_cost = issue_ns / n_valu
                 lane_util = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
-                peak = N_SIMDS * CLOCK_GHZ / VALU_CYCLES[pname]                           # G wave-instructions / s
-                ach = pmc["SQ_INSTS_VALU"] * lane_util / secs / 1e9 if secs > 0 else 0.0   # full-wave equivalents / s
+                peak = N_SIMDS / mean_cost                                                  # G wave-instructions / s the chip can issue of this mix
+                ach = n_valu * lane_util / secs / 1e9 if secs > 0 else 0.0                   # full-wave equivalents / s
+                issue_util = issue_ns * 1e-9 / N_SIMDS / secs if secs > 0 else 0.0
                 valu = {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": "G full-wave VALU instructions/s",
-                        "frac": round(ach / peak, 5), "lane_utilisation": round(lane_util, 4),
-                        "wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
-                        "wave_instructions_per_sample": round(pmc["SQ_INSTS_VALU"] / self.samples_rank, 1),
-                        "issue_cycles_per_instruction": VALU_CYCLES[pname], "source": pmc["source"],
-                        "note": "achieved = SQ_INSTS_VALU x SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) / kernel time: the vector "
-                                "instructions of one launch counted as full 64-lane instructions; peak = 1024 SIMDs x 2.4 GHz / cycles "
-                                "per wave64 instruction of this kernel's arithmetic"}
+                        "frac": round(ach / peak, 5), "lane_utilisation": round(lane_util, 4), "issue_utilisation": round(issue_util, 4),
+                        "wave_instructions_per_launch": n_valu,
+                        "wave_instructions_per_sample": round(n_valu / self.samples_rank, 1),
+                        "mean_issue_ns_per_instruction": round(mean_cost, 3),
+                        "instruction_classes": {k.replace("SQ_INSTS_VALU_", "").lower(): v for k, v in classified.items()},
+                        "unclassified_instructions": other, "source": pmc["source"],
+                        "note": "issue time the launch needs = sum over SQ_INSTS_VALU_* classes of count x measured issue cost "
+                                "(profiles/r04/valu_cost.txt) / 1024 SIMDs; issue_utilisation = that / kernel time; achieved = SQ_INSTS_VALU x "
+                                "SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) / kernel time: the launch's vector instructions counted as "
+                                "full 64-lane instructions; peak = 1024 SIMDs / the mix's mean issue cost; frac = issue_utilisation x lane_utilisation"}
             lds_resident = (form & 2) != 0   # rttnw_stats.reserved bit 1: the launch kept the node records in LDS (the library's own choice)
             form &= 1
             # the instantiation that ran, as rocprofv3's kernel trace names it (<R, COUNT, BLOCK, LDS nodes, GENERAL>; the bench

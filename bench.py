@@ -68,7 +68,7 @@ VALU_COST_OTHER_NS = 1.8
 NODE_VISIT_BYTES = 32.0  # ONE 32-B accounting record per node visit, whatever a record physically holds
 PROFILE_ROUND = "r04"
 KERNEL_SOURCES = ["rttnw_amd/csrc/trace_kernels.hpp", "rttnw_amd/csrc/render_tiles.hpp", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp",
-                  "rttnw_amd/csrc/Makefile"]
+                  "rttnw_amd/csrc/bvh_quant.hpp", "rttnw_amd/csrc/Makefile"]
 
 
 def log(*a):
@@ -361,36 +361,50 @@ def main():
         oprec = abi.F64 if precision == abi.F32 else abi.F32
         other = wl.record(oprec, max(1, min(args.steps, 5)), 1)
 
-    # ---- the other single-GPU configs of BASELINE.json, timed in the same run (default N = 1 run only)
+    def cpu_sample(w, seconds, name):
+        """The CPU oracle on the host cores for a bounded sample of workload `w` at its full frame and geometry: calibrate at 1 spp, then
+        the spp that fills `seconds`.  spheres_1m's 10^6 spheres go through the oracle's median-split builder (the reference's own
+        builder is O(n^2 log n): hittable.rs:265-321; tests/test_oracle_kat.py proves the two bit-identical where both can run)."""
+        from oracle import rto
+        big = w.scene_name == "spheres_1m"
+        so, _ = S.build(rto.binding(), scenes, w.scene_name, earth, w.param, bvh=rto.BVH_MEDIAN_SPLIT if big else None)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        camc, pcal = S.params_for(w.setup, w.W, w.H, 1, seed=1)
+        tc = time.perf_counter()
+        rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)      # calibration: 1 spp at full size
+        rate = w.W * w.H / max(1e-6, time.perf_counter() - tc)
+        cspp = int(max(1, min(256, round(rate * seconds / (w.W * w.H)))))
+        camc, pcpu = S.params_for(w.setup, w.W, w.H, cspp, seed=1)
+        tc = time.perf_counter()
+        rto.render(so, camc, pcpu, n_threads=cores, want_rgba8=False)
+        dt = time.perf_counter() - tc
+        return {"value": round(w.W * w.H * cspp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                "sample": "%s %dx%d spp=%d (%.1f s), f64 CPU oracle (reference-shaped: list scan + %s)"
+                          % (w.scene_name, w.W, w.H, cspp, dt, "BvhTree::hit over a median-split tree: the reference's builder cannot make this one" if big
+                             else "the reference's BVH builder")}
+
+    # ---- the other single-GPU configs of BASELINE.json, timed in the same run (default N = 1 run only).  spheres_1m reports the
+    # IEEE-strict f64 build first: on that scene (rounding grows ~100x per bounce) it is the build whose pixels equal the CPU
+    # reference's (tests/test_gpu_parity.py::test_config5_spheres_1m_at_its_size_vs_oracle); the contracted build rides along.
     subs = {}
     if world == 1 and share is None and args.workload is None and not args.no_sub and not args.spp and not args.size:
         for name in ("cornell_box", "spheres_1m"):
             w2 = Workload(name)
-            rec = w2.record(abi.F64, args.sub_steps, 1)
+            first = abi.F64_STRICT if name == "spheres_1m" else abi.F64
+            rec = w2.record(first, args.sub_steps, 1)
             rec["config"] = w2.config()
+            if first == abi.F64_STRICT:
+                rec["f64_kernels"] = w2.record(abi.F64, args.sub_steps, 1)
             rec["f32_kernels"] = w2.record(abi.F32, args.sub_steps, 1)
+            if rank == 0 and args.cpu_seconds > 0:
+                rec["cpu_baseline"] = cpu_sample(w2, min(args.cpu_seconds, 6.0), name)
             subs[name] = rec
             del w2
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        from oracle import rto
-        scene_name, W, H, param = wl.scene_name, wl.W, wl.H, wl.param
-        so, _ = S.build(rto.binding(), scenes, scene_name, earth, min(param or 20000, 20000) if scene_name == "spheres_1m" else param)
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        camc, pcal = S.params_for(wl.setup, W, H, 1, seed=1)
-        tc = time.perf_counter()
-        rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)      # calibration: 1 spp at full size
-        rate = W * H / max(1e-6, time.perf_counter() - tc)
-        cspp = int(max(1, min(256, round(rate * args.cpu_seconds / (W * H)))))
-        camc, pcpu = S.params_for(wl.setup, W, H, cspp, seed=1)
-        tc = time.perf_counter()
-        rto.render(so, camc, pcpu, n_threads=cores, want_rgba8=False)
-        dt = time.perf_counter() - tc
-        cpu = {"value": round(W * H * cspp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-               "sample": "%s %dx%d spp=%d (%.1f s), f64 CPU oracle (reference-shaped: list scan + reference BVH builder)"
-                         % (scene_name, W, H, cspp, dt)}
+        cpu = cpu_sample(wl, args.cpu_seconds, workload)
 
     if rank == 0 or share is not None:
         cfg = {"workload": "%s %dx%d spp=%d%s" % (wl.scene_name, wl.W, wl.H, wl.spp, " (spp = %d x %d GPUs)" % (wl.spp1, world) if world > 1 else ""),

@@ -19,6 +19,7 @@ run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run sq3 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM SQ_INSTS_BRANCH
 run sq4 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_INSTS_VALU_INT64 SQ_INSTS_FLAT SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC
+run sq5 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64
 run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
@@ -52,8 +53,13 @@ with open(os.path.join(out, "summary.txt"), "w") as fo:
         print(line); fo.write(line + "\n")
     g = lambda k: sum(summ[k]) / len(summ[k]) if k in summ else None
     if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU") and g("GRBM_GUI_ACTIVE"):
+        # issue time the launch needs at the measured per-class issue costs (bench.py VALU_COST_NS, profiles/r04/valu_cost.txt) against its duration
+        n_valu = g("SQ_INSTS_VALU")
+        classified = {k: g(k) for k in bench.VALU_COST_NS if g(k) is not None}
+        issue_ns = sum(v * bench.VALU_COST_NS[k] for k, v in classified.items()) + max(0.0, n_valu - sum(classified.values())) * bench.VALU_COST_OTHER_NS
+        dur = [v for k, vs in summ.items() if k.startswith("duration_ns[") for v in vs]
         d = ["lane_utilisation = SQ_THREAD_CYCLES_VALU/(SQ_ACTIVE_INST_VALU*64) = %.3f" % (g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64)),
-             "valu_busy = SQ_ACTIVE_INST_VALU*4/(1024*GRBM_GUI_ACTIVE/8) = %.3f" % (g("SQ_ACTIVE_INST_VALU") * 4 / (1024 * g("GRBM_GUI_ACTIVE") / 8)),
+             "issue_utilisation = sum(class count x measured issue ns) / 1024 SIMDs / duration = %.3f  (mean %.2f ns per instruction)" % (issue_ns / bench.N_SIMDS / (sum(dur) / len(dur)), issue_ns / n_valu),
              "wave_time: wait_any %.3f  wait_inst %.3f  active %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"))]
         for line in d:
             print(line); fo.write(line + "\n")

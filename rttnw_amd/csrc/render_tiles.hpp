@@ -27,6 +27,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
     rc.profile = p->collect_counters;
     rc.sample_begin = p->sample_begin;
+    rc.scene_flags = s->flat.moving.empty() ? SCENE_NO_TIME : 0u;
+    rc.inv_width = 1.0 / double(p->width); rc.inv_height = 1.0 / double(p->height);
     rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
     // The render's chunk schedule (a function of spp alone) and how many of its chunks one launch traces (rt_types.hpp
     // launch_chunks: the chunk sums of a launch stay within the device's budget; the resolve step continues every pixel's
@@ -239,6 +241,7 @@ int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
     rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    rc.inv_width = 1.0 / double(p->width); rc.inv_height = 1.0 / double(p->height);
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
                 cam->focus_distance, cam->open_time, cam->close_time, cam64);

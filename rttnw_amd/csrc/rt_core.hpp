@@ -306,7 +306,7 @@ using LaneCounters = LaneCountersT<true>;
 
 // ---------------------------------------------------------------- camera (camera.rs:63-84)
 template <typename R>
-RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key) {
+RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key, bool time_is_read = true) {
     // random_in_unit_disk runs even when lens_radius == 0 (Q15); with a zero radius its value
     // cannot matter, so the loop is skipped then — the draws are keyed, nothing shifts.
     R px = 0, py = 0;
@@ -324,7 +324,8 @@ RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key) {
     Ray<R> r;
     r.o = V3<R>(cam.origin) + offset;
     r.d = V3<R>(cam.lower_left_corner) + s * V3<R>(cam.horizontal) + t * V3<R>(cam.vertical) - V3<R>(cam.origin) - offset;
-    r.time = cam.open_time + (cam.close_time - cam.open_time) * uniform01<R>(key, rng_ctr(0, SLOT_TIME));
+    // camera.rs:82.  The draw is keyed: a scene in which nothing reads Ray::time (no MovingSphere) may leave it out
+    r.time = time_is_read ? cam.open_time + (cam.close_time - cam.open_time) * uniform01<R>(key, rng_ctr(0, SLOT_TIME)) : cam.open_time;
     return r;
 }
 
@@ -1393,9 +1394,20 @@ RT_HD void path_begin(PathState<R>& ps, const CameraRec<R>& cam, const RenderCon
     const uint64_t pixel = uint64_t(row) * rc.width + px;
     ps.key = sample_key(rc.seed, pixel, uint64_t(s) + rc.sample_begin);
     const uint32_t j = rc.height - 1 - row;
-    R u = rt_div(R(px) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_U)), R(rc.width));
-    R v = rt_div(R(j) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_V)), R(rc.height));
-    ps.ray = camera_ray(cam, u, v, ps.key);
+    R u, v; // main.rs:213-214
+#if defined(__HIP_DEVICE_COMPILE__) && RT_SHARED_RECIPROCALS
+    constexpr bool by_reciprocal = sizeof(R) == 8; // the contracted f64 kernels: two multiplications for two IEEE divisions by render constants
+#else
+    constexpr bool by_reciprocal = false;
+#endif
+    if constexpr (by_reciprocal) {
+        u = (R(px) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_U))) * R(rc.inv_width);
+        v = (R(j) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_V))) * R(rc.inv_height);
+    } else {
+        u = rt_div(R(px) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_U)), R(rc.width));
+        v = rt_div(R(j) + uniform01<R>(ps.key, rng_ctr(0, SLOT_JITTER_V)), R(rc.height));
+    }
+    ps.ray = camera_ray(cam, u, v, ps.key, (rc.scene_flags & SCENE_NO_TIME) == 0u);
     ps.throughput = V3<R>(R(1), R(1), R(1));
     ps.radiance = V3<R>();
     ps.bounce = 0;

@@ -242,7 +242,11 @@ struct RenderConsts {
     uint64_t seed;
     uint64_t sample_begin; // index of the first sample of this launch (rttnw_params::sample_begin + the pass's offset)
     uint32_t lds_recs[6];  // LDS form: how many insts / rects / moving / boxes / sphere_mat / (spare) records follow the Perlin tables in LDS (0: that array is read from global memory)
+    uint32_t scene_flags;  // SCENE_NO_TIME: nothing in the scene reads Ray::time (no MovingSphere): the shutter draw of camera.rs:82 is keyed, so skipping it shifts nothing
+    uint32_t pad0;
+    double inv_width, inv_height; // 1 / width, 1 / height: the contracted f64 build multiplies where main.rs:213-214 divides (the strict build divides)
 };
+enum : uint32_t { SCENE_NO_TIME = 1u };
 
 // A pixel's samples are split into CHUNKS; a job = (pixel, chunk) folds its samples sequentially (main.rs:211-216) and
 // the resolve step adds a pixel's chunk sums, in chunk order, onto the pixel's running sum: ONE chain per pixel,

@@ -55,16 +55,17 @@ WORKLOADS = {
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 N_SIMDS = 1024           # 256 CUs x 4 SIMDs (same table)
-# What a wave64 vector instruction costs a SIMD in issue time, by the classes the SQ_INSTS_VALU_* counters distinguish: MEASURED on an
-# MI355X with every SIMD issuing (profiles/valu_cost.hip -> profiles/r04/valu_cost.txt, ns per instruction and SIMD at 8 waves per
-# SIMD): f32 fma / add / mul 1.18, f64 fma / add / mul 1.77 (not 2x: the f64 pipe is not what an f64 kernel waits for), integer
-# multiplies 1.73, v_mad_u64_u32 2.17, conversions / compares / selects / popcounts / 64-bit shifts / max3 1.8-1.9, plain logic 1.0,
-# f32 transcendentals 3.4, f64 rcp / sqrt 6.8.  INT32 is priced at the mean of its measured members, the unclassified rest
-# (compares, selects, moves, min / max) at 1.8.
-VALU_COST_NS = {"SQ_INSTS_VALU_FMA_F32": 1.18, "SQ_INSTS_VALU_MUL_F32": 1.18, "SQ_INSTS_VALU_ADD_F32": 1.18, "SQ_INSTS_VALU_TRANS_F32": 3.42,
-                "SQ_INSTS_VALU_FMA_F64": 1.77, "SQ_INSTS_VALU_MUL_F64": 1.77, "SQ_INSTS_VALU_ADD_F64": 1.77, "SQ_INSTS_VALU_TRANS_F64": 6.8,
-                "SQ_INSTS_VALU_INT32": 1.6, "SQ_INSTS_VALU_INT64": 2.0, "SQ_INSTS_VALU_CVT": 1.85}
-VALU_COST_OTHER_NS = 1.8
+# What a wave64 vector instruction costs a SIMD in issue CYCLES, by the classes the SQ_INSTS_VALU_* counters distinguish: MEASURED on an
+# MI355X (profiles/valu_cost.hip under rocprofv3, profiles/valu_cost_cycles.sh -> profiles/r04/valu_cost_cycles.txt: one long launch per
+# kind at 8 waves per SIMD, GRBM_GUI_ACTIVE / instructions a SIMD issued, 2.38-2.40 GHz): v_fma_f32 2.36 and plain logic 2.28; f64
+# fma / add / mul 4.16 — and so do v_mul_lo / hi_u32, v_cndmask_b32, v_cmp_*, v_cvt_*, v_bcnt, v_lshrrev_b64, v_max3_f32 (4.16-4.5);
+# v_mad_u64_u32 4.6; v_rcp_f32 8.2; v_rcp_f64 / v_sqrt_f64 16.2.  INT32 holds logic and adds (2.3) as well as multiplies, selects and popcounts
+# (4.2): priced at their mean; the unclassified rest (moves 2.3; compares, selects, min / max 4.2) likewise.
+CLOCK_GHZ = 2.4          # max shader clock (MI355X_MICROARCH.md); the profiled launches ran at 2.38
+VALU_COST_CYCLES = {"SQ_INSTS_VALU_FMA_F32": 2.36, "SQ_INSTS_VALU_MUL_F32": 2.36, "SQ_INSTS_VALU_ADD_F32": 2.36, "SQ_INSTS_VALU_TRANS_F32": 8.2,
+                    "SQ_INSTS_VALU_FMA_F64": 4.16, "SQ_INSTS_VALU_MUL_F64": 4.16, "SQ_INSTS_VALU_ADD_F64": 4.16, "SQ_INSTS_VALU_TRANS_F64": 16.2,
+                    "SQ_INSTS_VALU_INT32": 3.3, "SQ_INSTS_VALU_INT64": 4.4, "SQ_INSTS_VALU_CVT": 4.3}
+VALU_COST_OTHER_CYCLES = 3.3
 NODE_VISIT_BYTES = 32.0  # ONE 32-B accounting record per node visit, whatever a record physically holds
 PROFILE_ROUND = "r04"
 KERNEL_SOURCES = ["rttnw_amd/csrc/trace_kernels.hpp", "rttnw_amd/csrc/render_tiles.hpp", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp",
@@ -283,29 +284,31 @@ def main():
                 traffic_src = pmc["source"]
             if pmc is not None and pmc.get("SQ_INSTS_VALU") and pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("SQ_THREAD_CYCLES_VALU"):
                 # The roof of a kernel bound by vector-instruction issue, from ITS OWN instruction mix: the launch's instructions by
-                # class x the measured issue cost of the class = the SIMD time the launch needs at best; peak = instructions per second
-                # at that mean cost with every lane of every instruction doing work.  achieved = instructions x lane utilisation / time.
-                # frac = issue utilisation (<= 1 by construction) x lane utilisation.
+                # class x the measured issue cycles of the class = the SIMD cycles the launch needs at best; peak = instructions per second
+                # at that mean cost and the maximum clock with every lane of every instruction doing work.  achieved = instructions x lane
+                # utilisation / time.  issue_utilisation = cycles needed / (1024 SIMDs x the launch's own GRBM_GUI_ACTIVE cycles): <= 1.
                 n_valu = pmc["SQ_INSTS_VALU"]
-                classified = {k: pmc[k] for k in VALU_COST_NS if k in pmc}
+                classified = {k: pmc[k] for k in VALU_COST_CYCLES if k in pmc}
                 other = max(0.0, n_valu - sum(classified.values()))
-                issue_ns = sum(v * VALU_COST_NS[k] for k, v in classified.items()) + other * VALU_COST_OTHER_NS
-                mean_cost = issue_ns / n_valu
+                need = sum(v * VALU_COST_CYCLES[k] for k, v in classified.items()) + other * VALU_COST_OTHER_CYCLES
+                mean_cost = need / n_valu
                 lane_util = pmc["SQ_THREAD_CYCLES_VALU"] / (pmc["SQ_ACTIVE_INST_VALU"] * 64.0)
-                peak = N_SIMDS / mean_cost                                                  # G wave-instructions / s the chip can issue of this mix
+                peak = N_SIMDS * CLOCK_GHZ / mean_cost                                       # G wave-instructions / s the chip can issue of this mix
                 ach = n_valu * lane_util / secs / 1e9 if secs > 0 else 0.0                   # full-wave equivalents / s
-                issue_util = issue_ns * 1e-9 / N_SIMDS / secs if secs > 0 else 0.0
+                issue_util = need / (N_SIMDS * pmc["GRBM_GUI_ACTIVE"] / 8.0) if pmc.get("GRBM_GUI_ACTIVE") else None
                 valu = {"achieved": round(ach, 2), "peak": round(peak, 1), "unit": "G full-wave VALU instructions/s",
-                        "frac": round(ach / peak, 5), "lane_utilisation": round(lane_util, 4), "issue_utilisation": round(issue_util, 4),
+                        "frac": round(ach / peak, 5), "lane_utilisation": round(lane_util, 4),
+                        "issue_utilisation": round(issue_util, 4) if issue_util is not None else None,
                         "wave_instructions_per_launch": n_valu,
                         "wave_instructions_per_sample": round(n_valu / self.samples_rank, 1),
-                        "mean_issue_ns_per_instruction": round(mean_cost, 3),
+                        "mean_issue_cycles_per_instruction": round(mean_cost, 3),
                         "instruction_classes": {k.replace("SQ_INSTS_VALU_", "").lower(): v for k, v in classified.items()},
                         "unclassified_instructions": other, "source": pmc["source"],
-                        "note": "issue time the launch needs = sum over SQ_INSTS_VALU_* classes of count x measured issue cost "
-                                "(profiles/r04/valu_cost.txt) / 1024 SIMDs; issue_utilisation = that / kernel time; achieved = SQ_INSTS_VALU x "
-                                "SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) / kernel time: the launch's vector instructions counted as "
-                                "full 64-lane instructions; peak = 1024 SIMDs / the mix's mean issue cost; frac = issue_utilisation x lane_utilisation"}
+                        "note": "cycles the launch needs = sum over SQ_INSTS_VALU_* classes of count x measured issue cycles "
+                                "(profiles/r04/valu_cost_cycles.txt); issue_utilisation = that / (1024 SIMDs x the launch's GRBM_GUI_ACTIVE cycles); "
+                                "achieved = SQ_INSTS_VALU x SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) / kernel time: the launch's vector "
+                                "instructions counted as full 64-lane instructions; peak = 1024 SIMDs x 2.4 GHz / the mix's mean issue cycles; "
+                                "frac ~ issue_utilisation x lane_utilisation"}
             lds_resident = (form & 2) != 0   # rttnw_stats.reserved bit 1: the launch kept the node records in LDS (the library's own choice)
             form &= 1
             # the instantiation that ran, as rocprofv3's kernel trace names it (<R, COUNT, BLOCK, LDS nodes, GENERAL>; the bench
@@ -369,10 +372,16 @@ def main():
         big = w.scene_name == "spheres_1m"
         so, _ = S.build(rto.binding(), scenes, w.scene_name, earth, w.param, bvh=rto.BVH_MEDIAN_SPLIT if big else None)
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        camc, pcal = S.params_for(w.setup, w.W, w.H, 1, seed=1)
-        tc = time.perf_counter()
-        rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)      # calibration: 1 spp at full size
-        rate = w.W * w.H / max(1e-6, time.perf_counter() - tc)
+        cal = 1
+        while True:                                                        # calibration at full size: enough spp for >= 0.4 s of work
+            camc, pcal = S.params_for(w.setup, w.W, w.H, cal, seed=1)
+            tc = time.perf_counter()
+            rto.render(so, camc, pcal, n_threads=cores, want_rgba8=False)
+            dt = time.perf_counter() - tc
+            if dt >= 0.4 or cal >= 64:
+                break
+            cal = min(64, max(2 * cal, int(cal * 0.6 / max(dt, 1e-3))))
+        rate = w.W * w.H * cal / dt
         cspp = int(max(1, min(256, round(rate * seconds / (w.W * w.H)))))
         camc, pcpu = S.params_for(w.setup, w.W, w.H, cspp, seed=1)
         tc = time.perf_counter()

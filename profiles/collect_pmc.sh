@@ -53,13 +53,13 @@ with open(os.path.join(out, "summary.txt"), "w") as fo:
         print(line); fo.write(line + "\n")
     g = lambda k: sum(summ[k]) / len(summ[k]) if k in summ else None
     if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU") and g("GRBM_GUI_ACTIVE"):
-        # issue time the launch needs at the measured per-class issue costs (bench.py VALU_COST_NS, profiles/r04/valu_cost.txt) against its duration
+        # SIMD cycles the launch needs at the measured per-class issue costs (bench.py VALU_COST_CYCLES, profiles/r04/valu_cost_cycles.txt)
+        # against the cycles it had: cannot exceed 1
         n_valu = g("SQ_INSTS_VALU")
-        classified = {k: g(k) for k in bench.VALU_COST_NS if g(k) is not None}
-        issue_ns = sum(v * bench.VALU_COST_NS[k] for k, v in classified.items()) + max(0.0, n_valu - sum(classified.values())) * bench.VALU_COST_OTHER_NS
-        dur = [v for k, vs in summ.items() if k.startswith("duration_ns[") for v in vs]
+        classified = {k: g(k) for k in bench.VALU_COST_CYCLES if g(k) is not None}
+        need = sum(v * bench.VALU_COST_CYCLES[k] for k, v in classified.items()) + max(0.0, n_valu - sum(classified.values())) * bench.VALU_COST_OTHER_CYCLES
         d = ["lane_utilisation = SQ_THREAD_CYCLES_VALU/(SQ_ACTIVE_INST_VALU*64) = %.3f" % (g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64)),
-             "issue_utilisation = sum(class count x measured issue ns) / 1024 SIMDs / duration = %.3f  (mean %.2f ns per instruction)" % (issue_ns / bench.N_SIMDS / (sum(dur) / len(dur)), issue_ns / n_valu),
+             "issue_utilisation = sum(class count x measured issue cycles) / (1024 SIMDs x GRBM_GUI_ACTIVE/8) = %.3f  (mean %.2f cycles per instruction)" % (need / (bench.N_SIMDS * g("GRBM_GUI_ACTIVE") / 8), need / n_valu),
              "wave_time: wait_any %.3f  wait_inst %.3f  active %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES"))]
         for line in d:
             print(line); fo.write(line + "\n")

@@ -93,7 +93,29 @@ template <int KIND> double run(const char* name, int waves_per_simd) {
 
 #define ROW(K, NAME) { const double a = run<K>(NAME, 1), b = run<K>(NAME, 4), c = run<K>(NAME, 8); std::printf("%-18s %8.2f %8.2f %8.2f   (%.3f ticks/ns at W=8 -> %.2f ns per instruction and SIMD)\n", NAME, a, b, c, g_ticks_per_ns, c / g_ticks_per_ns); }
 
-int main() {
+// "pmc" mode (profiles/valu_cost_cycles.sh runs it under rocprofv3 --pmc GRBM_GUI_ACTIVE): ONE long launch per kind at 8 waves per SIMD; the
+// script divides the launch's busy cycles by the instructions a SIMD issued: cycles per instruction from the counter the kernels' own
+// PMC summaries use.
+template <int KIND> void one_long_launch() {
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    unsigned long long* d_cycles;
+    float* d_sink;
+    const int grid = prop.multiProcessorCount * 2;
+    (void)hipMalloc(&d_cycles, grid * sizeof(unsigned long long));
+    (void)hipMalloc(&d_sink, 4);
+    hipLaunchKernelGGL(cost_kernel<KIND>, dim3(grid), dim3(1024), 0, 0, 32768, d_cycles, d_sink); // 8 waves per SIMD x 32768 iterations x 32 instructions
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d_cycles);
+    (void)hipFree(d_sink);
+}
+#define LONG(K) one_long_launch<K>();
+
+int main(int argc, char** argv) {
+    if (argc > 1) {
+        LONG(0) LONG(15) LONG(11) LONG(14) LONG(13) LONG(7) LONG(8) LONG(18) LONG(19) LONG(4) LONG(5) LONG(6) LONG(9) LONG(1) LONG(2) LONG(3) LONG(10) LONG(16) LONG(12) LONG(17)
+        return 0;
+    }
     std::printf("# SIMD issue cycles per wave64 instruction (s_memtime ticks), W waves per SIMD: W=1, W=4, W=8\n");
     ROW(0, "v_fma_f32") ROW(15, "v_max3_f32") ROW(11, "v_cmp_lt_f32") ROW(14, "v_cvt_f32_ubyte1") ROW(13, "v_rcp_f32")
     ROW(7, "v_xor_b32") ROW(8, "v_cndmask_b32") ROW(18, "v_add_co_u32") ROW(19, "v_bcnt_u32_b32") ROW(4, "v_mul_lo_u32") ROW(5, "v_mul_hi_u32") ROW(6, "v_mad_u64_u32") ROW(9, "v_lshrrev_b64")

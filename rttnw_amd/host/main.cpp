@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
     long scene_number = -1;
     uint32_t width = 0, spp = 0, gpus = 1;
     uint64_t seed = 1;
-    bool f32 = false;
+    uint32_t precision = RTTNW_F64; // --precision f64 (default: the reference's arithmetic) | f32 (throughput) | f64strict (nothing contracted: the CPU reference's path decisions bit for bit)
     std::string out = "image.png", assets;
     { // next to the executable: rttnw_amd/host/ -> rttnw_amd/assets/
         const std::string self(argv[0]);
@@ -160,7 +160,10 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = std::strtoull(value(), nullptr, 10);
         else if (a == "--out") out = value();
         else if (a == "--assets") assets = value();
-        else if (a == "--precision") f32 = std::strcmp(value(), "f32") == 0;
+        else if (a == "--precision") {
+            const char* v = value();
+            precision = std::strcmp(v, "f32") == 0 ? RTTNW_F32 : (std::strcmp(v, "f64strict") == 0 ? RTTNW_F64_STRICT : RTTNW_F64);
+        }
         else if (!a.empty() && a[0] != '-' && scene_number < 0) {
             char* end = nullptr;
             scene_number = std::strtol(a.c_str(), &end, 10);
@@ -205,7 +208,7 @@ int main(int argc, char** argv) {
     p.t_min = 0.001;    // main.rs:33
     for (int k = 0; k < 3; ++k) p.background[k] = setup.background[k];
     p.seed = seed;
-    p.precision = f32 ? RTTNW_F32 : RTTNW_F64;
+    p.precision = precision;
     p.quirks = RTTNW_QUIRKS_REFERENCE;
     p.tile_world = 1;
 
@@ -232,6 +235,6 @@ int main(int argc, char** argv) {
     double device_ms = 0.0;
     for (const auto& s : stats) device_ms = device_ms > s.kernel_ms ? device_ms : s.kernel_ms;
     std::printf("%.3fs (%ux%u, %u samples per pixel, %s kernels on %u GPU(s): %.1f ms device time, %.1f Msamples/s)\n", secs, p.width, p.height,
-                p.spp, f32 ? "f32" : "f64", gpus, device_ms, double(p.width) * p.height * p.spp / (device_ms > 0 ? device_ms : 1e-9) / 1e3);
+                p.spp, precision == RTTNW_F32 ? "f32" : (precision == RTTNW_F64_STRICT ? "f64strict" : "f64"), gpus, device_ms, double(p.width) * p.height * p.spp / (device_ms > 0 ? device_ms : 1e-9) / 1e3);
     return 0;
 }

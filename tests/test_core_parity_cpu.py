@@ -296,3 +296,44 @@ def test_quantised_records_never_change_an_image(hostsim, scenes_lib, earth, nam
         assert sta.nodes_visited <= stb.nodes_visited <= sta.nodes_visited * 1.25
         assert sta.prims_tested <= stb.prims_tested
 
+
+
+def test_quantised_records_on_hostile_geometry(hostsim, monkeypatch):
+    """The quantised node records (bvh_quant.hpp) on boxes that stress the quantisation: flat rectangles (an axis of zero extent), a huge
+    sphere beside tiny ones (one child spans the node, the others a cell of it), coordinates around 1e6 and around 1e-3, and a camera
+    whose rays are exactly parallel to an axis (NaN plane distances).  Conservative boxes may only OPEN more nodes: same image bit for
+    bit, same world.hit() calls, in both precisions."""
+    from rttnw_amd import scene as S
+    rng = np.random.default_rng(7)
+
+    def world(sc, scale, shift):
+        items = []
+        grey = sc.lambertian((0.6, 0.6, 0.6))
+        for k in range(300):
+            c = shift + scale * (rng.random(3) * 20 - 10)
+            items.append(sc.sphere(tuple(c), scale * float(10 ** rng.uniform(-3, 0)), grey if k % 3 else sc.metal((0.8, 0.7, 0.6), 0.1)))
+        for k in range(60):
+            a = shift + scale * (rng.random(3) * 20 - 10)
+            e = scale * rng.random(2) * 3
+            items.append(sc.rectangle(int(k % 3), (a[0], a[0] + e[0]), (a[1], a[1] + e[1]), a[2], grey))
+            b = shift + scale * (rng.random(3) * 20 - 10)
+            items.append(sc.cube(tuple(b), tuple(b + scale * (0.01 + rng.random(3))), grey))
+        items.append(sc.sphere(tuple(shift + np.array([0, -1000 * scale, 0])), 990 * scale, grey))      # the ground: as large as the node
+        items.append(sc.rectangle(abi.XZ, (shift[0] - 5 * scale, shift[0] + 5 * scale), (shift[2] - 5 * scale, shift[2] + 5 * scale), shift[1] + 15 * scale,
+                                  sc.diffuse_light((5, 5, 5))))
+        return sc.list([sc.bvh_tree(sc.list(items))])
+
+    for scale, shift in ((1.0, np.zeros(3)), (1e-3, np.array([1e-3, 2e-3, -1e-3])), (1.0, np.array([1e6, -2e6, 5e5]))):
+        sc = S.Scene(hostsim, 3)
+        sc.set_world(world(sc, scale, shift))
+        sc.commit()
+        for lookfrom in (shift + scale * np.array([0.0, 2.0, -40.0]), shift + scale * np.array([0.0, 0.0, -40.0])):   # the second: the centre ray is exactly (0, 0, 1)
+            cam = S.camera_desc(tuple(lookfrom), tuple(shift + scale * np.array([0.0, (lookfrom - shift)[1] / scale, 0.0])), 35.0, 1.0)
+            for prec in (abi.F64, abi.F32):
+                p = S.make_params(33, 33, 3, background=(0.2, 0.3, 0.5), precision=prec, seed=4, collect_counters=1, t_min=1e-3 * scale)
+                monkeypatch.delenv("HOSTSIM_QUANT", raising=False)
+                a, sta = util.hostsim_render(hostsim, sc, cam, p)
+                monkeypatch.setenv("HOSTSIM_QUANT", "1")
+                b, stb = util.hostsim_render(hostsim, sc, cam, p)
+                assert np.array_equal(a, b) and sta.rays == stb.rays and np.isfinite(a).all(), (scale, prec)
+                assert a.max() > 0   # (far from the origin the quantised step visits FEWER nodes in f64: it subtracts the origin in double, the f32-record test pays a slack of 2.4e-7 |o / d|)

@@ -34,7 +34,11 @@ template <int KIND> __device__ __forceinline__ void body(float (&f)[8], double (
     if constexpr (KIND == 16) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(d[i]) : "v"(u[i]));                                            \
     if constexpr (KIND == 17) asm volatile("v_sqrt_f64 %0, %0" : "+v"(d[i]));                                                           \
     if constexpr (KIND == 18) asm volatile("v_add_co_u32 %0, vcc, %0, %0" : "+v"(u[i]) : : "vcc");                                      \
-    if constexpr (KIND == 19) asm volatile("v_bcnt_u32_b32 %0, %0, %0" : "+v"(u[i]));
+    if constexpr (KIND == 19) asm volatile("v_bcnt_u32_b32 %0, %0, %0" : "+v"(u[i]));                                                   \
+    if constexpr (KIND == 20) asm volatile("v_fma_mix_f32 %0, %1, %0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(f[i]) : "v"(u[i]));   \
+    if constexpr (KIND == 21) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(f[i]) : "v"(u[i]));                                            \
+    if constexpr (KIND == 22) asm volatile("v_min_f32 %0, %0, %0" : "+v"(f[i]));                                                        \
+    if constexpr (KIND == 23) asm volatile("v_mov_b32 %0, %1" : "=v"(f[i]) : "v"(u[i]));
     REP8(ONE)
 #undef ONE
 }
@@ -113,12 +117,12 @@ template <int KIND> void one_long_launch() {
 
 int main(int argc, char** argv) {
     if (argc > 1) {
-        LONG(0) LONG(15) LONG(11) LONG(14) LONG(13) LONG(7) LONG(8) LONG(18) LONG(19) LONG(4) LONG(5) LONG(6) LONG(9) LONG(1) LONG(2) LONG(3) LONG(10) LONG(16) LONG(12) LONG(17)
+        LONG(0) LONG(15) LONG(11) LONG(14) LONG(13) LONG(7) LONG(8) LONG(18) LONG(19) LONG(4) LONG(5) LONG(6) LONG(9) LONG(1) LONG(2) LONG(3) LONG(10) LONG(16) LONG(12) LONG(17) LONG(20) LONG(21) LONG(22) LONG(23)
         return 0;
     }
     std::printf("# SIMD issue cycles per wave64 instruction (s_memtime ticks), W waves per SIMD: W=1, W=4, W=8\n");
     ROW(0, "v_fma_f32") ROW(15, "v_max3_f32") ROW(11, "v_cmp_lt_f32") ROW(14, "v_cvt_f32_ubyte1") ROW(13, "v_rcp_f32")
     ROW(7, "v_xor_b32") ROW(8, "v_cndmask_b32") ROW(18, "v_add_co_u32") ROW(19, "v_bcnt_u32_b32") ROW(4, "v_mul_lo_u32") ROW(5, "v_mul_hi_u32") ROW(6, "v_mad_u64_u32") ROW(9, "v_lshrrev_b64")
-    ROW(1, "v_fma_f64") ROW(2, "v_add_f64") ROW(3, "v_mul_f64") ROW(10, "v_cmp_lt_f64") ROW(16, "v_cvt_f64_u32") ROW(12, "v_rcp_f64") ROW(17, "v_sqrt_f64")
+    ROW(1, "v_fma_f64") ROW(2, "v_add_f64") ROW(3, "v_mul_f64") ROW(10, "v_cmp_lt_f64") ROW(16, "v_cvt_f64_u32") ROW(12, "v_rcp_f64") ROW(17, "v_sqrt_f64") ROW(20, "v_fma_mix_f32") ROW(21, "v_cvt_f32_f16") ROW(22, "v_min_f32") ROW(23, "v_mov_b32")
     return 0;
 }

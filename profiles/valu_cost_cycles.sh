@@ -10,7 +10,7 @@ python3 - $OUT <<'PY'
 import csv, glob, os, re, sys
 names = {0: "v_fma_f32", 15: "v_max3_f32", 11: "v_cmp_lt_f32", 14: "v_cvt_f32_ubyte1", 13: "v_rcp_f32", 7: "v_xor_b32", 8: "v_cndmask_b32", 18: "v_add_co_u32",
          19: "v_bcnt_u32_b32", 4: "v_mul_lo_u32", 5: "v_mul_hi_u32", 6: "v_mad_u64_u32", 9: "v_lshrrev_b64", 1: "v_fma_f64", 2: "v_add_f64", 3: "v_mul_f64",
-         10: "v_cmp_lt_f64", 16: "v_cvt_f64_u32", 12: "v_rcp_f64", 17: "v_sqrt_f64"}
+         10: "v_cmp_lt_f64", 16: "v_cvt_f64_u32", 12: "v_rcp_f64", 17: "v_sqrt_f64", 20: "v_fma_mix_f32", 21: "v_cvt_f32_f16", 22: "v_min_f32", 23: "v_mov_b32"}
 cyc, dur = {}, {}
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):

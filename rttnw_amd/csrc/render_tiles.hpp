@@ -161,8 +161,11 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             }
         } else {
             const bool gen = s->flat.needs_general;
-            if constexpr (wave_walks_quantised<R>())
-                if (int q4 = ds.ensure_quant4(s->flat)) return q4; // this kernel walks the quantised records: made here, on the device, once
+            if constexpr (wave_walks_half<R>()) {
+                if (int h4 = ds.ensure_half4(s->flat)) return h4;  // this kernel walks the half-precision node-local records: made here, on the device, once
+            } else if constexpr (wave_walks_quantised<R>()) {
+                if (int q4 = ds.ensure_quant4(s->flat)) return q4; // ... or the quantised ones
+            }
             auto kernel = count ? (gen ? trace_kernel<R, true, true> : trace_kernel<R, true, false>) : (gen ? trace_kernel<R, false, true> : trace_kernel<R, false, false>);
             const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
             size_t grid = 1;

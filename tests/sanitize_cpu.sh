@@ -30,9 +30,10 @@ for name, n in cases:
         cam, p = util.params_for(setup, 24, 24, 3, precision=prec, seed=3, collect_counters=1)
         os.environ.pop("HOSTSIM_QUANT", None)
         img, st = util.hostsim_render(b, sc, cam, p)
-        os.environ["HOSTSIM_QUANT"] = "1"          # ... and through the quantised records of the f64 decoupled kernel (bvh_quant.hpp, trav_node_step4q)
-        img_q, st_q = util.hostsim_render(b, sc, cam, p)
-        assert np.array_equal(img, img_q)
+        for mode in ("1", "2"):                    # ... and through the re-encoded records of the decoupled kernels (bvh_quant.hpp: quantised, half-precision)
+            os.environ["HOSTSIM_QUANT"] = mode
+            img_q, st_q = util.hostsim_render(b, sc, cam, p)
+            assert np.array_equal(img, img_q)
     print(name, "ok", flush=True)
 PY
 FLAGS="-O1 -g -std=c++17 -fPIC -pthread -Wno-unknown-pragmas -shared"

@@ -728,8 +728,9 @@ def test_bench_line_through_torch_distributed_with_one_rank(gpu):
     assert d["config"]["workload"].startswith("final_scene 800x800 spp=16") and d["roofline"]["kernel_ms"] > 0
 
 
-def test_bench_two_ranks_rehearsed_on_one_gpu(gpu, scenes_lib, earth, tmp_path):
-    """`bench.py --gpus 2` exactly as the driver launches it for N = 2 — `python -m torch.distributed.run --nproc-per-node 2 ...` — on a
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_n_ranks_rehearsed_on_one_gpu(gpu, scenes_lib, earth, tmp_path, world):
+    """`bench.py --gpus N` (N = 2, and N = 8: configs[3]'s partition) exactly as the driver launches it — `python -m torch.distributed.run --nproc-per-node N ...` — on a
     box with ONE GPU: RTTNW_BENCH_ONE_DEVICE=1 puts both ranks on device 0 and takes gloo for the barriers, the max-over-ranks and
     the gather (RCCL refuses two ranks on one device); the tile partition, each rank's launches, the packed buffers, the un-tile
     and the JSON line are the N-GPU code path.  Checked: ONE JSON line with n_gpus 2 and the weak-scaling workload (configs[3]'s
@@ -743,19 +744,19 @@ def test_bench_two_ranks_rehearsed_on_one_gpu(gpu, scenes_lib, earth, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = str(tmp_path / "frame.npz")
     env = dict(os.environ, RTTNW_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29531 + world), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--cpu-seconds", "0",
            "--spp", "3", "--no-other", "--dump-image", dump]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 1 and d["unit"] == "Msamples/s"
-    assert d["config"]["workload"].startswith("final_scene 1600x1600 spp=6"), d["config"]["workload"]
-    assert abs(d["value"] - 1600 * 1600 * 6 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["steps"] == 1 and d["unit"] == "Msamples/s"
+    assert d["config"]["workload"].startswith("final_scene 1600x1600 spp=%d " % (3 * world)), d["config"]["workload"]
+    assert abs(d["value"] - 1600 * 1600 * 3 * world / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
     sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
-    cam, p = util.params_for(setup, 1600, 1600, 6, precision=abi.F64, seed=1)
+    cam, p = util.params_for(setup, 1600, 1600, 3 * world, precision=abi.F64, seed=1)
     lin, rgba, _ = gpu_render(gpu, sc, cam, p)
     got = np.load(dump)
     assert np.array_equal(got["linear"], lin) and np.array_equal(got["rgba8"], rgba)

@@ -33,6 +33,16 @@
 #endif
 
 namespace rt {
+#ifndef RT_NODE_EMPTY_CHECK
+#define RT_NODE_EMPTY_CHECK 0 // 1: the node steps over f32 and half-precision records test child != CHILD_EMPTY beside the (inverted) box of an unused slot.  Without:
+                              // final_scene f64 1394 -> 1434 Msamples/s, f32 1857 -> 1889, cornell_box f64 1728 -> 1751 (four compares and the scalar ANDs between the
+                              // hit tests and the selects); the kernels that read f32 records from memory +-0.3 %, spheres_1m f32 +1 %
+#endif
+#ifndef RT_F64_SLAB_FOLDED
+#define RT_F64_SLAB_FOLDED 2 // the f64 kernels' box test: 0 every box's entry / exit widened by 3.6e-7 |t| + slack (15 operations per box), 1 the widening in per-walk
+                             // constants for both ends (11, five registers more: spills), 2 the slack in the constants and one multiplication per entry (12, two
+                             // registers more), 3 one fma per end (13).  Measured (final_scene / cornell_box f64, Msamples/s): 1364 / 1692, 1370 / 1589, 1393 / 1727, -
+#endif
 inline namespace RT_ARITH_NS {
 
 // ---------------------------------------------------------------- math wrappers
@@ -365,6 +375,9 @@ template <typename Stack, typename R> constexpr int slab_form() { return sizeof(
 template <> struct SlabRay<double> {
     float oinv[3], inv[3]; // o * (1 / d) and 1 / d: a plane distance is ONE fma, plane * inv - oinv (below)
     float slack; // the largest of the three axes' slacks: one widening of the box's entry / exit serves all planes (below)
+#if RT_F64_SLAB_FOLDED
+    float inv_n[3], oinv_n[3], inv_f[3], oinv_f[3]; // the same with the widening folded into the constants (slab_hit4 below)
+#endif
 };
 template <int FORM, typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     SlabRay<R> sr;
@@ -383,6 +396,24 @@ template <int FORM, typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
             sr.inv[a] = inv;
             sr.oinv[a] = o32 * inv;
             sr.slack = rt_max(sr.slack, rt_fabs(sr.oinv[a]) * 2.4e-7f); // maxNum: a NaN axis drops out
+#if RT_F64_SLAB_FOLDED
+            // The widening folded into the per-walk constants, as in the f32 kernels' SLAB_FMA_FOLDED form: near planes take
+            // inv (1 - 4.8e-7) and oi (1 - 4.8e-7) + 3.0e-7 |oi|, far planes the opposite.  With r1, r2, r3 the roundings of inv_n, of
+            // oinv_n's fma and of the plane's fma (each <= 2^-24):
+            //   t_n32 = (1 - 4.8e-7)(1 + e1)(1 + r3) [ t (1 + r1) + o inv (r1 - e0 - e2 - r2) ] - slack (1 + r2)(1 + r3)
+            // — for t >= 0 the first factor times (1 + r1) is <= 1 (4.8e-7 >= |e1| + |r1| + |r3| = 3.0e-7) and the second term is at most
+            // 2.4e-7 |o inv| < slack: t_n32 <= t.  A negative near distance cannot set the entry (t_min >= 0 or another axis does), a
+            // negative far distance is a box behind the origin; a NaN axis drops out of max3 / min3.
+            const float slack_a = rt_fabs(sr.oinv[a]) * 3.0e-7f;
+            sr.inv_n[a] = inv * (1.f - 4.8e-7f);
+            sr.inv_f[a] = inv * (1.f + 4.8e-7f);
+            sr.oinv_n[a] = __builtin_fmaf(sr.oinv[a], 1.f - 4.8e-7f, slack_a);
+            sr.oinv_f[a] = __builtin_fmaf(sr.oinv[a], 1.f + 4.8e-7f, -slack_a);
+#if RT_F64_SLAB_FOLDED == 2
+            sr.oinv_n[a] = sr.oinv[a] + slack_a;
+            sr.oinv_f[a] = sr.oinv[a] - slack_a;
+#endif
+#endif
         }
     } else {
         sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -459,6 +490,43 @@ RT_HD void slab4_planes(const Planes4& nd, const float o[3], const float inv[3],
 // an upper bound of the true exit: ONE widening per box instead of one per plane (round 1), a box the exact f64 test
 // would pass still always passes.  NaN / inf (axis-parallel rays) never cull.
 template <int FORM> RT_HD void slab_hit4(const Planes4& nd, V3<double>, const SlabRay<double>& sr, float lo_t, float hi_t, float e[4], bool h[4]) {
+#if RT_F64_SLAB_FOLDED == 3
+    {
+        float tn[4], tf[4];
+        slab4_planes_fma(nd, sr.oinv, sr.inv, tn, tf);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { // 13 operations per box: one fma per end widens it (valid for the non-negative distances that matter)
+            const float n = __builtin_fmaf(tn[c], 1.f - 3.6e-7f, -sr.slack);
+            const float f = __builtin_fmaf(tf[c], 1.f + 3.6e-7f, sr.slack);
+            const float lo = rt_max(n, lo_t), hi = rt_min(f, hi_t);
+            e[c] = lo;
+            h[c] = !(hi < lo);
+        }
+        return;
+    }
+#elif RT_F64_SLAB_FOLDED == 2
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { // 12 operations per box: the slack in the constants, the relative widening on the entry alone
+        const float nx = __builtin_fmaf(nd.nr[0][c], sr.inv[0], -sr.oinv_n[0]), fx = __builtin_fmaf(nd.fr[0][c], sr.inv[0], -sr.oinv_f[0]);
+        const float ny = __builtin_fmaf(nd.nr[1][c], sr.inv[1], -sr.oinv_n[1]), fy = __builtin_fmaf(nd.fr[1][c], sr.inv[1], -sr.oinv_f[1]);
+        const float nz = __builtin_fmaf(nd.nr[2][c], sr.inv[2], -sr.oinv_n[2]), fz = __builtin_fmaf(nd.fr[2][c], sr.inv[2], -sr.oinv_f[2]);
+        const float lo = rt_max(rt_max(nz, rt_max(ny, nx)) * (1.f - 9.6e-7f), lo_t), hi = rt_min(rt_min(fz, rt_min(fy, fx)), hi_t);
+        e[c] = lo;
+        h[c] = !(hi < lo);
+    }
+    return;
+#elif RT_F64_SLAB_FOLDED
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { // 11 operations per box instead of 15: the widening is in the constants (slab_ray)
+        const float nx = __builtin_fmaf(nd.nr[0][c], sr.inv_n[0], -sr.oinv_n[0]), fx = __builtin_fmaf(nd.fr[0][c], sr.inv_f[0], -sr.oinv_f[0]);
+        const float ny = __builtin_fmaf(nd.nr[1][c], sr.inv_n[1], -sr.oinv_n[1]), fy = __builtin_fmaf(nd.fr[1][c], sr.inv_f[1], -sr.oinv_f[1]);
+        const float nz = __builtin_fmaf(nd.nr[2][c], sr.inv_n[2], -sr.oinv_n[2]), fz = __builtin_fmaf(nd.fr[2][c], sr.inv_f[2], -sr.oinv_f[2]);
+        const float lo = rt_max(rt_max(nz, rt_max(ny, nx)), lo_t), hi = rt_min(rt_min(fz, rt_min(fy, fx)), hi_t); // maxNum / minNum: a NaN drops out
+        e[c] = lo;
+        h[c] = !(hi < lo);
+    }
+    return;
+#endif
     float tn[4], tf[4];
     slab4_planes_fma(nd, sr.oinv, sr.inv, tn, tf);
 #pragma unroll
@@ -889,7 +957,14 @@ RT_HD void trav_node_step4(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wr
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         ch[c] = nd.child[c];
-        k[c] = (h[c] && ch[c] != CHILD_EMPTY) ? float_bits(e[c]) : MISS; // entry distances are positive: their bit patterns order like the values
+        // (entry distances are positive: their bit patterns order like the values.  An unused slot needs no test of its own: its box is
+        // inverted, lo = +inf / hi = -inf (rt_types.hpp Bvh4Node), so its entry is +inf and its exit -inf whatever the direction's signs;
+        // were every one of its plane distances NaN — |o / d| overflowing — it would be descended into and popped at once, trav_leaf_step)
+#if RT_NODE_EMPTY_CHECK
+        k[c] = (h[c] && ch[c] != CHILD_EMPTY) ? float_bits(e[c]) : MISS;
+#else
+        k[c] = h[c] ? float_bits(e[c]) : MISS;
+#endif
     }
     trav_descend_sorted4(tr, wray, stack, k, ch);
 }
@@ -941,6 +1016,8 @@ RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
         const float tn = rt_max(nz, rt_max(ny, nx)), tf = rt_min(fz, rt_min(fy, fx));
         const float n = __builtin_fmaf(tn, 1.f - 4e-7f, -K), f = __builtin_fmaf(tf, 1.f + 4e-7f, K);
         const float lo = rt_max(n, lo_t), hi = rt_min(f, hi_t); // maxNum / minNum: a NaN drops out
+        // (an unused slot has q_lo = 255, q_hi = 0 and would miss by itself, but here the test of the slot stays: without it the compiler
+        // sinks the read of the children's piece below the hit tests — a second dependent round trip to memory per visit: spheres_1m f64 280 -> 248)
         k[c] = (!(hi < lo) && ch[c] != CHILD_EMPTY) ? float_bits(lo) : MISS_KEY;
     }
     trav_descend_sorted4(tr, wray, stack, k, ch);
@@ -1009,7 +1086,12 @@ RT_HD void trav_node_step4h(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
             nz = fma_half<1>(near_w[2][hw], inv_lo[2], a_lo[2]); fz = fma_half<1>(far_w[2][hw], inv_hi[2], a_hi[2]);
         }
         const float lo = rt_max(rt_max(nz, rt_max(ny, nx)), lo_t), hi = rt_min(rt_min(fz, rt_min(fy, fx)), hi_t); // maxNum / minNum: a NaN drops out
+        // (an unused slot: lower planes +inf, upper planes 0 — entry +inf or exit -inf whatever the signs)
+#if RT_NODE_EMPTY_CHECK
         k[c] = (!(hi < lo) && ch[c] != CHILD_EMPTY) ? float_bits(lo) : MISS_KEY;
+#else
+        k[c] = !(hi < lo) ? float_bits(lo) : MISS_KEY;
+#endif
     }
     trav_descend_sorted4(tr, wray, stack, k, ch);
 }

@@ -282,10 +282,112 @@ static void walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const r
     out2[1] = cnt.nodes; out2[2] = cnt.prims;
 }
 
+
+// Lockstep model of the lane-owns-path kernel (trace_kernels.hpp trace_kernel_plain): `n_waves` waves of 64 lanes, each folding
+// `jobs_per_wave` consecutive jobs the way the kernel does (job hand-out, path begin, one walk + shade per round), the walk driven by a
+// POLICY that decides, wave-uniformly, which kind of step runs next.  Experiment support: it counts what a policy would cost before
+// anything is built for the device.  out: [0] rounds, [1] node-step executions, [2] node lane-steps, [3] leaf-step executions,
+// [4] leaf lane-steps, [5] samples, [6..6+16) leaf executions by the SET of record kinds served (bit k = kind k), [32] walks.
+// policy 0: trips of `a` node steps + one leaf step (the kernel's).  policy 1: vote — a leaf step when leaf lanes * 256 >= b * (node + leaf
+// lanes) or no lane is at a node, else a node step.  policy 2: node steps until fewer than `a` lanes are at nodes (or none), then leaf steps
+// until fewer than `b` lanes are at leaves.
+template <typename R>
+static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, int policy, int a, int b, uint32_t n_waves,
+                       uint32_t jobs_per_wave, uint64_t* out) {
+    HostScene<R> hs(s->flat);
+    CameraRec<double> cam64;
+    make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
+                cam->focus_distance, cam->open_time, cam->close_time, cam64);
+    CameraRec<R> camr = narrow_camera<R>(cam64);
+    RenderConsts rc{};
+    rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth; rc.quirks = p->quirks; rc.seed = p->seed;
+    rc.sample_begin = p->sample_begin;
+    plan_chunks(rc, p->spp, p->spp_chunk);
+    rc.tiles_x = (rc.width + 7) / 8; rc.tiles_y = (rc.height + 7) / 8; rc.n_tiles = rc.tiles_x * rc.tiles_y;
+    rc.tile_rank = 0; rc.tile_world = 1; rc.my_tiles = rc.n_tiles;
+    rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
+    plan_jobs(rc);
+    V3<R> background(R(p->background[0]), R(p->background[1]), R(p->background[2]));
+    const R t_min = R(p->t_min);
+    struct Lane {
+        HostStack stack; Trav<R> tr; PathState<R> ps;
+        bool alive = false, done = false;
+        uint32_t px = 0, row = 0, s = 0, s_end = 0;
+    };
+    NoCounters cnt;
+    std::vector<Lane> L(64);
+    for (uint32_t w = 0; w < n_waves; ++w) {
+        uint64_t next = uint64_t(w) * (rc.n_jobs / n_waves) / 64 * 64, end = next + jobs_per_wave;
+        for (auto& l : L) { l.alive = false; l.done = false; l.s = l.s_end = 0; }
+        for (;;) {
+            bool any = false;
+            for (auto& l : L) {
+                while (!l.done && !l.alive && l.s >= l.s_end) {
+                    if (next >= end || next >= rc.n_jobs) { l.done = true; break; }
+                    const JobInfo ji = job_decode(rc, uint32_t(next++));
+                    l.px = ji.px; l.row = ji.row; l.s = ji.s; l.s_end = ji.s_end;
+                }
+                if (l.done) continue;
+                any = true;
+                if (!l.alive) { path_begin(l.ps, camr, rc, l.px, l.row, l.s); l.alive = true; }
+                trav_begin(l.tr, hs.view, l.ps.ray, l.stack);
+                out[32]++;
+            }
+            if (!any) break;
+            out[0]++;
+            // ---- the walk, in lockstep
+            auto at_node = [&](const Lane& l) { return !l.done && l.tr.node >= 0; };
+            auto at_leaf = [&](const Lane& l) { return !l.done && l.tr.node < 0 && l.tr.node != TRAV_DONE; };
+            auto node_step = [&]() {
+                uint32_t n = 0;
+                for (auto& l : L) if (at_node(l)) { trav_node_step(l.tr, hs.view, l.ps.ray, t_min, l.stack, cnt); ++n; }
+                if (n) { out[1]++; out[2] += n; }
+                return n;
+            };
+            auto leaf_step = [&]() {
+                uint32_t n = 0, kinds = 0;
+                for (auto& l : L) if (at_leaf(l)) {
+                    if (l.tr.node != CHILD_EMPTY) kinds |= 1u << (leaf_kind(l.tr.node) & 15u);
+                    trav_leaf_step(l.tr, hs.view, l.ps.ray, t_min, l.stack, cnt); ++n;
+                }
+                if (n) { out[3]++; out[4] += n; out[6 + (kinds & 15u)]++; }
+                return n;
+            };
+            for (;;) {
+                uint32_t nn = 0, nl = 0;
+                for (auto& l : L) { nn += at_node(l); nl += at_leaf(l); }
+                if (nn + nl == 0) break;
+                if (policy == 0) {
+                    for (int k = 0; k < a; ++k) node_step();
+                    leaf_step();
+                } else if (policy == 1) {
+                    if (nn == 0 || (nl != 0 && nl * 256u >= uint32_t(b) * (nn + nl))) leaf_step(); else node_step();
+                } else {
+                    while (nn >= uint32_t(a) || (nn && !nl)) { node_step(); nn = nl = 0; for (auto& l : L) { nn += at_node(l); nl += at_leaf(l); } if (!nn) break; }
+                    for (;;) { nn = nl = 0; for (auto& l : L) { nn += at_node(l); nl += at_leaf(l); } if (nl == 0 || (nl < uint32_t(b) && nn >= uint32_t(a))) break; leaf_step(); }
+                    nn = nl = 0; for (auto& l : L) { nn += at_node(l); nl += at_leaf(l); }
+                    if (nn && nn < uint32_t(a) && nl && nl < uint32_t(b)) { node_step(); leaf_step(); } // neither threshold met: a plain trip
+                }
+            }
+            // ---- shade
+            for (auto& l : L) {
+                if (l.done) continue;
+                l.alive = path_shade(l.ps, hs.view, rc, background, t_min, l.tr.found, l.tr.closest, l.tr.best, cnt);
+                if (!l.alive) { ++l.s; out[5]++; }
+            }
+        }
+    }
+}
+
 extern "C" {
 void hostsim_walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, int node_steps, uint64_t* hist,
                             uint64_t* out2) {
     walk_histogram(s, cam, p, node_steps, hist, out2);
+}
+void hostsim_wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, int policy, int a, int b, uint32_t n_waves,
+                        uint32_t jobs_per_wave, uint64_t* out) {
+    if (p->precision == RTTNW_F32) wave_model<float>(s, cam, p, policy, a, b, n_waves, jobs_per_wave, out);
+    else wave_model<double>(s, cam, p, policy, a, b, n_waves, jobs_per_wave, out);
 }
 int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, double* out_linear,
                    rttnw_stats* stats, int n_threads) {

@@ -38,6 +38,9 @@ namespace rt {
                               // final_scene f64 1394 -> 1434 Msamples/s, f32 1857 -> 1889, cornell_box f64 1728 -> 1751 (four compares and the scalar ANDs between the
                               // hit tests and the selects); the kernels that read f32 records from memory +-0.3 %, spheres_1m f32 +1 %
 #endif
+#ifndef RT_PIN_CHILD_PIECE
+#define RT_PIN_CHILD_PIECE 1 // the steps over records in memory (quantised, half-precision) keep the read of the children's piece beside the other pieces' reads
+#endif
 #ifndef RT_F64_SLAB_FOLDED
 #define RT_F64_SLAB_FOLDED 2 // the f64 kernels' box test: 0 every box's entry / exit widened by 3.6e-7 |t| + slack (15 operations per box), 1 the widening in per-walk
                              // constants for both ends (11, five registers more: spills), 2 the slack in the constants and one multiplication per entry (12, two
@@ -983,6 +986,11 @@ template <typename R, typename Stack, typename Cnt>
 RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
     uint32_t w[16]; // pieces 0-3 of the record
     stack.fetch4q(sc, tr.node, w);
+#if RT_PIN_CHILD_PIECE && defined(__HIP_DEVICE_COMPILE__)
+    // the children's piece is READ with the others: nothing below needs it before the hit tests are done, and left alone the compiler sinks its
+    // read below them — a second dependent round trip to memory per visit (spheres_1m f64 280 -> 248 Msamples/s)
+    asm volatile("" : "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+#endif
     cnt.node();
     float lo_t, hi_t;
     slab_range(t_min, tr.closest, lo_t, hi_t);
@@ -1016,9 +1024,12 @@ RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
         const float tn = rt_max(nz, rt_max(ny, nx)), tf = rt_min(fz, rt_min(fy, fx));
         const float n = __builtin_fmaf(tn, 1.f - 4e-7f, -K), f = __builtin_fmaf(tf, 1.f + 4e-7f, K);
         const float lo = rt_max(n, lo_t), hi = rt_min(f, hi_t); // maxNum / minNum: a NaN drops out
-        // (an unused slot has q_lo = 255, q_hi = 0 and would miss by itself, but here the test of the slot stays: without it the compiler
-        // sinks the read of the children's piece below the hit tests — a second dependent round trip to memory per visit: spheres_1m f64 280 -> 248)
+        // (an unused slot: q_lo = 255, q_hi = 0 — its entry lies 255 max |S| beyond its exit, the widening moves them by 3e-4 max |S| + 8e-7 |t|)
+#if RT_NODE_EMPTY_CHECK || !RT_PIN_CHILD_PIECE
         k[c] = (!(hi < lo) && ch[c] != CHILD_EMPTY) ? float_bits(lo) : MISS_KEY;
+#else
+        k[c] = !(hi < lo) ? float_bits(lo) : MISS_KEY;
+#endif
     }
     trav_descend_sorted4(tr, wray, stack, k, ch);
 }
@@ -1043,6 +1054,9 @@ template <typename R, typename Stack, typename Cnt>
 RT_HD void trav_node_step4h(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
     uint32_t w[20]; // pieces 0-4 of the record
     stack.fetch4h(sc, tr.node, w);
+#if RT_PIN_CHILD_PIECE && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(w[16]), "+v"(w[17]), "+v"(w[18]), "+v"(w[19])); // (as in trav_node_step4q)
+#endif
     cnt.node();
     float lo_t, hi_t;
     slab_range(t_min, tr.closest, lo_t, hi_t);

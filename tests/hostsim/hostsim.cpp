@@ -54,6 +54,21 @@ struct HostStack { // shaped like the device's: 16 entries + a spare slot "in LD
     }
 };
 
+struct HostStackAll : HostStack { // HOSTSIM_QUANT=3: the f32 records with every used slot's box opened to the whole space — a walk that never culls:
+    // the reference the conservative box tests are held against (a box test may only ever open more nodes: same hits, same image)
+    template <typename R> void fetch(const SceneView<R>& sc, int32_t i, const uint32_t* near_off, Planes4& out) const {
+        const Bvh4Node& nd = sc.nodes[i];
+        for (uint32_t a = 0; a < 3; ++a)
+            for (int c = 0; c < 4; ++c) {
+                const bool used = nd.child[c] != CHILD_EMPTY;
+                const float lo = used ? -1e30f : nd.lo[a][c], hi = used ? 1e30f : nd.hi[a][c];
+                out.nr[a][c] = near_off[a] == a ? lo : hi;
+                out.fr[a][c] = near_off[a] == a ? hi : lo;
+            }
+        for (int c = 0; c < 4; ++c) out.child[c] = nd.child[c];
+    }
+};
+
 struct HostStack4Q : HostStack { // the f64 decoupled kernel's: walks the quantised records (bvh_quant.hpp, made on the host here)
     static constexpr int WIDE = NODES_Q8X4;
     template <typename R> void fetch4q(const SceneView<R>& sc, int32_t i, uint32_t* w) const { std::memcpy(w, &sc.nodes4q[i], 64); }
@@ -403,11 +418,37 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     if (q && q[0] == '1')
         return p->precision == RTTNW_F32 ? render_t<float, HostStack4Q>(s, cam, p, out_linear, stats, n_threads)
                                          : render_t<double, HostStack4Q>(s, cam, p, out_linear, stats, n_threads);
+    if (q && q[0] == '3')
+        return p->precision == RTTNW_F32 ? render_t<float, HostStackAll>(s, cam, p, out_linear, stats, n_threads)
+                                         : render_t<double, HostStackAll>(s, cam, p, out_linear, stats, n_threads);
     if (q && q[0] == '2')
         return p->precision == RTTNW_F32 ? render_t<float, HostStack4H>(s, cam, p, out_linear, stats, n_threads)
                                          : render_t<double, HostStack4H>(s, cam, p, out_linear, stats, n_threads);
     return p->precision == RTTNW_F32 ? render_t<float, HostStack>(s, cam, p, out_linear, stats, n_threads)
                                      : render_t<double, HostStack>(s, cam, p, out_linear, stats, n_threads);
+}
+// The f64 kernels' 4-wide box test (rt_core.hpp slab_ray + slab_hit4, the form the host build is compiled with) on n cases: case i = four
+// boxes lo[i][a][c] / hi[i][a][c] (floats), ray o[i], d[i] (doubles), range [tmin[i], tmax[i]]; pass[i][c] = 1 where the test lets the walk in.
+int hostsim_slab4_f64(uint32_t n, const float* lo, const float* hi, const double* o, const double* d, const double* tmin, const double* tmax, uint8_t* pass) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3<double> oo(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+        const SlabRay<double> sr = slab_ray<-1>(oo, dd);
+        Planes4 nd;
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 4; ++c) {
+                const float l = lo[(size_t(i) * 3 + a) * 4 + c], h = hi[(size_t(i) * 3 + a) * 4 + c];
+                const bool near_is_lo = near_piece(a, sr) == uint32_t(a);
+                nd.nr[a][c] = near_is_lo ? l : h;
+                nd.fr[a][c] = near_is_lo ? h : l;
+            }
+        for (int c = 0; c < 4; ++c) nd.child[c] = 0;
+        float lo_t, hi_t, e[4];
+        bool h[4];
+        slab_range(tmin[i], tmax[i], lo_t, hi_t);
+        slab_hit4<-1>(nd, oo, sr, lo_t, hi_t, e, h);
+        for (int c = 0; c < 4; ++c) pass[size_t(i) * 4 + c] = h[c] ? 1 : 0;
+    }
+    return 0;
 }
 // Chunk schedule and launch split of a render (rt_types.hpp plan_chunks / launch_chunks + rt_core.hpp plan_jobs) as a rank that
 // owns rank_tiles 8x8 tiles sees it: out = {spp_chunk, n_main, n_chunks of the whole render, chunks per launch, launches, n_jobs

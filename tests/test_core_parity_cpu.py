@@ -301,6 +301,73 @@ def test_quantised_records_never_change_an_image(hostsim, scenes_lib, earth, nam
 
 
 
+@pytest.mark.parametrize("name,w,h,spp", [("cornell_box", 40, 40, 6), ("final_scene", 40, 40, 4), ("random_scene", 48, 27, 4), ("smoke_cornell_box", 32, 32, 4)])
+def test_f64_box_tests_only_cull(hostsim, scenes_lib, earth, name, w, h, spp, monkeypatch):
+    """The f64 kernels test the f32 boxes in f32 with the error bounds folded into per-walk constants (rt_core.hpp slab_ray / slab_hit4):
+    a box the exact test would pass must always pass.  Held against a walk that never culls (HOSTSIM_QUANT=3: every used slot's box opened to the
+    whole space, unused slots left inverted): same image bit for bit, same world.hit() calls, fewer visits."""
+    sc, setup = util.build(hostsim, scenes_lib, name, earth)
+    cam, p = util.params_for(setup, w, h, spp, precision=abi.F64, collect_counters=1, seed=11)
+    monkeypatch.delenv("HOSTSIM_QUANT", raising=False)
+    a, sta = util.hostsim_render(hostsim, sc, cam, p)
+    monkeypatch.setenv("HOSTSIM_QUANT", "3")
+    b, stb = util.hostsim_render(hostsim, sc, cam, p)
+    assert np.array_equal(a, b) and sta.rays == stb.rays and sta.nodes_visited < stb.nodes_visited
+    assert sta.prims_tested < stb.prims_tested
+
+
+def test_f64_box_test_passes_whatever_the_reference_test_passes(hostsim):
+    """Property test of the f64 kernels' box test (rt_core.hpp slab_ray + slab_hit4: f32 arithmetic, error bounds folded into per-walk constants)
+    against Bound::hit (bound.rs:13-32) evaluated in f64: on 1.2 million (box, ray, range) cases — boxes and origins from 1e-3 to 1e6, directions with
+    tiny and zero components, open and closed ranges, and rays aimed AT corners, edges and faces so that entry and exit coincide — every box
+    the reference test passes, the product's test passes too (it may pass more)."""
+    import ctypes as C
+    rng = np.random.default_rng(2026)
+    n = 300_000
+    lib = hostsim.lib
+    lib.hostsim_slab4_f64.argtypes = [C.c_uint32] + [C.c_void_p] * 7
+    passed_ref = passed_prod = 0
+    for scale in (1.0, 1e3, 1e-3, 1e6):
+        c = (rng.random((n, 3, 4)) * 2 - 1) * scale * 10
+        ext = scale * 10.0 ** rng.uniform(-4, 0.5, (n, 3, 4))
+        ext[rng.random((n, 3, 4)) < 0.1] = 0.0                                      # flat boxes
+        lo = (c - ext).astype(np.float32); hi = (c + ext).astype(np.float32)
+        lo, hi = np.minimum(lo, hi), np.maximum(lo, hi)
+        o = (rng.random((n, 3)) * 2 - 1) * scale * 10 * 10.0 ** rng.integers(0, 3, (n, 1))
+        d = rng.normal(size=(n, 3))
+        tiny = rng.random((n, 3)) < 0.15
+        d[tiny] *= 10.0 ** rng.uniform(-12, -4, tiny.sum())
+        d[rng.random((n, 3)) < 0.05] = 0.0
+        d[(d == 0).all(axis=1)] = (0.0, 0.0, 1.0)
+        # half of the rays aimed at a point ON box 0 (a corner, an edge, a face point, by choosing lo / hi / between per axis): grazing hits
+        aim = rng.random(n) < 0.5
+        pick = rng.integers(0, 3, (n, 3))
+        between = lo[:, :, 0].astype(np.float64) + rng.random((n, 3)) * (hi[:, :, 0].astype(np.float64) - lo[:, :, 0])
+        target = np.where(pick == 0, lo[:, :, 0], np.where(pick == 1, hi[:, :, 0], between)).astype(np.float64)
+        d[aim] = (target - o)[aim] * 10.0 ** rng.uniform(-2, 1, (aim.sum(), 1))
+        tmin = np.where(rng.random(n) < 0.8, 1e-3 * scale, 0.0)
+        tmax = np.where(rng.random(n) < 0.5, np.finfo(np.float64).max, 10.0 ** rng.uniform(-2, 3, n))
+        out = np.zeros((n, 4), dtype=np.uint8)
+        lo = np.ascontiguousarray(lo); hi = np.ascontiguousarray(hi); o = np.ascontiguousarray(o); d = np.ascontiguousarray(d)
+        lib.hostsim_slab4_f64(n, lo.ctypes.data, hi.ctypes.data, o.ctypes.data, d.ctypes.data, tmin.ctypes.data, tmax.ctypes.data, out.ctypes.data)
+        # Bound::hit in f64 (f64::max / min ignore a NaN operand, as np.fmax / np.fmin do)
+        with np.errstate(all="ignore"):
+            inv = 1.0 / d
+            mn = np.repeat(tmin[:, None], 4, axis=1); mx = np.repeat(tmax[:, None], 4, axis=1)
+            ok = np.ones((n, 4), dtype=bool)
+            for a in range(3):
+                t0 = (lo[:, a, :].astype(np.float64) - o[:, a, None]) * inv[:, a, None]
+                t1 = (hi[:, a, :].astype(np.float64) - o[:, a, None]) * inv[:, a, None]
+                neg = (inv[:, a] < 0)[:, None]
+                t0, t1 = np.where(neg, t1, t0), np.where(neg, t0, t1)
+                mn = np.fmax(t0, mn); mx = np.fmin(t1, mx)
+                ok &= ~(mx < mn)
+        missed = ok & (out == 0)
+        assert not missed.any(), (scale, int(missed.sum()), np.argwhere(missed)[:3])
+        passed_ref += int(ok.sum()); passed_prod += int(out.sum())
+    assert passed_ref > 100_000 and passed_ref <= passed_prod <= passed_ref * 1.5, (passed_ref, passed_prod)   # (more: tiny and zero direction components cost slack; but not everything)
+
+
 def test_quantised_records_on_hostile_geometry(hostsim, monkeypatch):
     """The quantised node records (bvh_quant.hpp) on boxes that stress the quantisation: flat rectangles (an axis of zero extent), a huge
     sphere beside tiny ones (one child spans the node, the others a cell of it), coordinates around 1e6 and around 1e-3, and a camera
@@ -340,4 +407,8 @@ def test_quantised_records_on_hostile_geometry(hostsim, monkeypatch):
                     monkeypatch.setenv("HOSTSIM_QUANT", mode)
                     b, stb = util.hostsim_render(hostsim, sc, cam, p)
                     assert np.array_equal(a, b) and sta.rays == stb.rays and np.isfinite(a).all(), (scale, prec, mode)
+                if prec == abi.F64:   # ... and a walk that never culls (every used slot's box opened to the whole space) finds the same hits: the f64 kernels' box tests are conservative
+                    monkeypatch.setenv("HOSTSIM_QUANT", "3")
+                    b, stb = util.hostsim_render(hostsim, sc, cam, p)
+                    assert np.array_equal(a, b) and sta.rays == stb.rays and stb.nodes_visited > sta.nodes_visited, (scale, "never culls")
                 assert a.max() > 0   # (far from the origin the quantised step visits FEWER nodes in f64: it subtracts the origin in double, the f32-record test pays a slack of 2.4e-7 |o / d|)

@@ -96,6 +96,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         const size_t extra = rc.stack_depth > lds_entries ? rc.stack_depth - lds_entries : 0;
         return grow(&d->spill, &d->spill_bytes, std::max<size_t>(threads * extra, 1) * sizeof(int32_t));
     };
+    bool three_steps = false; // the lane-owns-path kernel's instantiation with three node steps per trip (tiny top trees)
     // One pass: trace kernel over the pass's jobs, then the resolve step.
     auto trace_pass = [&]() -> int {
         const size_t n_jobs = rc.n_jobs;
@@ -135,7 +136,11 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             }
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
             const bool gen = s->flat.needs_general; // rare graph shapes: the instantiation that carries their code
+            // a top tree of one or two levels (cornell_box: 6 nodes; its walks are mostly entered instances) takes three node steps per trip
+            three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2;
+            const bool tiny_tree = three_steps && !count; // (the counting variant's tallied loop is written for two: same steps per lane, same counters)
             const void* kernel =
+                tiny_tree ? (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true, 3> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false, 3>) :
                 want_lds ? (count ? (gen ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, false>)
                                   : (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false>))
                          : (count ? (gen ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, false>)
@@ -228,7 +233,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
         // which kernel form ran: bit 0 = decoupled (else lane-owns-path), bit 1 = node records resident in LDS (the form bench.py's
         // roofline calls issue-bound)
-        stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u);
+        stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u) | (plain && three_steps ? 4u : 0u);
     }
     return RTTNW_OK;
 }

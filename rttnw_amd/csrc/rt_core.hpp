@@ -1180,7 +1180,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     }
 }
 
-template <typename R, typename Stack, typename Cnt>
+template <int NODE_STEPS = RT_NODE_STEPS, typename R, typename Stack, typename Cnt>
 RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R& closest, HitRef& best, Stack& stack, Cnt& cnt) {
     Trav<R> tr;
     trav_begin(tr, sc, wray, stack);
@@ -1192,7 +1192,9 @@ RT_HD bool closest_solid(const SceneView<R>& sc, const Ray<R>& wray, R t_min, R&
         // cornell_box 1707 / 1718 / 1665 / 1691.
         // (re-measured with the spheres of transformed groups in the top tree, node steps per trip 1 / 2 / 3: final_scene f32
         // 1605 / 1632 / 1562, f64 - / 1058 / 1037; cornell_box f32 1893 / 2040 / 2066, f64 - / 1359 / 1370)
-        constexpr int node_steps = RT_NODE_STEPS;
+        // (round 4, per tree size: the lane-owns-path kernel takes THREE for a top tree of <= 16 nodes — cornell_box, whose walks are mostly
+        // entered instances: f64 1749 -> 1804, f32 2305 -> 2347; final_scene with three: 1429 -> 1401 — render_tiles.hpp picks the instantiation)
+        constexpr int node_steps = NODE_STEPS;
 #pragma unroll
         for (int k = 0; k < node_steps; ++k)
             if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
@@ -1613,13 +1615,13 @@ RT_HD bool path_shade(PathState<R>& ps, const SceneView<R>& sc, const RenderCons
     return ps.bounce < rc.max_depth;
 }
 
-template <typename R, typename Stack, typename Cnt>
+template <int NODE_STEPS = RT_NODE_STEPS, typename R, typename Stack, typename Cnt>
 RT_HD bool path_step(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min,
                      Stack& stack, Cnt& cnt) {
     cnt.ray();
     R closest;
     HitRef best;
-    const bool found = closest_solid(sc, ps.ray, t_min, closest, best, stack, cnt);
+    const bool found = closest_solid<NODE_STEPS>(sc, ps.ray, t_min, closest, best, stack, cnt);
     return path_shade(ps, sc, rc, background, t_min, found, closest, best, cnt);
 }
 

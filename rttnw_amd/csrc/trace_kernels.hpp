@@ -425,7 +425,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 // bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
 // bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
 // decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
-template <typename R, bool COUNT, int BLOCK, bool LDSN, bool GENERAL>
+// NSTEPS: node steps per trip round the walk loop (rt_core.hpp closest_solid): RT_NODE_STEPS, or 3 for tiny top trees (render_tiles.hpp).
+template <typename R, bool COUNT, int BLOCK, bool LDSN, bool GENERAL, int NSTEPS = RT_NODE_STEPS>
 // (the 256-thread form — nodes in global memory — asks for at least 3 waves/SIMD like the decoupled kernel: its f64 code,
 // allowed 256 VGPRs, ran at 2: a 20 000-sphere scene 29.9 -> 13.7 ms per 67 Msamples)
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plain(SceneView<R> sc_arg, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
                     alive = true;
                 }
                 if (alive) {
-                    alive = path_step(ps, sc, rc, background, t_min, stack, cnt);
+                    alive = path_step<NSTEPS>(ps, sc, rc, background, t_min, stack, cnt);
                     if (!alive) { // main.rs:216: acc + color(...)
                         acc = acc + ps.radiance;
                         ++s;

@@ -338,6 +338,17 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
             # whose hit sits within an ulp of a decision goes another way (measured: 1 pixel of 4032 on final_scene)
             d = np.abs(out[form][0] - out["plain"][0]).max(axis=2)
             assert (d > 0).mean() <= 2e-3 and out[form][2] == pytest.approx(out["plain"][2], rel=1e-3), form
+    # the timed instantiation (no counters): for a top tree of <= 16 nodes it takes THREE node steps per walk trip (rttnw_stats.reserved bit 2) —
+    # the same steps per lane in another rhythm: the same image
+    monkeypatch.setenv("RTTNW_KERNEL", "plain")
+    p.collect_counters = 0
+    lin, rgba, st = gpu_render(gpu, sc, cam, p)
+    assert ((st.reserved & 4) != 0) == ((st.reserved & 2) != 0 and st.n_nodes <= 16), (st.reserved, st.n_nodes)
+    assert ((st.reserved & 4) != 0) == (name in ("cornell_box", "smoke_cornell_box"))
+    if precision == abi.F64:
+        assert np.array_equal(lin, out["plain"][0]) and np.array_equal(rgba, out["plain"][1])
+    else:
+        assert ((np.abs(lin - out["plain"][0]).max(axis=2)) > 0).mean() <= 2e-3
 
 
 def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):

@@ -34,7 +34,7 @@ void device_release(DeviceState* d) {
     (void)hipGetDevice(&prev);
     if (d->device >= 0) (void)hipSetDevice(d->device);
     struct Restore { int dev; ~Restore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore{prev};
-    d->s32.release(); d->s64.release();
+    d->s32.release(); d->s64.release(); d->s64_ref.release();
     if (d->partial) (void)hipFree(d->partial);
     if (d->pool_r) (void)hipFree(d->pool_r);
     if (d->pool_u) (void)hipFree(d->pool_u);
@@ -106,6 +106,31 @@ int device_commit(::rttnw_scene* s, std::string& err) {
 }
 
 
+// RTTNW_F64_STRICT promises the reference's operations in the reference's order.  The default lowering breaks that promise in one place: a
+// sphere under Translate / YRotate wrappers is tested as a world-space copy in the top tree (scene_lower.cpp: the same quadratic written in
+// another frame — t differs in the last place, which a few bounces off small spheres amplify: final_scene 800x800 spp 1000, 9 of 1536 pixels of
+// the cluster crop beyond 1e-9).  So the strict build walks a second lowering of the same graph that leaves those spheres in their groups'
+// trees (the ray goes through the wrappers as in hittable.rs:599-606,686-699): on that crop every pixel is within 1.5e-13 of the CPU
+// restatement, at 7 % of the strict build's speed on that scene (more node steps, a second tree).  Made at the first strict render of a scene
+// that has such copies, with the scene's own builder and shutter interval; scenes without them render `flat` itself.
+int reference_frame_scene(::rttnw_scene* s, const FlatScene*& flat) {
+    flat = &s->flat;
+    if (s->flat.n_world_copies == 0) return 0;
+    std::lock_guard<std::mutex> lock(s->rebuild_mutex);
+    if (!s->flat_ref) {
+        std::string err;
+        DeviceBvhApi device_builder;
+        const bool on_device = s->bvh_builder != RTTNW_BVH_HOST_SAH;
+        if (on_device)
+            if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
+        std::unique_ptr<FlatScene> ref(new FlatScene());
+        if (int rc = lower_scene(s->graph, *ref, err, on_device ? &device_builder : nullptr, s->flat.time0, s->flat.time1, 0)) { set_last_error(err); return rc; }
+        s->flat_ref = std::move(ref);
+    }
+    flat = s->flat_ref.get();
+    return 0;
+}
+
 void fill_layout(uint32_t w, uint32_t h, uint32_t world, rttnw_tile_layout& L) {
     L.tiles_x = (w + 7) / 8; L.tiles_y = (h + 7) / 8;
     L.n_tiles = L.tiles_x * L.tiles_y;
@@ -153,10 +178,11 @@ int validate(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params*
             for (DeviceState* d : all) { // nothing of an earlier render may still read the arrays that are about to go
                 (void)hipSetDevice(d->device);
                 (void)hipDeviceSynchronize();
-                d->s32.release(); d->s64.release();
+                d->s32.release(); d->s64.release(); d->s64_ref.release();
             }
             if (prev >= 0) (void)hipSetDevice(prev);
             s->flat = std::move(wider);
+            s->flat_ref.reset(); // (made again, for the wider interval, by the next RTTNW_F64_STRICT render)
         }
     }
     return 0;

@@ -203,6 +203,7 @@ struct DeviceState {
     uint64_t chunk_budget = 0; // bytes of chunk sums a launch may hold on this device (rt_types.hpp launch_chunks): total HBM / 12, 4 .. 24 GiB
     DeviceScene<float> s32;
     DeviceScene<double> s64;
+    DeviceScene<double> s64_ref; // rttnw_scene::flat_ref on this device (RTTNW_F64_STRICT renders of scenes with world-space copies)
     // workspace, grown on demand and kept
     void* partial = nullptr;
     size_t partial_bytes = 0;
@@ -223,6 +224,9 @@ struct DeviceState {
 int grow(void** p, size_t* have, size_t want); // a workspace buffer kept at its high-water mark (render_api.cpp)
 void debug_print_sched(const DeviceCounters& hc, bool plain, uint32_t profile, uint64_t samples); // RTTNW_DEBUG_SCHED=1 only (debug_sched.cpp)
 int device_state_create(DeviceState*& out, std::string& err);
+// The lowering an RTTNW_F64_STRICT render walks: s->flat, or — when that holds world-space copies of transformed groups' spheres — the same
+// graph lowered without them (made once, under the scene's mutex).  render_api.cpp.
+int reference_frame_scene(::rttnw_scene* s, const FlatScene*& flat);
 
 template <typename R> DeviceScene<R>& scene_of(DeviceState* d);
 template <> inline DeviceScene<float>& scene_of<float>(DeviceState* d) { return d->s32; }

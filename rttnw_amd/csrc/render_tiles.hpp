@@ -13,9 +13,17 @@ template <typename R>
 int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* cam, const rttnw_params* p, void* d_packed, hipStream_t stream,
                    rttnw_stats* stats, bool sync_for_stats, bool prepare_only) {
     HIP_TRY(hipSetDevice(d->device));
-    DeviceScene<R>& ds = scene_of<R>(d);
+    const FlatScene* flat_p = &s->flat;
+    DeviceScene<R>* ds_p = &scene_of<R>(d);
+#if defined(RT_STRICT_F64)
+    // the IEEE-strict build walks the lowering that tests every object in the reference's frame (render_api.cpp reference_frame_scene)
+    if (int rc = reference_frame_scene(s, flat_p)) return rc;
+    if (flat_p != &s->flat) ds_p = &d->s64_ref;
+#endif
+    const FlatScene& flat = *flat_p;
+    DeviceScene<R>& ds = *ds_p;
     if (!ds.ready)
-        if (int rc = ds.upload(s->flat)) return rc;
+        if (int rc = ds.upload(flat)) return rc;
 
     rttnw_tile_layout L;
     fill_layout(p->width, p->height, p->tile_world, L);
@@ -24,10 +32,10 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     rc.tiles_x = L.tiles_x; rc.tiles_y = L.tiles_y; rc.n_tiles = L.n_tiles;
     rc.tile_rank = p->tile_rank; rc.tile_world = p->tile_world;
     rc.my_tiles = L.n_tiles > p->tile_rank ? (L.n_tiles - p->tile_rank + p->tile_world - 1) / p->tile_world : 0;
-    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = flat.stack_depth;
     rc.profile = p->collect_counters;
     rc.sample_begin = p->sample_begin;
-    rc.scene_flags = s->flat.moving.empty() ? SCENE_NO_TIME : 0u;
+    rc.scene_flags = flat.moving.empty() ? SCENE_NO_TIME : 0u;
     rc.inv_width = 1.0 / double(p->width); rc.inv_height = 1.0 / double(p->height);
     rc.div_tiles_x = make_fastdiv(std::max<uint32_t>(1u, rc.tiles_x));
     // The render's chunk schedule (a function of spp alone) and how many of its chunks one launch traces (rt_types.hpp
@@ -75,7 +83,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     const char* kv = getenv("RTTNW_KERNEL");
     // (crossover measured on spheres_1m-like scenes of 2e4 - 2.5e5 spheres, 512x512 spp 256: f32 at ~24 k 4-wide nodes — 19.6 k:
     // 3105 against 2972 Msamples/s, 28.3 k: 2258 against 2452 — f64 at ~50 k — 28.3 k: 2022 against 1740, 50.9 k: 1284 against 1318)
-    bool plain = s->flat.total_nodes4() < (sizeof(R) == 4 ? 24576u : 49152u);
+    bool plain = flat.total_nodes4() < (sizeof(R) == 4 ? 24576u : 49152u);
     if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     if (!prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
@@ -104,11 +112,11 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             // Small scenes: node array in LDS, in ONE large block per CU so that nodes + all the lanes' stacks fit in 160 KB:
             // 1024 threads in both precisions (4 waves/SIMD at <= 128 VGPRs; RT_F64_BLOCK: the f64 code spills ~26 registers to get there)
             constexpr int LDS_BLOCK = sizeof(R) == 4 ? 1024 : RT_F64_BLOCK;
-            const uint32_t n4 = s->flat.total_nodes4();
+            const uint32_t n4 = flat.total_nodes4();
             const bool want_lds = !(kv && std::strcmp(kv, "plainglobal") == 0) && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) <= 160 * 1024;
             rc.lds_nodes = want_lds ? n4 : 0u;
             // the scene's Perlin tables ride along in LDS when they fit behind the stacks (trace_kernel_plain)
-            const size_t n_perlin = s->flat.perlin_vec.size() / 768u;
+            const size_t n_perlin = flat.perlin_vec.size() / 768u;
             size_t perlin_bytes = lds_perlin_bytes(n_perlin, sizeof(R));
             if (want_lds && n_perlin > 0 && n_perlin < 256 && n4 <= LDS_NODES_MASK && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes <= 160 * 1024)
                 rc.lds_nodes |= uint32_t(n_perlin) << LDS_PERLIN_SHIFT;
@@ -118,7 +126,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             for (int k = 0; k < 6; ++k) rc.lds_recs[k] = 0;
             if (want_lds) {
                 perlin_bytes = lds_pad32(perlin_bytes);
-                const size_t counts[4] = {s->flat.insts.size(), s->flat.rects.size(), s->flat.moving.size(), s->flat.boxes.size()};
+                const size_t counts[4] = {flat.insts.size(), flat.rects.size(), flat.moving.size(), flat.boxes.size()};
                 const size_t sizes[4] = {sizeof(InstanceRec<R>), sizeof(RectRec<R>), sizeof(MovingSphereRec<R>), sizeof(BoxRec<R>)};
                 for (int k = 0; k < 4; ++k) {
                     const size_t bytes = lds_pad32(counts[k] * sizes[k]);
@@ -127,15 +135,15 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                     perlin_bytes += bytes;
                 }
                 {
-                    const size_t bytes = lds_pad32(s->flat.sphere_mat.size() * 4);
-                    if (!s->flat.sphere_mat.empty() && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes + bytes <= 160 * 1024) {
-                        rc.lds_recs[4] = uint32_t(s->flat.sphere_mat.size());
+                    const size_t bytes = lds_pad32(flat.sphere_mat.size() * 4);
+                    if (!flat.sphere_mat.empty() && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes + bytes <= 160 * 1024) {
+                        rc.lds_recs[4] = uint32_t(flat.sphere_mat.size());
                         perlin_bytes += bytes;
                     }
                 }
             }
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
-            const bool gen = s->flat.needs_general; // rare graph shapes: the instantiation that carries their code
+            const bool gen = flat.needs_general; // rare graph shapes: the instantiation that carries their code
             // a top tree of one or two levels (cornell_box: 6 nodes; its walks are mostly entered instances) takes three node steps per trip
             three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2;
             const bool tiny_tree = three_steps && !count; // (the counting variant's tallied loop is written for two: same steps per lane, same counters)
@@ -165,11 +173,11 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                 HIP_TRY(hipLaunchKernel(kernel, dim3(uint32_t(grid)), dim3(block), args, lds_bytes, stream));
             }
         } else {
-            const bool gen = s->flat.needs_general;
+            const bool gen = flat.needs_general;
             if constexpr (wave_walks_half<R>()) {
-                if (int h4 = ds.ensure_half4(s->flat)) return h4;  // this kernel walks the half-precision node-local records: made here, on the device, once
+                if (int h4 = ds.ensure_half4(flat)) return h4;  // this kernel walks the half-precision node-local records: made here, on the device, once
             } else if constexpr (wave_walks_quantised<R>()) {
-                if (int q4 = ds.ensure_quant4(s->flat)) return q4; // ... or the quantised ones
+                if (int q4 = ds.ensure_quant4(flat)) return q4; // ... or the quantised ones
             }
             auto kernel = count ? (gen ? trace_kernel<R, true, true> : trace_kernel<R, true, false>) : (gen ? trace_kernel<R, false, true> : trace_kernel<R, false, false>);
             const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
@@ -228,8 +236,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             stats->rays = hc.rays; stats->nodes_visited = hc.nodes; stats->prims_tested = hc.prims; stats->texel_fetches = hc.texels;
             if (getenv("RTTNW_DEBUG_SCHED")) debug_print_sched(hc, plain, rc.profile, stats->samples); // (debug_sched.cpp)
         }
-        stats->n_nodes = s->flat.total_nodes4();
-        stats->n_prims = s->flat.n_prims_in_bvh;
+        stats->n_nodes = flat.total_nodes4();
+        stats->n_prims = flat.n_prims_in_bvh;
         stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
         // which kernel form ran: bit 0 = decoupled (else lane-owns-path), bit 1 = node records resident in LDS (the form bench.py's
         // roofline calls issue-bound)
@@ -243,12 +251,19 @@ int probe_path_t(::rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
                  double* out, uint32_t max_out) {
     DeviceState* d = s->device;
     HIP_TRY(hipSetDevice(d->device));
-    DeviceScene<R>& ds = scene_of<R>(d);
+    const FlatScene* flat_p = &s->flat;
+    DeviceScene<R>* ds_p = &scene_of<R>(d);
+#if defined(RT_STRICT_F64)
+    if (int rc = reference_frame_scene(s, flat_p)) return rc;
+    if (flat_p != &s->flat) ds_p = &d->s64_ref;
+#endif
+    const FlatScene& flat = *flat_p;
+    DeviceScene<R>& ds = *ds_p;
     if (!ds.ready)
-        if (int rc = ds.upload(s->flat)) return rc;
+        if (int rc = ds.upload(flat)) return rc;
     RenderConsts rc{};
     rc.width = p->width; rc.height = p->height; rc.spp = p->spp; rc.max_depth = p->max_depth;
-    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = s->flat.stack_depth;
+    rc.quirks = p->quirks; rc.seed = p->seed; rc.stack_depth = flat.stack_depth;
     rc.inv_width = 1.0 / double(p->width); rc.inv_height = 1.0 / double(p->height);
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,

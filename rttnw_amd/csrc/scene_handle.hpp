@@ -3,6 +3,7 @@
 #pragma once
 #include "scene_lower.hpp"
 
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -25,6 +26,10 @@ void set_last_error(const std::string& msg);
 struct rttnw_scene {
     rt::SceneGraph graph;
     rt::FlatScene flat;
+    // The same graph lowered with the spheres of transformed groups LEFT in their groups' trees — every object tested in the frame the
+    // reference tests it in: what RTTNW_F64_STRICT renders (render_api.cpp reference_frame_scene: made at the first such render of a scene
+    // whose `flat` holds world-space copies; null otherwise).
+    std::unique_ptr<rt::FlatScene> flat_ref;
     bool committed = false;
     uint32_t n_media = 0;
     uint32_t bvh_builder = 0;      // RTTNW_BVH_*

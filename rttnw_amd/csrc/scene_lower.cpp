@@ -598,7 +598,8 @@ struct Lowering {
     int nesting = 0; // recursion guard: a list that (transitively) contains itself
     ItemVec* top_items = nullptr;
     std::vector<WorldSphere> world_spheres;
-    bool move_spheres = true;         // RTTNW_WORLD_SPHERES=0 keeps them in their groups' trees (experiments)
+    bool move_spheres = true;         // false keeps them in their groups' trees (lower_scene's world_spheres; RTTNW_WORLD_SPHERES)
+    int world_spheres_arg = -1;       // lower_scene's argument: -1 = the default above or the environment's word
 
     bool append_ops(Chain& c, const InstanceRec<double>& in) {
         for (int i = 0; i < in.n_ops; ++i) {
@@ -926,7 +927,8 @@ struct Lowering {
         const auto t_start = now();
         lower_textures_materials();
         const auto t_mats = now();
-        if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
+        if (world_spheres_arg >= 0) move_spheres = world_spheres_arg != 0;
+        else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
         ItemVec top;
         top_items = &top;
         collect(g.world, top, Chain{});
@@ -998,7 +1000,7 @@ struct Lowering {
 static bool fits_lds_form(const FlatScene& f) {
     return lds_form_bytes(f.total_nodes4(), f.stack_depth, 1024) <= 160 * 1024;
 }
-int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const DeviceBvhApi* builder, double time0, double time1) {
+int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const DeviceBvhApi* builder, double time0, double time1, int world_spheres) {
     const bool small = g.objs.size() <= 8192 && builder == nullptr;
     const char* forced = getenv("RTTNW_MAX_LEAF"); // experiments: force the leaf size of the host SAH build (1, 2 or 4)
     for (size_t max_leaf : {size_t(1), size_t(2), size_t(4)}) {
@@ -1007,7 +1009,9 @@ int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const Dev
         out = FlatScene();
         out.time0 = time0; out.time1 = time1;
         Lowering lw(g, out, err, builder, max_leaf, time0, time1);
+        lw.world_spheres_arg = world_spheres;
         const int rc = lw.run();
+        out.n_world_copies = uint32_t(lw.world_spheres.size());
         if (rc != 0 || max_leaf == 4 || fits_lds_form(out)) return rc;
     }
     return 0;

@@ -90,13 +90,16 @@ struct FlatScene {
     int32_t top_root = 0;
     uint32_t stack_depth = 4;         // entries a lane's traversal stack can need (exact bound for the 4-wide trees)
     uint32_t n_prims_in_bvh = 0;
+    uint32_t n_world_copies = 0;      // spheres of transformed groups that the walk tests as world-space copies in the top tree (scene_lower.cpp collect)
 };
 
 // Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.  `device` (optional)
 // replaces the host binned-SAH build for every tree of two or more leaves by the device builder (bvh_build.hpp); those
 // trees stay on the device.
+// `world_spheres`: 1 / 0 = test the spheres of transformed groups as world-space copies in the top tree / leave them in their groups' trees, in
+// the frame the reference tests them in (what RTTNW_F64_STRICT renders); -1 = the default (1, or RTTNW_WORLD_SPHERES).
 int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const DeviceBvhApi* device = nullptr, double time0 = 0.0,
-                double time1 = 1.0);
+                double time1 = 1.0, int world_spheres = -1);
 
 // Camera::new — camera.rs:32-61 (computed once on the host, in f64)
 void make_camera(const double lookfrom[3], const double lookat[3], const double view_up[3], double vfov_deg,

@@ -4,7 +4,6 @@
 OUT=gpurun_out/r04
 mkdir -p $OUT
 ROOT=$(pwd)
-python3 bench.py --steps 10 --warmup 2 > $OUT/bench_r04.json 2> $OUT/bench_r04.err
 for spec in "final_scene f64" "final_scene f32" "cornell_box f64" "spheres_1m f64strict" "spheres_1m f64" "spheres_1m f32"; do
   set -- $spec
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/stats_$1_$2 -- python3 $ROOT/bench.py --workload $1 --precision $2 --steps 4 --warmup 1 --cpu-seconds 0 --no-other --no-sub > $ROOT/$OUT/stats_$1_$2.log 2>&1 )
@@ -17,4 +16,8 @@ for spec in "final_scene f64" "final_scene f32" "cornell_box f64" "cornell_box f
   cp $OUT/pmc_$1_$2/summary.txt $OUT/pmc_$1_$2.txt
 done
 bash profiles/collect_phases.sh $OUT
+# the default bench line LAST, with this run's PMC summaries in place (bench.py reads roofline.valu / traffic from profiles/r04 while their
+# kernel_source_sha is the tree's)
+cp $OUT/pmc_*.txt profiles/r04/
+python3 bench.py --steps 10 --warmup 2 > $OUT/bench_r04.json 2> $OUT/bench_r04.err
 ls $OUT

@@ -3,6 +3,9 @@
 #pragma once
 #include "trace_kernels.hpp"
 
+#ifndef RT_TINY_TREE_STEPS
+#define RT_TINY_TREE_STEPS 3 // node steps per walk trip of the lane-owns-path kernel for top trees of <= 16 nodes (RT_NODE_STEPS otherwise)
+#endif
 namespace rt {
 inline namespace RT_ARITH_NS {
 
@@ -148,7 +151,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2;
             const bool tiny_tree = three_steps && !count; // (the counting variant's tallied loop is written for two: same steps per lane, same counters)
             const void* kernel =
-                tiny_tree ? (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true, 3> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false, 3>) :
+                tiny_tree ? (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false, RT_TINY_TREE_STEPS>) :
                 want_lds ? (count ? (gen ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, false>)
                                   : (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false>))
                          : (count ? (gen ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, false>)

@@ -44,7 +44,7 @@ namespace rt {
 #ifndef RT_F64_SLAB_FOLDED
 #define RT_F64_SLAB_FOLDED 2 // the f64 kernels' box test: 0 every box's entry / exit widened by 3.6e-7 |t| + slack (15 operations per box), 1 the widening in per-walk
                              // constants for both ends (11, five registers more: spills), 2 the slack in the constants and one multiplication per entry (12, two
-                             // registers more), 3 one fma per end (13).  Measured (final_scene / cornell_box f64, Msamples/s): 1364 / 1692, 1370 / 1589, 1393 / 1727, -
+                             // registers more), 3 one fma per end (13).  Measured (final_scene / cornell_box f64, Msamples/s): 1364 / 1692, 1370 / 1589, 1393 / 1727, 1.5-2 % behind 2
 #endif
 inline namespace RT_ARITH_NS {
 

@@ -421,6 +421,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
     }
 }
 
+// The f64 translation unit that holds the launch code is built with the pre-RA machine scheduler off (Makefile: the lane-owns-path kernel's
+// 128 registers), which costs THIS kernel 10 % (spheres_1m f64 280 -> 308 Msamples/s without the flag): its contracted f64 instantiations are
+// compiled in a unit of their own (render_f64_wave.hip) and only declared where they are launched.
+#if defined(RT_F64_WAVE_KERNELS_ELSEWHERE)
+#define RT_WAVE_DECL(COUNT, GENERAL)                                                                                                                      \
+    extern template __global__ void trace_kernel<double, COUNT, GENERAL>(SceneView<double>, CameraRec<double>, RenderConsts, double, double, double, double, \
+                                                                         double*, unsigned long long*, DeviceCounters*, double*, uint32_t*, uint32_t, int32_t*);
+RT_WAVE_DECL(false, false) RT_WAVE_DECL(false, true) RT_WAVE_DECL(true, false) RT_WAVE_DECL(true, true)
+#undef RT_WAVE_DECL
+#endif
+
 // The plain form of the same loop: a lane OWNS a path (and its job) and alternates "regenerate or advance by one
 // bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
 // bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the

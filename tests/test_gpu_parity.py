@@ -685,12 +685,18 @@ def test_config3_final_scene_1600_at_spp_10000_across_eight_ranks(gpu, oracle, h
     torch.cuda.synchronize()
     assert st5.samples == w * h * spp // 8
     assert np.array_equal(dr.packed.cpu().numpy()[:, :3], tiles.pack_rank(one, 5, 8)[:, :3])
+    # ... and the frame through RTTNW_F64_STRICT (the reference's operations in the reference's frames): no remainder at spp 10 000 either
+    _, ps = util.params_for(setup, w, h, spp, precision=abi.F64_STRICT)
+    strict, rgba_s, _ = gpu_render(gpu, sc, cam, ps)
     for (x0, y0) in [(500, 1100), (1020, 580)]:
         lo, ro, _, _ = rto.render_window(so, cam, p, x0, y0, x0 + 32, y0 + 24)
         d = np.abs(one[y0:y0 + 24, x0:x0 + 32] - lo).max(axis=2)
-        print("final_scene 1600x1600 spp 10000 crop (%d, %d): %d of 768 pixels beyond 1e-9, max |delta| %.3g" % (x0, y0, int((d > T1_ABS).sum()), d.max()))
+        d_s = np.abs(strict[y0:y0 + 24, x0:x0 + 32] - lo).max(axis=2)
+        print("final_scene 1600x1600 spp 10000 crop (%d, %d): RTTNW_F64 %d of 768 pixels beyond 1e-9, max |delta| %.3g; RTTNW_F64_STRICT max |delta| %.3g"
+              % (x0, y0, int((d > T1_ABS).sum()), d.max(), d_s.max()))
         assert (d <= T1_ABS).mean() >= 0.95 and d.max() <= 1e-6, (x0, y0, (d <= T1_ABS).mean(), d.max())
         assert (rgba[y0:y0 + 24, x0:x0 + 32] == ro).all(axis=2).mean() >= 0.999
+        assert d_s.max() <= 1e-11 and np.array_equal(rgba_s[y0:y0 + 24, x0:x0 + 32], ro), (x0, y0, d_s.max())
 
 
 _RCCL_SCRIPT = r"""

@@ -311,13 +311,13 @@ def main():
                                 "frac ~ issue_utilisation x lane_utilisation"}
             lds_resident = (form & 2) != 0   # rttnw_stats.reserved bit 1: the launch kept the node records in LDS (the library's own choice)
             node_steps = 3 if (form & 4) else 2   # bit 2: the instantiation with three node steps per walk trip (tiny top trees)
-            form &= 1
-            # the instantiation that ran, as rocprofv3's kernel trace names it (<R, COUNT, BLOCK, LDS nodes, GENERAL, node steps per trip>; the bench
+            # the instantiation that ran, as rocprofv3's kernel trace names it (<R, COUNT, BLOCK, LDS nodes, SHAPES, node steps per trip>; the bench
             # scenes have none of the rare graph shapes of the GENERAL instantiations)
             rname = "float" if prec == abi.F32 else "double"
             ns = "rt::ieee_strict" if prec == abi.F64_STRICT else "rt::contracted"   # (rt_core.hpp: the two builds of the arithmetic)
-            kernel = ("%s::trace_kernel<%s, false, false>" % (ns, rname) if form != 0 else
-                      "%s::trace_kernel_plain<%s, false, %s, false, %d>" % (ns, rname, "1024, true" if lds_resident else "256, false", node_steps))
+            shapes = 2 if (form & 8) else 0   # bit 3: the decoupled kernel's instantiation for scenes without instance records (rt_core.hpp SHAPES_NONE)
+            kernel = ("%s::trace_kernel<%s, false, %d>" % (ns, rname, shapes) if (form & 1) != 0 else
+                      "%s::trace_kernel_plain<%s, false, %s, %d, %d>" % (ns, rname, "1024, true" if lds_resident else "256, false", shapes, node_steps))
             common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),
                       "per_sample": {k: round(v, 3) for k, v in per.items()},
                       "grays_per_s": round(per["rays"] * self.samples_rank / secs / 1e9, 3) if secs > 0 else None,  # world.hit() calls / s

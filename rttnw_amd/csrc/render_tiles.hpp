@@ -108,6 +108,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         return grow(&d->spill, &d->spill_bytes, std::max<size_t>(threads * extra, 1) * sizeof(int32_t));
     };
     bool three_steps = false; // the lane-owns-path kernel's instantiation with three node steps per trip (tiny top trees)
+    bool no_inst = false;     // the decoupled kernel's instantiation for scenes without instance records
     // One pass: trace kernel over the pass's jobs, then the resolve step.
     auto trace_pass = [&]() -> int {
         const size_t n_jobs = rc.n_jobs;
@@ -148,10 +149,14 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             const int block = want_lds ? LDS_BLOCK : TRACE_BLOCK;
             const bool gen = flat.needs_general; // rare graph shapes: the instantiation that carries their code
             // a top tree of one or two levels (cornell_box: 6 nodes; its walks are mostly entered instances) takes three node steps per trip
-            three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2;
+            // ... and a scene whose walk never changes frames the instantiation without instance code (rt_core.hpp SHAPES_NONE: final_scene — its one
+            // instance record is the bare chain of the cluster's world-space copies)
+            const bool lds_no_inst = want_lds && !gen && !count && !flat.walk_changes_frames;
+            three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2 && !lds_no_inst;
             const bool tiny_tree = three_steps && !count; // (the counting variant's tallied loop is written for two: same steps per lane, same counters)
             const void* kernel =
-                tiny_tree ? (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false, RT_TINY_TREE_STEPS>) :
+                lds_no_inst ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE> :
+                tiny_tree ? (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_GENERAL, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_FAST, RT_TINY_TREE_STEPS>) :
                 want_lds ? (count ? (gen ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, false>)
                                   : (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false>))
                          : (count ? (gen ? (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, true> : (const void*)trace_kernel_plain<R, true, TRACE_BLOCK, false, false>)
@@ -182,7 +187,10 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             } else if constexpr (wave_walks_quantised<R>()) {
                 if (int q4 = ds.ensure_quant4(flat)) return q4; // ... or the quantised ones
             }
-            auto kernel = count ? (gen ? trace_kernel<R, true, true> : trace_kernel<R, true, false>) : (gen ? trace_kernel<R, false, true> : trace_kernel<R, false, false>);
+            // (a scene without any instance record takes the instantiation whose walk never changes frames, rt_core.hpp SHAPES_NONE)
+            no_inst = !gen && !count && !flat.walk_changes_frames;
+            auto kernel = count ? (gen ? trace_kernel<R, true, SHAPES_GENERAL> : trace_kernel<R, true, SHAPES_FAST>)
+                                : (gen ? trace_kernel<R, false, SHAPES_GENERAL> : (no_inst ? trace_kernel<R, false, SHAPES_NONE> : trace_kernel<R, false, SHAPES_FAST>));
             const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
             size_t grid = 1;
             if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
@@ -244,7 +252,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
         // which kernel form ran: bit 0 = decoupled (else lane-owns-path), bit 1 = node records resident in LDS (the form bench.py's
         // roofline calls issue-bound)
-        stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u) | (plain && three_steps ? 4u : 0u);
+        stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u) | (plain && three_steps ? 4u : 0u) | (!flat.needs_general && !flat.walk_changes_frames && (!plain || rc.lds_nodes != 0u) ? 8u : 0u);
     }
     return RTTNW_OK;
 }

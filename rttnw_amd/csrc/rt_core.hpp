@@ -299,23 +299,30 @@ template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bo
 // Counter policies.  Their template flag GENERAL also selects, at compile time, whether the code for the rare graph shapes
 // (more than FAST_INSTANCE_OPS wrappers around an object, List / BvhTree medium boundaries, media inside transformed groups;
 // FlatScene::needs_general) is compiled into a kernel at all: it costs the common kernels registers even when it never runs.
-template <bool G> struct NoCountersT {
-    static constexpr bool GENERAL = G;
+// Since round 4 the flag has a third value: SHAPES_NONE = a scene without ANY instance record (no Translate / YRotate wrapper that survived the
+// lowering: spheres_1m, random_scene): the walk then never changes frames, so its per-lane copy of the ray in the current frame, the sentinel
+// test of every pop and the instance branch of the leaf step are compiled out — 14 registers in the f64 decoupled kernel, which is held to
+// 168 for its third wave: scratch 120 -> 52 B per lane, spheres_1m f64 310 -> 325 Msamples/s, RTTNW_F64_STRICT 300 -> 320.
+enum : int { SHAPES_FAST = 0, SHAPES_GENERAL = 1, SHAPES_NONE = 2 };
+template <int G> struct NoCountersT {
+    static constexpr bool GENERAL = G == SHAPES_GENERAL;
+    static constexpr bool NO_INST = G == SHAPES_NONE;
     RT_HD void ray() {}
     RT_HD void node() {}
     RT_HD void prim() {}
     RT_HD void texel() {}
 };
-template <bool G> struct LaneCountersT {
-    static constexpr bool GENERAL = G;
+template <int G> struct LaneCountersT {
+    static constexpr bool GENERAL = G == SHAPES_GENERAL;
+    static constexpr bool NO_INST = G == SHAPES_NONE;
     uint32_t rays = 0, nodes = 0, prims = 0, texels = 0;
     RT_HD void ray() { ++rays; }
     RT_HD void node() { ++nodes; }
     RT_HD void prim() { ++prims; }
     RT_HD void texel() { ++texels; }
 };
-using NoCounters = NoCountersT<true>;     // host build, probes: every shape
-using LaneCounters = LaneCountersT<true>;
+using NoCounters = NoCountersT<SHAPES_GENERAL>;     // host build, probes: every shape
+using LaneCounters = LaneCountersT<SHAPES_GENERAL>;
 
 // ---------------------------------------------------------------- camera (camera.rs:63-84)
 template <typename R>
@@ -881,11 +888,11 @@ template <typename R, typename Stack> RT_HD void trav_begin(Trav<R>& tr, const S
 }
 
 // Take the next pending subtree off the stack (leaving an instance when its sentinel comes up).
-template <typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray<R>& wray, Stack& stack) {
+template <bool NO_INST = false, typename R, typename Stack> RT_HD void trav_pop(Trav<R>& tr, const Ray<R>& wray, Stack& stack) {
     tr.leaf_k = 0;
     if (tr.sp == 0) { tr.node = TRAV_DONE; return; }
     int32_t node = stack.get(--tr.sp);
-    if (node == STACK_SENTINEL) {
+    if (!NO_INST && node == STACK_SENTINEL) { // (a scene without instances never pushes one)
         trav_set_ray(tr, wray, stack);
         tr.cur_inst = -1;
         if (tr.sp == 0) { tr.node = TRAV_DONE; return; }
@@ -921,12 +928,12 @@ RT_HD float bits_float(uint32_t u) {
 // The second half of a 4-wide node step: order the (key, child) pairs (key = the bits of the entry distance, MISS_KEY for a miss),
 // descend into the nearest hit child, push the others farthest first.
 constexpr uint32_t MISS_KEY = 0xFFFFFFFFu;
-template <typename R, typename Stack>
+template <bool NO_INST = false, typename R, typename Stack>
 RT_HD void trav_descend_sorted4(Trav<R>& tr, const Ray<R>& wray, Stack& stack, uint32_t* k, int32_t* ch) {
     constexpr uint32_t MISS = MISS_KEY;
     pair_swap(k[0], ch[0], k[1], ch[1]); pair_swap(k[2], ch[2], k[3], ch[3]); pair_swap(k[0], ch[0], k[2], ch[2]);
     pair_swap(k[1], ch[1], k[3], ch[3]); pair_swap(k[1], ch[1], k[2], ch[2]);
-    if (k[0] == MISS) { trav_pop(tr, wray, stack); return; }
+    if (k[0] == MISS) { trav_pop<NO_INST>(tr, wray, stack); return; }
     // the other hit children become pending, farthest first
     const int32_t n_push = int32_t(k[1] != MISS) + int32_t(k[2] != MISS) + int32_t(k[3] != MISS);
     const int32_t sp = tr.sp;
@@ -956,7 +963,7 @@ RT_HD void trav_node_step4(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wr
     int32_t ch[4];
     float e[4];
     bool h[4];
-    slab_hit4<slab_form<Stack, R>()>(nd, tr.ray.o, tr.sr, lo_t, hi_t, e, h);
+    slab_hit4<slab_form<Stack, R>()>(nd, (Cnt::NO_INST ? wray : tr.ray).o, tr.sr, lo_t, hi_t, e, h);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         ch[c] = nd.child[c];
@@ -969,7 +976,7 @@ RT_HD void trav_node_step4(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wr
         k[c] = h[c] ? float_bits(e[c]) : MISS;
 #endif
     }
-    trav_descend_sorted4(tr, wray, stack, k, ch);
+    trav_descend_sorted4<Cnt::NO_INST>(tr, wray, stack, k, ch);
 }
 // ---- the same step over a 4-wide QUANTISED record (rt_types.hpp Bvh4QNode: four 16-byte pieces instead of the f32 record's seven).
 // Plane distances: with D = org - o, A = D inv, S = step inv (step a power of two: exact), a child's plane at org + q step lies at
@@ -994,7 +1001,8 @@ RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
     cnt.node();
     float lo_t, hi_t;
     slab_range(t_min, tr.closest, lo_t, hi_t);
-    const R oo[3] = {tr.ray.o.x, tr.ray.o.y, tr.ray.o.z};
+    const Ray<R>& cray = Cnt::NO_INST ? wray : tr.ray; // the ray in the current frame
+    const R oo[3] = {cray.o.x, cray.o.y, cray.o.z};
     float A[3], S[3];
     uint32_t near_w[3], far_w[3]; // the four children's near / far plane bytes of axis a
     float smax = 0.f;
@@ -1031,7 +1039,7 @@ RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
         k[c] = !(hi < lo) ? float_bits(lo) : MISS_KEY;
 #endif
     }
-    trav_descend_sorted4(tr, wray, stack, k, ch);
+    trav_descend_sorted4<Cnt::NO_INST>(tr, wray, stack, k, ch);
 }
 
 // ---- the same step over a HALF-PRECISION NODE-LOCAL record (rt_types.hpp Bvh4HNode: five 16-byte pieces).  The box planes are halves
@@ -1060,7 +1068,8 @@ RT_HD void trav_node_step4h(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
     cnt.node();
     float lo_t, hi_t;
     slab_range(t_min, tr.closest, lo_t, hi_t);
-    const R oo[3] = {tr.ray.o.x, tr.ray.o.y, tr.ray.o.z};
+    const Ray<R>& cray = Cnt::NO_INST ? wray : tr.ray; // the ray in the current frame
+    const R oo[3] = {cray.o.x, cray.o.y, cray.o.z};
     float a_lo[3], a_hi[3], inv_lo[3], inv_hi[3];
     uint32_t near_w[3][2], far_w[3][2]; // the four children's near / far planes of axis a, two halves to a word
 #pragma unroll
@@ -1107,7 +1116,7 @@ RT_HD void trav_node_step4h(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
         k[c] = !(hi < lo) ? float_bits(lo) : MISS_KEY;
 #endif
     }
-    trav_descend_sorted4(tr, wray, stack, k, ch);
+    trav_descend_sorted4<Cnt::NO_INST>(tr, wray, stack, k, ch);
 }
 
 template <typename R, typename Stack, typename Cnt>
@@ -1120,10 +1129,11 @@ RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
 // One step at a leaf (tr.node < 0, not TRAV_DONE): enter an instance, or test ONE primitive record.  WHOLE_LEAF tests
 // all (<= 4) records of the leaf in one step instead — the same tests in the same order; measured 10-14 % SLOWER in
 // the lockstep kernel (lanes with a one-record leaf wait instead of going on with node steps), so nothing uses it.
-template <typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min) {
+// (`ray`: the walk's ray in the current frame — tr.ray, or the world ray itself where the scene has no instances)
+template <typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray) {
     R t;
     int aux = 0;
-    if (prim_t(sc, kind, idx, tr.ray, t_min, tr.closest, t, aux)) {
+    if (prim_t(sc, kind, idx, ray, t_min, tr.closest, t, aux)) {
         // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
         const bool loses_tie = tr.found && t == tr.closest &&
                                prim_seq(sc, kind, idx) < prim_seq(sc, ref_kind(tr.best.prim), ref_index(tr.best.prim));
@@ -1138,9 +1148,10 @@ template <typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R
 }
 template <bool WHOLE_LEAF = false, typename R, typename Stack, typename Cnt>
 RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
-    if (tr.node == CHILD_EMPTY) { trav_pop(tr, wray, stack); return; }
+    constexpr bool NI = Cnt::NO_INST;
+    if (tr.node == CHILD_EMPTY) { trav_pop<NI>(tr, wray, stack); return; }
     const uint32_t kind = leaf_kind(tr.node), count = leaf_count(tr.node), first = leaf_first(tr.node);
-    if (kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
+    if (!NI && kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
         cnt.prim();
         const InstanceRec<R>& in_rec = sc.insts[first];
         const InstanceHead<R> head = head_of(in_rec); // one by-value copy serves the transform below
@@ -1155,7 +1166,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
             tr.ray = object_ray();
             tr.cur_inst = int32_t(first);
             cnt.prim();
-            trav_test_record(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min);
+            trav_test_record(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min, tr.ray);
             tr.ray = outer;
             tr.cur_inst = outer_inst;
             trav_pop(tr, wray, stack);
@@ -1170,13 +1181,13 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     if constexpr (WHOLE_LEAF) {
         for (uint32_t k = 0; k < count; ++k) {
             cnt.prim();
-            trav_test_record(tr, sc, kind, first + k, t_min);
+            trav_test_record(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray);
         }
-        trav_pop(tr, wray, stack);
+        trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
-        trav_test_record(tr, sc, kind, first + tr.leaf_k, t_min);
-        if (++tr.leaf_k >= count) trav_pop(tr, wray, stack);
+        trav_test_record(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray);
+        if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }
 }
 

@@ -121,8 +121,8 @@ template <uint32_t STRIDE> struct LdsStackNodes : LdsStack<STRIDE> {
     }
 };
 
-template <bool COUNT, bool GENERAL> struct CounterSel { using type = NoCountersT<GENERAL>; };
-template <bool GENERAL> struct CounterSel<true, GENERAL> { using type = LaneCountersT<GENERAL>; };
+template <bool COUNT, int SHAPES> struct CounterSel { using type = NoCountersT<SHAPES>; }; // SHAPES: rt_core.hpp SHAPES_FAST / SHAPES_GENERAL / SHAPES_NONE
+template <int SHAPES> struct CounterSel<true, SHAPES> { using type = LaneCountersT<SHAPES>; };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
@@ -205,7 +205,7 @@ template <typename T> __device__ __forceinline__ T kernarg_reload(uint32_t offse
 template <typename R> struct TraceArgsHead { SceneView<R> sc; CameraRec<R> cam; RenderConsts rc; };
 static_assert(alignof(SceneView<float>) <= 8 && alignof(CameraRec<double>) <= 8 && alignof(RenderConsts) <= 8, "kernarg_reload assumes naturally aligned arguments");
 
-template <typename R, bool COUNT, bool GENERAL>
+template <typename R, bool COUNT, int GENERAL> // GENERAL: SHAPES_FAST (0) / SHAPES_GENERAL (1) / SHAPES_NONE (2: the scene has no instance record, rt_core.hpp)
 // (at least 3 waves/SIMD: 170 VGPRs — the f32 code needs 164; the f64 code, allowed 256, ran at 2 waves/SIMD and waited on
 // the fabric: spheres_1m f64 167 -> 264 Msamples/s with 140 registers spilled; 4 waves/SIMD: 205)
 __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 #define RT_WAVE_DECL(COUNT, GENERAL)                                                                                                                      \
     extern template __global__ void trace_kernel<double, COUNT, GENERAL>(SceneView<double>, CameraRec<double>, RenderConsts, double, double, double, double, \
                                                                          double*, unsigned long long*, DeviceCounters*, double*, uint32_t*, uint32_t, int32_t*);
-RT_WAVE_DECL(false, false) RT_WAVE_DECL(false, true) RT_WAVE_DECL(true, false) RT_WAVE_DECL(true, true)
+RT_WAVE_DECL(false, SHAPES_FAST) RT_WAVE_DECL(false, SHAPES_GENERAL) RT_WAVE_DECL(false, SHAPES_NONE) RT_WAVE_DECL(true, SHAPES_FAST) RT_WAVE_DECL(true, SHAPES_GENERAL)
 #undef RT_WAVE_DECL
 #endif
 
@@ -437,7 +437,7 @@ RT_WAVE_DECL(false, false) RT_WAVE_DECL(false, true) RT_WAVE_DECL(true, false) R
 // bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
 // decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
 // NSTEPS: node steps per trip round the walk loop (rt_core.hpp closest_solid): RT_NODE_STEPS, or 3 for tiny top trees (render_tiles.hpp).
-template <typename R, bool COUNT, int BLOCK, bool LDSN, bool GENERAL, int NSTEPS = RT_NODE_STEPS>
+template <typename R, bool COUNT, int BLOCK, bool LDSN, int GENERAL, int NSTEPS = RT_NODE_STEPS> // GENERAL: SHAPES_FAST / SHAPES_GENERAL / SHAPES_NONE, as above
 // (the 256-thread form — nodes in global memory — asks for at least 3 waves/SIMD like the decoupled kernel: its f64 code,
 // allowed 256 VGPRs, ran at 2: a 20 000-sphere scene 29.9 -> 13.7 ms per 67 Msamples)
 __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plain(SceneView<R> sc_arg, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,

@@ -232,7 +232,7 @@ def test_config5_spheres_1m_at_its_size_vs_oracle(gpu, oracle, scenes_lib):
     for name, prec in (("strict", abi.F64_STRICT), ("f64", abi.F64), ("f32", abi.F32)):
         cam, p = util.params_for(setup, w, h, spp, precision=prec)
         lin, rgba, st = gpu_render(gpu, sg, cam, p)
-        assert st.samples == w * h * spp and st.reserved == 1 and np.isfinite(lin).all(), name
+        assert st.samples == w * h * spp and st.reserved == 9 and np.isfinite(lin).all(), name   # the decoupled kernel (bit 0), the instantiation without instance code (bit 3)
         out[name] = (lin, rgba)
     cam, p64 = util.params_for(setup, w, h, spp, precision=abi.F64)
     n_px = n_bound32 = n_lsb64 = 0
@@ -355,12 +355,23 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
     monkeypatch.setenv("RTTNW_KERNEL", "plain")
     p.collect_counters = 0
     lin, rgba, st = gpu_render(gpu, sc, cam, p)
-    assert ((st.reserved & 4) != 0) == ((st.reserved & 2) != 0 and st.n_nodes <= 16), (st.reserved, st.n_nodes)
-    assert ((st.reserved & 4) != 0) == (name in ("cornell_box", "smoke_cornell_box"))
+    assert ((st.reserved & 4) != 0) == ((st.reserved & 2) != 0 and st.n_nodes <= 16 and (st.reserved & 8) == 0), (st.reserved, st.n_nodes)
+    assert ((st.reserved & 4) != 0) == (name == "cornell_box")
+    # (bit 3: a walk that never changes frames — spheres_1m; final_scene, whose only instance record is the bare chain of the cluster's world-space
+    # copies; smoke_cornell_box, whose rotated boxes are medium boundaries, not solids in a tree)
+    assert ((st.reserved & 8) != 0) == (name != "cornell_box" and (st.reserved & 2) != 0), st.reserved   # (the LDS form of this kernel has that instantiation)
     if precision == abi.F64:
         assert np.array_equal(lin, out["plain"][0]) and np.array_equal(rgba, out["plain"][1])
     else:
         assert ((np.abs(lin - out["plain"][0]).max(axis=2)) > 0).mean() <= 2e-3
+    # ... and the decoupled kernel's: a scene without any instance record takes the instantiation whose walk never changes frames (bit 3)
+    monkeypatch.setenv("RTTNW_KERNEL", "wave")
+    lin, rgba, st = gpu_render(gpu, sc, cam, p)
+    assert ((st.reserved & 8) != 0) == (name != "cornell_box"), st.reserved
+    if precision == abi.F64:
+        assert np.array_equal(lin, out["wave"][0]) and np.array_equal(rgba, out["wave"][1])
+    else:
+        assert ((np.abs(lin - out["wave"][0]).max(axis=2)) > 0).mean() <= 2e-3
 
 
 def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):
@@ -369,7 +380,7 @@ def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):
     sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=150000)
     cam, p = util.params_for(setup, 64, 64, 4, precision=abi.F32, seed=3)
     lin, rgba, st = gpu_render(gpu, sc, cam, p)
-    assert st.reserved == 1 and st.n_nodes >= 65536
+    assert (st.reserved & 1) == 1 and st.n_nodes >= 65536
     import os
     os.environ["RTTNW_KERNEL"] = "plain"
     try:

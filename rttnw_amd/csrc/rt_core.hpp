@@ -1574,7 +1574,7 @@ RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, 
 template <typename R> struct PathState {
     Ray<R> ray;
     V3<R> throughput; // product of attenuations so far
-    V3<R> radiance;   // sum of throughput * emitted
+    V3<R> radiance;   // the finished path's value (set by the path's LAST path_shade: see there)
     uint64_t key;
     uint32_t bounce;
 };
@@ -1600,12 +1600,15 @@ RT_HD void path_begin(PathState<R>& ps, const CameraRec<R>& cam, const RenderCon
     }
     ps.ray = camera_ray(cam, u, v, ps.key, (rc.scene_flags & SCENE_NO_TIME) == 0u);
     ps.throughput = V3<R>(R(1), R(1), R(1));
-    ps.radiance = V3<R>();
     ps.bounce = 0;
 }
 
 // One world.hit + shade: the body of color() (main.rs:26-45) unrolled into a loop:
 //   L = sum_k (prod_{i<k} att_i) * emitted_k  (+ throughput * background on a miss).
+// Only the LAST term of that sum can be non-zero — nothing that emits scatters (material.rs:242-250: DiffuseLight::scatter is None; every other
+// material emits black) — so the sum is not carried through the path: every call sets ps.radiance to ITS term, and what the last call of a
+// path leaves there is the path's value, bit for bit what the carried sum was (0 + x = x; the earlier terms were throughput * 0).  Three
+// reals fewer alive across the BVH walk (six registers in the f64 kernels) and out of the decoupled kernel's path-state pool.
 // path_shade(): the part after the BVH walk (media, hit record, emitted/scatter, bookkeeping).
 // Returns true while the path is alive.
 template <typename R, typename Cnt>
@@ -1613,12 +1616,12 @@ RT_HD bool path_shade(PathState<R>& ps, const SceneView<R>& sc, const RenderCons
                       R closest, HitRef best, Cnt& cnt) {
     HitRecord<R> rec;
     if (!world_hit_finish(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, found, closest, best, rec, cnt)) {
-        ps.radiance = ps.radiance + ps.throughput * background;
+        ps.radiance = ps.throughput * background;
         return false;
     }
     V3<R> att, emitted;
     bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, emitted, cnt);
-    ps.radiance = ps.radiance + ps.throughput * emitted;
+    ps.radiance = ps.throughput * emitted;
     if (!cont) return false;
     ps.throughput = ps.throughput * att;
     ps.bounce += 1;

@@ -159,7 +159,8 @@ constexpr uint32_t SLOTS_PER_WAVE = 128; // paths owned by one wave64: 64 being 
 constexpr uint32_t QCAP = 128;           // capacity of a wave's ray queue and hit queue (entries)
 
 // Path state of a slot, in global memory (L2-resident), struct-of-arrays over all slots of the launch.
-enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_LX, PR_LY, PR_LZ, PR_AX, PR_AY, PR_AZ, PR_COUNT };
+// (no radiance: a path's value is the term of its last bounce, rt_core.hpp path_shade — round 4; 13 reals a slot instead of 16)
+enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_AX, PR_AY, PR_AZ, PR_COUNT };
 enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
 // bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
 // LDS stack entries of the decoupled kernel: 16 for f32; 12 for f64, whose queues are twice as wide — with 16 a 256-thread
@@ -276,7 +277,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                 ps.ray.d = V3<R>(pr[size_t(PR_DX) * n_slots], pr[size_t(PR_DY) * n_slots], pr[size_t(PR_DZ) * n_slots]);
                 ps.ray.time = pr[size_t(PR_TIME) * n_slots];
                 ps.throughput = V3<R>(pr[size_t(PR_TX) * n_slots], pr[size_t(PR_TY) * n_slots], pr[size_t(PR_TZ) * n_slots]);
-                ps.radiance = V3<R>(pr[size_t(PR_LX) * n_slots], pr[size_t(PR_LY) * n_slots], pr[size_t(PR_LZ) * n_slots]);
                 ps.key = (unsigned long long)pu[size_t(PU_KEY_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_KEY_HI) * n_slots] << 32);
                 ps.bounce = pu[size_t(PU_BOUNCE) * n_slots];
                 HitRef best;
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                 pr[size_t(PR_DX) * n_slots] = ps.ray.d.x; pr[size_t(PR_DY) * n_slots] = ps.ray.d.y; pr[size_t(PR_DZ) * n_slots] = ps.ray.d.z;
                 pr[size_t(PR_TIME) * n_slots] = ps.ray.time;
                 pr[size_t(PR_TX) * n_slots] = ps.throughput.x; pr[size_t(PR_TY) * n_slots] = ps.throughput.y; pr[size_t(PR_TZ) * n_slots] = ps.throughput.z;
-                pr[size_t(PR_LX) * n_slots] = ps.radiance.x; pr[size_t(PR_LY) * n_slots] = ps.radiance.y; pr[size_t(PR_LZ) * n_slots] = ps.radiance.z;
                 pu[size_t(PU_BOUNCE) * n_slots] = ps.bounce;
                 const uint32_t idx = ray_n + uint32_t(__popcll(em & lanes_below));
                 rq_f[0u * QCAP + idx] = ps.ray.o.x; rq_f[1u * QCAP + idx] = ps.ray.o.y; rq_f[2u * QCAP + idx] = ps.ray.o.z;

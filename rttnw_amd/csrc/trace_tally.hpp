@@ -89,12 +89,12 @@ __device__ __forceinline__ void plain_round_tallied(bool done, bool& alive, uint
         const bool hit = world_hit_finish(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, found, closest, best, rec, cnt);
         tk3b = clock64();
         if (!hit) {
-            ps.radiance = ps.radiance + ps.throughput * background;
+            ps.radiance = ps.throughput * background;
             alive = false;
         } else {
             V3<R> att, emitted;
             const bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, emitted, cnt);
-            ps.radiance = ps.radiance + ps.throughput * emitted;
+            ps.radiance = ps.throughput * emitted;
             if (cont) { ps.throughput = ps.throughput * att; ps.bounce += 1; }
             alive = cont && ps.bounce < rc.max_depth;
         }

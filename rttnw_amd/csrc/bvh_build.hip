@@ -880,23 +880,7 @@ __global__ void quant4_make_kernel(const Bvh4Node* __restrict__ nodes4, uint32_t
     quant4_make(nodes4, int32_t(i), o);
     out[i] = o;
 }
-__global__ void half4_make_kernel(const Bvh4Node* __restrict__ nodes4, uint32_t n, Bvh4HNode* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Bvh4HNode o;
-    half4_make(nodes4, int32_t(i), o);
-    out[i] = o;
-}
 } // namespace
-
-int half4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4HNode* d_out, std::string& err) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(half4_make_kernel, dim3((n + 127) / 128), dim3(128), 0, 0, d_nodes4, n, d_out);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) { err = std::string("half4_build: ") + hipGetErrorString(e); return -4; }
-    return 0;
-}
 
 int quant4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4QNode* d_out, std::string& err) {
     if (n == 0) return 0;

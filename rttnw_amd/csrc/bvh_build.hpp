@@ -61,7 +61,5 @@ int device_tree_rebase(DeviceTree& tree, uint32_t base4, uint32_t base2, std::st
 // The scene's f32 4-wide records (on the current device) -> the quantised records the f64 decoupled kernel walks (rt_types.hpp
 // Bvh4QNode, bvh_quant.hpp), index for index, into d_out[0, n).  Synchronous.
 int quant4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4QNode* d_out, std::string& err);
-// ... -> the half-precision node-local records (Bvh4HNode).
-int half4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4HNode* d_out, std::string& err);
 
 } // namespace rt

@@ -55,50 +55,4 @@ RT_HD void quant4_make(const Bvh4Node* nodes4, int32_t i, Bvh4QNode& out) {
     for (int c = 0; c < 4; ++c) out.child[c] = nd.child[c];
 }
 
-// ---- half-precision node-local records (rt_types.hpp Bvh4HNode) ----
-// binary16 bits of the largest half <= x (x >= 0) / the smallest half >= x, by bit manipulation of the float (no hardware conversion:
-// the rounding DIRECTION is the point).  Halves below the smallest normal (6.1e-5) are avoided: a positive hi rounds up to it at least.
-RT_HD uint16_t half_down(float x) { // x >= 0 (or NaN -> 0)
-    if (!(x > 0.f)) return 0;
-    if (x >= 65504.f) return x < INFINITY ? 0x7BFFu : 0x7C00u; // the largest finite half (or +inf for +inf)
-    if (x < 6.103515625e-5f) return 0;                           // below the smallest normal: down to zero
-    uint32_t bits;
-    __builtin_memcpy(&bits, &x, 4);
-    const uint32_t e = (bits >> 23) - 112u, m = (bits >> 13) & 1023u; // truncation of the mantissa rounds a positive value down
-    return uint16_t((e << 10) | m);
-}
-RT_HD uint16_t half_up(float x) { // x >= 0
-    if (!(x > 0.f)) return 0;
-    if (x > 65504.f) return 0x7C00u;                              // +inf
-    if (x <= 6.103515625e-5f) return 0x0400u;                     // the smallest normal
-    uint16_t h = half_down(x);
-    if (half_bits_to_float(h) < x) ++h;                           // (mantissa overflow carries into the exponent: the next half; 0x7BFF + 1 = inf)
-    return h;
-}
-RT_HD void half4_make(const Bvh4Node* nodes4, int32_t i, Bvh4HNode& out) {
-    const Bvh4Node& nd = nodes4[i];
-    float org[3] = {INFINITY, INFINITY, INFINITY};
-    for (int c = 0; c < 4; ++c) {
-        if (nd.child[c] == CHILD_EMPTY) continue;
-        for (int a = 0; a < 3; ++a) org[a] = fminf(org[a], nd.lo[a][c]);
-    }
-    out.pad0 = 0;
-    for (int k = 0; k < 12; ++k) out.pad[k] = 0;
-    for (int a = 0; a < 3; ++a) {
-        if (!(org[a] < INFINITY)) org[a] = 0.f; // no children
-        out.org[a] = org[a];
-        for (int c = 0; c < 4; ++c) {
-            if (nd.child[c] == CHILD_EMPTY) { out.h[a][0][c] = 0x7C00u; out.h[a][1][c] = 0; continue; }
-            // the offsets in double (exact for two floats), then to float outward, then to half outward
-            const double dl = double(nd.lo[a][c]) - double(org[a]), dh = double(nd.hi[a][c]) - double(org[a]);
-            float fl = float(dl), fh = float(dh);
-            if (double(fl) > dl) fl = nextafterf(fl, -INFINITY);
-            if (double(fh) < dh) fh = nextafterf(fh, INFINITY);
-            out.h[a][0][c] = half_down(fl);
-            out.h[a][1][c] = half_up(fh);
-        }
-    }
-    for (int c = 0; c < 4; ++c) out.child[c] = nd.child[c];
-}
-
 } // namespace rt

@@ -62,8 +62,7 @@ template <typename T> struct DevBuf {
 template <typename R> struct DeviceScene {
     bool ready = false;
     DevBuf<Bvh4Node> nodes;
-    DevBuf<Bvh4QNode> nodes4q;   // the same records with quantised boxes (made on first use by the f64 decoupled kernel, ensure_quant4)   // the traversal-stack bound of those trees (FlatScene::stack_depth is the 4-wide trees')
-    DevBuf<Bvh4HNode> nodes4h;   // ... as half-precision node-local records (ensure_half4)
+    DevBuf<Bvh4QNode> nodes4q;   // the same records with quantised boxes (made on first use by the decoupled kernels, ensure_quant4)
     DevBuf<SphereRec<R>> spheres;
     DevBuf<int32_t> sphere_mat, sphere_seq;
     DevBuf<MovingSphereRec<R>> moving;
@@ -110,7 +109,7 @@ template <typename R> struct DeviceScene {
         return 0;
     }
 
-    // The f64 decoupled kernel's node records, made on this device from the f32 ones the first time that kernel is chosen.
+    // The decoupled kernels' node records, made on this device from the f32 ones the first time such a kernel is chosen.
     int ensure_quant4(const FlatScene& f) {
         if (nodes4q.p) return 0;
         const uint32_t n = f.total_nodes4();
@@ -122,16 +121,6 @@ template <typename R> struct DeviceScene {
         return 0;
     }
 
-    int ensure_half4(const FlatScene& f) {
-        if (nodes4h.p) return 0;
-        const uint32_t n = f.total_nodes4();
-        HIP_TRY(hipMalloc((void**)&nodes4h.p, std::max<size_t>(n, 1) * sizeof(Bvh4HNode)));
-        nodes4h.n = n;
-        std::string err;
-        if (int rc = half4_build_device(nodes.p, n, nodes4h.p, err)) { set_last_error(err); nodes4h.release(); return rc; }
-        view.nodes4h = nodes4h.p;
-        return 0;
-    }
 
     int upload(const FlatScene& f) {
         std::vector<SphereRec<R>> sp;
@@ -178,7 +167,7 @@ template <typename R> struct DeviceScene {
             (rc = texs.upload(tx)) || (rc = images.upload(f.images)) || (rc = texels.upload(f.texels)) ||
             (rc = perlin_vec.upload(pv)) || (rc = perlin_perm.upload(f.perlin_perm)))
             return rc;
-        view.nodes = nodes.p; view.nodes4q = nullptr; view.nodes4h = nullptr; view.spheres = spheres.p; view.sphere_mat = sphere_mat.p; view.sphere_seq = sphere_seq.p;
+        view.nodes = nodes.p; view.nodes4q = nullptr; view.spheres = spheres.p; view.sphere_mat = sphere_mat.p; view.sphere_seq = sphere_seq.p;
         view.moving = moving.p; view.rects = rects.p; view.boxes = boxes.p; view.insts = insts.p; view.media = media.p; view.medium_refs = medium_refs.p;
         view.mats = mats.p; view.texs = texs.p; view.images = images.p; view.texels = texels.p;
         view.perlin_vec = perlin_vec.p; view.perlin_perm = perlin_perm.p;
@@ -190,7 +179,7 @@ template <typename R> struct DeviceScene {
         return 0;
     }
     void release() {
-        nodes.release(); nodes4q.release(); nodes4h.release(); spheres.release(); sphere_mat.release(); sphere_seq.release(); moving.release(); rects.release();
+        nodes.release(); nodes4q.release(); spheres.release(); sphere_mat.release(); sphere_seq.release(); moving.release(); rects.release();
         boxes.release(); insts.release(); media.release(); medium_refs.release(); mats.release(); texs.release(); images.release();
         texels.release(); perlin_vec.release(); perlin_perm.release();
         ready = false;

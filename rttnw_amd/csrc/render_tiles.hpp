@@ -182,10 +182,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             }
         } else {
             const bool gen = flat.needs_general;
-            if constexpr (wave_walks_half<R>()) {
-                if (int h4 = ds.ensure_half4(flat)) return h4;  // this kernel walks the half-precision node-local records: made here, on the device, once
-            } else if constexpr (wave_walks_quantised<R>()) {
-                if (int q4 = ds.ensure_quant4(flat)) return q4; // ... or the quantised ones
+            if constexpr (wave_walks_quantised<R>()) {
+                if (int q4 = ds.ensure_quant4(flat)) return q4; // this kernel walks the quantised records: made here, on the device, once
             }
             // (a scene without any instance record takes the instantiation whose walk never changes frames, rt_core.hpp SHAPES_NONE)
             no_inst = !gen && !count && !flat.walk_changes_frames;

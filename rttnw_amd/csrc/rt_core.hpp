@@ -34,12 +34,12 @@
 
 namespace rt {
 #ifndef RT_NODE_EMPTY_CHECK
-#define RT_NODE_EMPTY_CHECK 0 // 1: the node steps over f32 and half-precision records test child != CHILD_EMPTY beside the (inverted) box of an unused slot.  Without:
+#define RT_NODE_EMPTY_CHECK 0 // 1: the node steps over f32 and quantised records test child != CHILD_EMPTY beside the (inverted) box of an unused slot.  Without:
                               // final_scene f64 1394 -> 1434 Msamples/s, f32 1857 -> 1889, cornell_box f64 1728 -> 1751 (four compares and the scalar ANDs between the
-                              // hit tests and the selects); the kernels that read f32 records from memory +-0.3 %, spheres_1m f32 +1 %
+                              // hit tests and the selects); the kernels that read f32 records from memory +-0.3 %
 #endif
 #ifndef RT_PIN_CHILD_PIECE
-#define RT_PIN_CHILD_PIECE 1 // the steps over records in memory (quantised, half-precision) keep the read of the children's piece beside the other pieces' reads
+#define RT_PIN_CHILD_PIECE 1 // the step over quantised records (read from memory) keeps the read of the children's piece beside the other pieces' reads
 #endif
 #ifndef RT_F64_SLAB_FOLDED
 #define RT_F64_SLAB_FOLDED 2 // the f64 kernels' box test: 0 every box's entry / exit widened by 3.6e-7 |t| + slack (15 operations per box), 1 the widening in per-walk
@@ -359,9 +359,7 @@ RT_HD Ray<R> camera_ray(const CameraRec<R>& cam, R s, R t, uint64_t key, bool ti
 // kernels that read nodes from global memory (big trees) keep the exact two-operation form (plane - o) * inv: the fma form's
 // error is ABSOLUTE, ~eps |o inv|, which for a far-away origin and a small direction component — spheres_1m's primary rays —
 // is larger than a leaf, so its widening opens boxes the exact form culls (spheres_1m f32 396 -> 346 with the folded form).
-// SLAB_HALF: the stack walks half-precision node-local records (trav_node_step4h): the walk keeps the cleaned reciprocal (NaN for an axis the
-// ray is parallel to) and its lower / upper bounds inv -+ 5e-7 |inv| (SlabRay::oinv_n, inv_n, inv_f) instead of making them at every visit.
-enum : int { SLAB_EXACT = 0, SLAB_FMA_FOLDED = 2, SLAB_HALF = 4 };
+enum : int { SLAB_EXACT = 0, SLAB_FMA_FOLDED = 2 };
 template <typename R> struct SlabRay { // what a ray contributes to every slab test of its walk
     V3<R> inv; // 1 / d                                                               (SLAB_EXACT)
     // near planes: t = plane * inv_n - oinv_n comes out ALREADY moved down by the error bound, far planes up   (SLAB_FMA_FOLDED)
@@ -427,17 +425,6 @@ template <int FORM, typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
         }
     } else {
         sr.inv = V3<R>(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
-        if constexpr (FORM == SLAB_HALF) {
-            const float ii[3] = {sr.inv.x, sr.inv.y, sr.inv.z};
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                float inv = ii[a];
-                if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
-                sr.oinv_n[a] = inv;
-                sr.inv_n[a] = __builtin_fmaf(-rt_fabs(inv), 5e-7f, inv);
-                sr.inv_f[a] = __builtin_fmaf(rt_fabs(inv), 5e-7f, inv);
-            }
-        }
         if constexpr (FORM == SLAB_FMA_FOLDED) {
             // t32 = fl(b inv - oi), oi = fl(o inv), inv = rcp(d) (1 ulp): |t32 - t| <= 1.8e-7 |t| + 6e-8 |o inv|; the widening by
             // 4.2e-7 |t| + 3.0e-7 |o_a inv_a| is folded into the constants: scaling by (1 -+ 4.2e-7) widens a positive distance —
@@ -1042,87 +1029,9 @@ RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
     trav_descend_sorted4<Cnt::NO_INST>(tr, wray, stack, k, ch);
 }
 
-// ---- the same step over a HALF-PRECISION NODE-LOCAL record (rt_types.hpp Bvh4HNode: five 16-byte pieces).  The box planes are halves
-// b' >= 0, offsets from the record's org; a plane distance is t = b' inv + A with A = (org - o) inv per visit: ONE v_fma_mix_f32 per
-// plane (the half is an operand of the instruction: no conversion).  Conservative: with inv the walk's 1-ulp reciprocal of the (f64
-// kernels: rounded) direction (|e| <= 1.8e-7), D = org - o rounded once (the f64 kernels subtract in double first) and A's product and the
-// fma rounded once each, |t32 - t| <= 2.4e-7 |b' inv| + 3.6e-7 |A|; near planes take inv - 5e-7 |inv| and A - 5e-7 |A|, far planes the
-// opposite (b' >= 0), so a box the exact test passes always passes.  An axis the ray is parallel to gets NaNs, which maxNum / minNum drop.
-template <int HI> RT_HD float fma_half(uint32_t packed, float b, float c) { // half(low / high 16 bits of `packed`) * b + c, one rounding
-#if defined(__HIP_DEVICE_COMPILE__)
-    float r;
-    if constexpr (HI != 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b), "v"(c));
-    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(b), "v"(c));
-    return r;
-#else
-    return __builtin_fmaf(half_bits_to_float(uint16_t(HI != 0 ? packed >> 16 : packed & 0xFFFFu)), b, c);
-#endif
-}
-template <typename R, typename Stack, typename Cnt>
-RT_HD void trav_node_step4h(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
-    uint32_t w[20]; // pieces 0-4 of the record
-    stack.fetch4h(sc, tr.node, w);
-#if RT_PIN_CHILD_PIECE && defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(w[16]), "+v"(w[17]), "+v"(w[18]), "+v"(w[19])); // (as in trav_node_step4q)
-#endif
-    cnt.node();
-    float lo_t, hi_t;
-    slab_range(t_min, tr.closest, lo_t, hi_t);
-    const Ray<R>& cray = Cnt::NO_INST ? wray : tr.ray; // the ray in the current frame
-    const R oo[3] = {cray.o.x, cray.o.y, cray.o.z};
-    float a_lo[3], a_hi[3], inv_lo[3], inv_hi[3];
-    uint32_t near_w[3][2], far_w[3][2]; // the four children's near / far planes of axis a, two halves to a word
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float inv;
-        if constexpr (slab_form<Stack, R>() == SLAB_HALF) { // f32: kept by the walk (slab_ray)
-            inv = tr.sr.oinv_n[a]; inv_lo[a] = tr.sr.inv_n[a]; inv_hi[a] = tr.sr.inv_f[a];
-        } else {
-            inv = slab_inv_of(tr.sr, a);
-            if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
-            inv_lo[a] = __builtin_fmaf(-rt_fabs(inv), 5e-7f, inv);
-            inv_hi[a] = __builtin_fmaf(rt_fabs(inv), 5e-7f, inv);
-        }
-        const bool neg = inv < 0.f;
-        const float D = float(R(bits_float(w[a])) - oo[a]);
-        const float A = D * inv;
-        a_lo[a] = __builtin_fmaf(-rt_fabs(A), 5e-7f, A);
-        a_hi[a] = __builtin_fmaf(rt_fabs(A), 5e-7f, A);
-        const uint32_t l0 = w[4 + 4 * a], l1 = w[5 + 4 * a], h0 = w[6 + 4 * a], h1 = w[7 + 4 * a];
-        near_w[a][0] = neg ? h0 : l0; near_w[a][1] = neg ? h1 : l1;
-        far_w[a][0] = neg ? l0 : h0; far_w[a][1] = neg ? l1 : h1;
-    }
-    uint32_t k[4];
-    int32_t ch[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        ch[c] = int32_t(w[16 + c]);
-        const int hw = c >> 1;
-        float nx, ny, nz, fx, fy, fz;
-        if ((c & 1) == 0) {
-            nx = fma_half<0>(near_w[0][hw], inv_lo[0], a_lo[0]); fx = fma_half<0>(far_w[0][hw], inv_hi[0], a_hi[0]);
-            ny = fma_half<0>(near_w[1][hw], inv_lo[1], a_lo[1]); fy = fma_half<0>(far_w[1][hw], inv_hi[1], a_hi[1]);
-            nz = fma_half<0>(near_w[2][hw], inv_lo[2], a_lo[2]); fz = fma_half<0>(far_w[2][hw], inv_hi[2], a_hi[2]);
-        } else {
-            nx = fma_half<1>(near_w[0][hw], inv_lo[0], a_lo[0]); fx = fma_half<1>(far_w[0][hw], inv_hi[0], a_hi[0]);
-            ny = fma_half<1>(near_w[1][hw], inv_lo[1], a_lo[1]); fy = fma_half<1>(far_w[1][hw], inv_hi[1], a_hi[1]);
-            nz = fma_half<1>(near_w[2][hw], inv_lo[2], a_lo[2]); fz = fma_half<1>(far_w[2][hw], inv_hi[2], a_hi[2]);
-        }
-        const float lo = rt_max(rt_max(nz, rt_max(ny, nx)), lo_t), hi = rt_min(rt_min(fz, rt_min(fy, fx)), hi_t); // maxNum / minNum: a NaN drops out
-        // (an unused slot: lower planes +inf, upper planes 0 — entry +inf or exit -inf whatever the signs)
-#if RT_NODE_EMPTY_CHECK
-        k[c] = (!(hi < lo) && ch[c] != CHILD_EMPTY) ? float_bits(lo) : MISS_KEY;
-#else
-        k[c] = !(hi < lo) ? float_bits(lo) : MISS_KEY;
-#endif
-    }
-    trav_descend_sorted4<Cnt::NO_INST>(tr, wray, stack, k, ch);
-}
-
 template <typename R, typename Stack, typename Cnt>
 RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
-    if constexpr (Stack::WIDE == NODES_H16X4) trav_node_step4h(tr, sc, wray, t_min, stack, cnt); // half-precision node-local records
-    else if constexpr (Stack::WIDE == NODES_Q8X4) trav_node_step4q(tr, sc, wray, t_min, stack, cnt); // quantised records (the f64 decoupled kernel)
+    if constexpr (Stack::WIDE == NODES_Q8X4) trav_node_step4q(tr, sc, wray, t_min, stack, cnt); // quantised records (the decoupled kernels)
     else trav_node_step4(tr, sc, wray, t_min, stack, cnt);
 }
 

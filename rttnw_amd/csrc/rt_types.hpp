@@ -68,16 +68,17 @@ struct alignas(16) Bvh4Node {
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 constexpr uint32_t BVH4_USED_SIXTEENTHS = 7; // 16-byte pieces of a record that carry data (the LDS copy leaves the pad out)
 
-// What the f64 DECOUPLED kernel walks (trees that live in HBM / the Infinity Cache): the same 4-wide record with QUANTISED boxes, 64
+// What the DECOUPLED kernels walk (trees that live in HBM / the Infinity Cache): the same 4-wide record with QUANTISED boxes, 64
 // bytes — two records to a 128-byte line, FOUR 16-byte pieces a visit instead of seven, the tree itself unchanged (record i = 4-wide
 // record i: same children in the same slots, same stack bound).  Made from the f32 records on the device (bvh_quant.hpp).
 //   piece 0  org[3]: the lower corner of the box around the children; ex[3]: the quantisation step of axis a is 2^(ex[a] - 127)
 //   piece 1  q_lo[4], q_hi[4] of x, then of y: child c's box is [org + q_lo[c] step, org + q_hi[c] step], q_lo rounded DOWN and q_hi UP
 //            (the boxes only cull: a dequantised box contains the f32 box it was made from); an unused slot has q_lo 255, q_hi 0
 //   piece 2  q_lo[4], q_hi[4] of z;   piece 3  child[4], coded like Bvh4Node::child
-// Measured (profiles/r04/README.md): spheres_1m f64 277 -> 289 Msamples/s, RTTNW_F64_STRICT 269 -> 288, half the node bytes; the f32
-// kernel LOSES 2 % to this record's per-visit set-up and conversions (it walks the half-precision records below instead: +4 %); an
-// 8-wide quantised record (96 bytes, six pieces, 21 % fewer visits, twice the instructions per visit) lost 40 %.
+// Measured (profiles/r04/README.md): spheres_1m f64 277 -> 289 Msamples/s, RTTNW_F64_STRICT 269 -> 288, half the node bytes.  The f32
+// kernel first LOST 2 % to this record's per-visit set-up and conversions and walked half-precision node-local records (80 of 128 bytes, one
+// v_fma_mix_f32 per plane: +4 %) — until the round's other changes left it bound by bytes alone: 433 -> 476 on these records, and the
+// half-precision ones were removed.  An 8-wide quantised record (96 bytes, six pieces, 21 % fewer visits, twice the instructions per visit) lost 40 %.
 struct alignas(16) Bvh4QNode {
     float org[3];
     uint8_t ex[3];
@@ -87,40 +88,7 @@ struct alignas(16) Bvh4QNode {
     int32_t child[4];
 };
 static_assert(sizeof(Bvh4QNode) == 64, "Bvh4QNode must be 64 bytes");
-enum : int { NODES_F32X4 = 4, NODES_Q8X4 = 44, NODES_H16X4 = 45 }; // what a traversal stack type walks (Stack::WIDE)
-
-// A third encoding of the same 4-wide record, for walks bound by the L1's rate of divergent accesses (measured: the f32 decoupled
-// kernel issues 1.1 lane-accesses per clock and CU — seven 16-byte pieces a visit x the lanes in the step; an EIGHTH piece costs 13-14 %):
-// the boxes as IEEE HALF-precision offsets from `org`, the lower corner of the box around the children (lo rounded down, hi up: a
-// local box contains the f32 box it was made from; 11 significant bits of the OFFSET, i.e. 2^-11 of the node's size at worst).
-// Five pieces a visit, and a plane distance is ONE v_fma_mix_f32 (the half is an operand: no conversion):
-//   t = b' inv + A,   A = (org - o) inv per visit and axis        (both of the size of the distances involved: the error is relative)
-//   piece 0  org[3];  piece 1 + a  axis a: lo'[4], hi'[4] (halves);  piece 4  child[4], coded like Bvh4Node::child
-// An unused slot has lo' = +inf.  Record stride stays 128 bytes (index for index with the f32 records; one line a visit).
-// Measured: the f32 decoupled kernel 402 -> 417 Msamples/s on spheres_1m (+0.2 % visits); the f64 ones prefer the 8-bit records (284
-// against 266; strict 291 / 293); the f32 lane-owns-path kernel of mid-size scenes, bound by instruction issue, loses 12 %: not used there.
-struct alignas(16) Bvh4HNode {
-    float org[3];
-    int32_t pad0;
-    uint16_t h[3][2][4]; // [axis][0 lo' / 1 hi'][slot], IEEE binary16 bits
-    int32_t child[4];
-    int32_t pad[12];
-};
-static_assert(sizeof(Bvh4HNode) == 128, "Bvh4HNode must be 128 bytes");
-// the value of a binary16 bit pattern (host code and the record conversion; the kernels feed the halves to v_fma_mix_f32)
-RT_HD float half_bits_to_float(uint16_t h) {
-    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
-    uint32_t bits;
-    if (e == 0) { // zero / denormal: m 2^-24
-        const float f = float(m) * 5.9604644775390625e-8f;
-        return f;
-    }
-    if (e == 31) bits = 0x7F800000u | (m << 13);
-    else bits = ((e + 112u) << 23) | (m << 13);
-    float f;
-    __builtin_memcpy(&f, &bits, 4);
-    return f;
-}
+enum : int { NODES_F32X4 = 4, NODES_Q8X4 = 44 }; // what a traversal stack type walks (Stack::WIDE)
 
 // Traversal stack: the first LDS_STACK_ENTRIES entries of a lane live in LDS, deeper ones (a 4-wide walk can have three
 // pending children per level, but rarely has) in a per-lane strip of global memory.
@@ -219,7 +187,6 @@ template <typename R> struct CameraRec { // Camera — camera.rs:18-29
 template <typename R> struct SceneView {
     const Bvh4Node* nodes;
     const Bvh4QNode* nodes4q; // the same trees as quantised records, index for index (the f64 decoupled kernel; else null)
-    const Bvh4HNode* nodes4h; // ... as half-precision node-local records
     const SphereRec<R>* spheres;
     const int32_t* sphere_mat;
     const int32_t* sphere_seq; // list-order sequence numbers, read only to break exact ties in t

@@ -21,13 +21,14 @@
 #include "trace_tally.hpp"
 
 #ifndef RT_WAVE_QUANT
-#define RT_WAVE_QUANT 1 // which decoupled kernels walk the quantised records (rt_types.hpp Bvh4QNode): 1 the f64 ones (measured: +4 / +7 %; f32 -2 %), 2 all, 0 none
+#define RT_WAVE_QUANT 2 // which decoupled kernels walk the quantised records (rt_types.hpp Bvh4QNode): 1 the f64 ones, 2 all, 0 none.  (Mid-round-4: f64 +4 / +7 %,
+                        // f32 -2 % against the f32 records — and +4 % for half-precision node-local records, 80 of 128 bytes a visit, which the f32 kernel walked
+                        // for a while.  At the round's end — no slot tests, no instance code, 13-real path slots — the f32 kernel moves 6.2 TB/s and little else,
+                        // and half the node bytes are worth +10 %: spheres_1m f32 433 -> 476 Msamples/s on these records; the half-precision ones are gone.)
 #endif
 #ifndef RT_WAVE_STEPS
-#define RT_WAVE_STEPS 6 // node steps per trip of the decoupled kernel's bursts (2 / 3 / 4 / 6: 302 / 321 / 325 / 330 Msamples/s in round 1)
-#endif
-#ifndef RT_WAVE_HALF
-#define RT_WAVE_HALF 1 // which decoupled kernels walk the half-precision node-local records (rt_types.hpp Bvh4HNode): 1 the f32 one, 2 all, 0 none
+#define RT_WAVE_STEPS 5 // node steps per trip of the decoupled kernel's bursts (2 / 3 / 4 / 6: 302 / 321 / 325 / 330 Msamples/s in round 1; round 4's end, spheres_1m
+                        // f64 / strict / f32 with 4 / 5 / 6: 334 / 340 / 332, 331 / 332 / 331, 481 / 481 / 476; 8: f32 442)
 #endif
 #ifndef RT_F64_BLOCK
 #define RT_F64_BLOCK 1024 // threads per block of the LDS-resident f64 kernel (4 waves/SIMD at 128 VGPRs; see the Makefile's f64 flags and profiles/r03/README.md)
@@ -86,18 +87,6 @@ template <uint32_t STRIDE, uint32_t ENTRIES> struct LdsStackQuant4 : LdsStack<ST
 #pragma unroll
         for (int k = 0; k < 4; ++k) q[k] = rec[k];
         __builtin_memcpy(w, q, 64);
-    }
-};
-// ... or the half-precision node-local records (rt_types.hpp Bvh4HNode): five reads per visit.
-template <uint32_t STRIDE, uint32_t ENTRIES> struct LdsStackHalf4 : LdsStack<STRIDE, ENTRIES> {
-    static constexpr int WIDE = NODES_H16X4;
-    static constexpr int SLAB_F32 = SLAB_HALF; // the walk keeps the reciprocal's bounds (rt_core.hpp)
-    template <typename R> __device__ __forceinline__ void fetch4h(const SceneView<R>& sc, int32_t i, uint32_t* w) const {
-        const int4* rec = reinterpret_cast<const int4*>(sc.nodes4h + i);
-        int4 q[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) q[k] = rec[k];
-        __builtin_memcpy(w, q, 80);
     }
 };
 // Same, with the whole node array resident in LDS in PIECE-MAJOR order: the q-th 16 bytes of node i at
@@ -170,8 +159,7 @@ template <typename R> __host__ __device__ constexpr uint32_t wave_stack_entries(
 template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
     return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (wave_stack_entries<R>() + 1u) * 64u * 4u; // stack: + the spare slot
 }
-template <typename R> __host__ __device__ constexpr bool wave_walks_half() { return RT_WAVE_HALF == 2 || (RT_WAVE_HALF == 1 && sizeof(R) == 4); }
-template <typename R> __host__ __device__ constexpr bool wave_walks_quantised() { return !wave_walks_half<R>() && (RT_WAVE_QUANT == 2 || (RT_WAVE_QUANT == 1 && sizeof(R) == 8)); }
+template <typename R> __host__ __device__ constexpr bool wave_walks_quantised() { return RT_WAVE_QUANT == 2 || (RT_WAVE_QUANT == 1 && sizeof(R) == 8); }
 constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
 
 // The per-pixel sample loop of main.rs:202-229 as ONE persistent kernel in which PATHS ARE DECOUPLED FROM LANES.
@@ -224,8 +212,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
     int32_t* const hq_prim = reinterpret_cast<int32_t*>(rq_slot + QCAP);
     int32_t* const hq_inst = hq_prim + QCAP;
     uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
-    typename std::conditional<wave_walks_half<R>(), LdsStackHalf4<64, wave_stack_entries<R>()>,
-                              typename std::conditional<wave_walks_quantised<R>(), LdsStackQuant4<64, wave_stack_entries<R>()>, LdsStack<64, wave_stack_entries<R>()>>::type>::type stack;
+    typename std::conditional<wave_walks_quantised<R>(), LdsStackQuant4<64, wave_stack_entries<R>()>, LdsStack<64, wave_stack_entries<R>()>>::type stack;
     stack.base = (LdsIntPtr)(reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane);
     stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x));
     stack.spill_stride = gridDim.x * TRACE_BLOCK;

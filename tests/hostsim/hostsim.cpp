@@ -74,12 +74,6 @@ struct HostStack4Q : HostStack { // the f64 decoupled kernel's: walks the quanti
     template <typename R> void fetch4q(const SceneView<R>& sc, int32_t i, uint32_t* w) const { std::memcpy(w, &sc.nodes4q[i], 64); }
 };
 
-struct HostStack4H : HostStack { // ... or the half-precision node-local records (bvh_quant.hpp half4_make; rt_core.hpp trav_node_step4h)
-    static constexpr int WIDE = NODES_H16X4;
-    static constexpr int SLAB_F32 = SLAB_HALF;
-    template <typename R> void fetch4h(const SceneView<R>& sc, int32_t i, uint32_t* w) const { std::memcpy(w, &sc.nodes4h[i], 80); }
-};
-
 template <typename R> struct HostScene {
     std::vector<SphereRec<R>> spheres;
     std::vector<MovingSphereRec<R>> moving;
@@ -92,12 +86,6 @@ template <typename R> struct HostScene {
     std::vector<R> perlin_vec;
     SceneView<R> view;
     std::vector<Bvh4QNode> nodes4q; // HOSTSIM_QUANT=1: the f64 decoupled kernel's records, made by the same per-record function as on the device
-    std::vector<Bvh4HNode> nodes4h; // HOSTSIM_QUANT=2: the half-precision node-local records
-    void make_half4(const FlatScene& f) {
-        nodes4h.resize(f.nodes4.size());
-        for (size_t i = 0; i < f.nodes4.size(); ++i) half4_make(f.nodes4.data(), int32_t(i), nodes4h[i]);
-        view.nodes4h = nodes4h.data();
-    }
     void make_quant4(const FlatScene& f) {
         nodes4q.resize(f.nodes4.size());
         for (size_t i = 0; i < f.nodes4.size(); ++i) quant4_make(f.nodes4.data(), int32_t(i), nodes4q[i]);
@@ -133,7 +121,6 @@ template <typename R> struct HostScene {
         for (double v : f.perlin_vec) perlin_vec.push_back(R(v));
         view.nodes = f.nodes4.data();
         view.nodes4q = nullptr;
-        view.nodes4h = nullptr;
         view.spheres = spheres.data(); view.sphere_mat = f.sphere_mat.data(); view.sphere_seq = f.sphere_seq.data();
         view.moving = moving.data(); view.rects = rects.data(); view.boxes = boxes.data();
         view.insts = insts.data(); view.media = media.data(); view.medium_refs = f.medium_refs.data(); view.mats = mats.data(); view.texs = texs.data();
@@ -158,7 +145,6 @@ int render_t(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p
              int n_threads) {
     HostScene<R> hs(s->flat);
     if (StackT::WIDE == NODES_Q8X4) hs.make_quant4(s->flat);
-    if (StackT::WIDE == NODES_H16X4) hs.make_half4(s->flat);
     CameraRec<double> cam64;
     make_camera(cam->lookfrom, cam->lookat, cam->view_up, cam->vertical_fov, cam->aspect_ratio, cam->aperture,
                 cam->focus_distance, cam->open_time, cam->close_time, cam64);
@@ -421,9 +407,6 @@ int hostsim_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_par
     if (q && q[0] == '3')
         return p->precision == RTTNW_F32 ? render_t<float, HostStackAll>(s, cam, p, out_linear, stats, n_threads)
                                          : render_t<double, HostStackAll>(s, cam, p, out_linear, stats, n_threads);
-    if (q && q[0] == '2')
-        return p->precision == RTTNW_F32 ? render_t<float, HostStack4H>(s, cam, p, out_linear, stats, n_threads)
-                                         : render_t<double, HostStack4H>(s, cam, p, out_linear, stats, n_threads);
     return p->precision == RTTNW_F32 ? render_t<float, HostStack>(s, cam, p, out_linear, stats, n_threads)
                                      : render_t<double, HostStack>(s, cam, p, out_linear, stats, n_threads);
 }

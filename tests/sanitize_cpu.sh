@@ -30,7 +30,7 @@ for name, n in cases:
         cam, p = util.params_for(setup, 24, 24, 3, precision=prec, seed=3, collect_counters=1)
         os.environ.pop("HOSTSIM_QUANT", None)
         img, st = util.hostsim_render(b, sc, cam, p)
-        for mode in ("1", "2") + (("3",) if n == 0 else ()):   # ... and through the re-encoded records of the decoupled kernels (bvh_quant.hpp: quantised, half-precision); small scenes: the walk that never culls
+        for mode in ("1",) + (("3",) if n == 0 else ()):   # ... and through the quantised records of the decoupled kernels (bvh_quant.hpp); small scenes: the walk that never culls
             os.environ["HOSTSIM_QUANT"] = mode
             img_q, st_q = util.hostsim_render(b, sc, cam, p)
             assert np.array_equal(img, img_q) or (mode == "3" and prec == abi.F32)

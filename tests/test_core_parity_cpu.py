@@ -282,17 +282,15 @@ def test_ball_draw_shortcut_is_the_full_rejection_loop(hostsim):
 @pytest.mark.parametrize("name,param,w,h,spp", [("cornell_box", 0, 48, 48, 6), ("final_scene", 0, 48, 48, 6), ("spheres_1m", 30000, 64, 64, 6),
                                                 ("random_scene", 0, 64, 36, 6), ("smoke_cornell_box", 0, 40, 40, 4)])
 def test_quantised_records_never_change_an_image(hostsim, scenes_lib, earth, name, param, w, h, spp, monkeypatch):
-    """The decoupled kernels walk the trees through re-encoded records made by bvh_quant.hpp from the f32 ones: the f64 kernels through
-    8-bit quantised records (rt_types.hpp Bvh4QNode; rt_core.hpp trav_node_step4q; HOSTSIM_QUANT=1 in the host build of the same code),
-    the f32 kernel through half-precision node-local records (Bvh4HNode; trav_node_step4h; HOSTSIM_QUANT=2).  Conservative boxes only
-    ever OPEN more nodes, so the image is bit-identical in both precisions and the same world.hit() calls are made; the visits grow by a
-    few per cent (8-bit) or a few per mille (half)."""
+    """The decoupled kernels walk the trees through 8-bit quantised records made by bvh_quant.hpp from the f32 ones (rt_types.hpp Bvh4QNode; rt_core.hpp
+    trav_node_step4q; HOSTSIM_QUANT=1 in the host build of the same code).  Conservative boxes only ever OPEN more nodes, so the image is bit-identical in
+    both precisions and the same world.hit() calls are made; the visits grow by a few per cent."""
     sc, setup = util.build(hostsim, scenes_lib, name, earth, param)
     for prec in (abi.F64, abi.F32):
         cam, p = util.params_for(setup, w, h, spp, precision=prec, collect_counters=1, seed=9)
         monkeypatch.delenv("HOSTSIM_QUANT", raising=False)
         a, sta = util.hostsim_render(hostsim, sc, cam, p)
-        for mode, growth in (("1", 1.25), ("2", 1.05)):
+        for mode, growth in (("1", 1.25),):
             monkeypatch.setenv("HOSTSIM_QUANT", mode)
             b, stb = util.hostsim_render(hostsim, sc, cam, p)
             assert np.array_equal(a, b) and sta.rays == stb.rays, mode
@@ -403,7 +401,7 @@ def test_quantised_records_on_hostile_geometry(hostsim, monkeypatch):
                 p = S.make_params(33, 33, 3, background=(0.2, 0.3, 0.5), precision=prec, seed=4, collect_counters=1, t_min=1e-3 * scale)
                 monkeypatch.delenv("HOSTSIM_QUANT", raising=False)
                 a, sta = util.hostsim_render(hostsim, sc, cam, p)
-                for mode in ("1", "2"):   # 8-bit quantised records, half-precision node-local records
+                for mode in ("1",):   # 8-bit quantised records
                     monkeypatch.setenv("HOSTSIM_QUANT", mode)
                     b, stb = util.hostsim_render(hostsim, sc, cam, p)
                     assert np.array_equal(a, b) and sta.rays == stb.rays and np.isfinite(a).all(), (scale, prec, mode)

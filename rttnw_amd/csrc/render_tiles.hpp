@@ -152,10 +152,11 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             // ... and a scene whose walk never changes frames the instantiation without instance code (rt_core.hpp SHAPES_NONE: final_scene — its one
             // instance record is the bare chain of the cluster's world-space copies)
             const bool lds_no_inst = want_lds && !gen && !count && !flat.walk_changes_frames;
-            three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2 && !lds_no_inst;
+            three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2;
             const bool tiny_tree = three_steps && !count; // (the counting variant's tallied loop is written for two: same steps per lane, same counters)
             const void* kernel =
-                lds_no_inst ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE> :
+                lds_no_inst && !flat.has_instance_leaves ? (tiny_tree ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE>) :
+                lds_no_inst ? (tiny_tree ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_SINGLE, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_SINGLE>) :
                 tiny_tree ? (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_GENERAL, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_FAST, RT_TINY_TREE_STEPS>) :
                 want_lds ? (count ? (gen ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, false>)
                                   : (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, false>))
@@ -186,7 +187,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                 if (int q4 = ds.ensure_quant4(flat)) return q4; // this kernel walks the quantised records: made here, on the device, once
             }
             // (a scene without any instance record takes the instantiation whose walk never changes frames, rt_core.hpp SHAPES_NONE)
-            no_inst = !gen && !count && !flat.walk_changes_frames;
+            no_inst = !gen && !count && !flat.has_instance_leaves;
             auto kernel = count ? (gen ? trace_kernel<R, true, SHAPES_GENERAL> : trace_kernel<R, true, SHAPES_FAST>)
                                 : (gen ? trace_kernel<R, false, SHAPES_GENERAL> : (no_inst ? trace_kernel<R, false, SHAPES_NONE> : trace_kernel<R, false, SHAPES_FAST>));
             const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
@@ -250,7 +251,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         stats->scene_bytes = uint32_t(std::min<size_t>(ds.bytes, 0xFFFFFFFFu));
         // which kernel form ran: bit 0 = decoupled (else lane-owns-path), bit 1 = node records resident in LDS (the form bench.py's
         // roofline calls issue-bound)
-        stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u) | (plain && three_steps ? 4u : 0u) | (!flat.needs_general && !flat.walk_changes_frames && (!plain || rc.lds_nodes != 0u) ? 8u : 0u);
+        stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u) | (plain && three_steps ? 4u : 0u) | (!flat.needs_general && (plain ? !flat.walk_changes_frames && rc.lds_nodes != 0u : !flat.has_instance_leaves) ? 8u : 0u) |
+                          (!flat.needs_general && plain && !flat.walk_changes_frames && rc.lds_nodes != 0u && flat.has_instance_leaves ? 16u : 0u);
     }
     return RTTNW_OK;
 }

@@ -299,14 +299,17 @@ template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bo
 // Counter policies.  Their template flag GENERAL also selects, at compile time, whether the code for the rare graph shapes
 // (more than FAST_INSTANCE_OPS wrappers around an object, List / BvhTree medium boundaries, media inside transformed groups;
 // FlatScene::needs_general) is compiled into a kernel at all: it costs the common kernels registers even when it never runs.
-// Since round 4 the flag has a third value: SHAPES_NONE = a scene without ANY instance record (no Translate / YRotate wrapper that survived the
-// lowering: spheres_1m, random_scene): the walk then never changes frames, so its per-lane copy of the ray in the current frame, the sentinel
-// test of every pop and the instance branch of the leaf step are compiled out — 14 registers in the f64 decoupled kernel, which is held to
+// Since round 4 the flag has a third value: SHAPES_NONE = a scene whose WALK NEVER CHANGES FRAMES: no tree holds an instance with a tree of its own
+// (spheres_1m, random_scene: no wrapper at all; final_scene: its cluster's spheres are world-space copies).  The walk's per-lane copy of the ray in the current frame, the sentinel test of
+// every pop and the descent into an instance's tree are compiled out — 14 registers in the f64 decoupled kernel, which is held to
 // 168 for its third wave: scratch 120 -> 52 B per lane, spheres_1m f64 310 -> 325 Msamples/s, RTTNW_F64_STRICT 300 -> 320.
-enum : int { SHAPES_FAST = 0, SHAPES_GENERAL = 1, SHAPES_NONE = 2 };
+// SHAPES_SINGLE is the same where instance leaves do exist but all are single wrapped records (cornell_box: +2.9 % in f64, +4 % in the strict build): it
+// keeps the branch that tests such a record in place, which SHAPES_NONE scenes are better off without (final_scene f32: 1 %).
+enum : int { SHAPES_FAST = 0, SHAPES_GENERAL = 1, SHAPES_NONE = 2, SHAPES_SINGLE = 3 };
 template <int G> struct NoCountersT {
     static constexpr bool GENERAL = G == SHAPES_GENERAL;
-    static constexpr bool NO_INST = G == SHAPES_NONE;
+    static constexpr bool NO_INST = G == SHAPES_NONE || G == SHAPES_SINGLE; // the walk never changes frames
+    static constexpr bool NO_INST_LEAF = G == SHAPES_NONE;                  // ... and meets no instance leaf at all
     RT_HD void ray() {}
     RT_HD void node() {}
     RT_HD void prim() {}
@@ -314,7 +317,8 @@ template <int G> struct NoCountersT {
 };
 template <int G> struct LaneCountersT {
     static constexpr bool GENERAL = G == SHAPES_GENERAL;
-    static constexpr bool NO_INST = G == SHAPES_NONE;
+    static constexpr bool NO_INST = G == SHAPES_NONE || G == SHAPES_SINGLE;
+    static constexpr bool NO_INST_LEAF = G == SHAPES_NONE;
     uint32_t rays = 0, nodes = 0, prims = 0, texels = 0;
     RT_HD void ray() { ++rays; }
     RT_HD void node() { ++nodes; }
@@ -1038,8 +1042,9 @@ RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
 // One step at a leaf (tr.node < 0, not TRAV_DONE): enter an instance, or test ONE primitive record.  WHOLE_LEAF tests
 // all (<= 4) records of the leaf in one step instead — the same tests in the same order; measured 10-14 % SLOWER in
 // the lockstep kernel (lanes with a one-record leaf wait instead of going on with node steps), so nothing uses it.
-// (`ray`: the walk's ray in the current frame — tr.ray, or the world ray itself where the scene has no instances)
-template <typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray) {
+// (`ray`: the ray in the frame of the record — tr.ray, the world ray itself where the walk never changes frames, or a single wrapped record's
+// object-space ray; `inst`: the instance that frame belongs to, or -1)
+template <typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
     R t;
     int aux = 0;
     if (prim_t(sc, kind, idx, ray, t_min, tr.closest, t, aux)) {
@@ -1049,7 +1054,7 @@ template <typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R
         if (!loses_tie) {
             tr.closest = t;
             tr.best.prim = make_ref(kind, idx);
-            tr.best.inst = tr.cur_inst;
+            tr.best.inst = inst;
             tr.best.aux = aux;
             tr.found = true;
         }
@@ -1060,7 +1065,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     constexpr bool NI = Cnt::NO_INST;
     if (tr.node == CHILD_EMPTY) { trav_pop<NI>(tr, wray, stack); return; }
     const uint32_t kind = leaf_kind(tr.node), count = leaf_count(tr.node), first = leaf_first(tr.node);
-    if (!NI && kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
+    if (!Cnt::NO_INST_LEAF && kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
         cnt.prim();
         const InstanceRec<R>& in_rec = sc.insts[first];
         const InstanceHead<R> head = head_of(in_rec); // one by-value copy serves the transform below
@@ -1069,33 +1074,30 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
             if (!Cnt::GENERAL || head.n_ops <= FAST_INSTANCE_OPS) return to_object_fast(head, wray, head.n_ops);
             return to_object<Cnt::GENERAL>(in_rec, wray);
         };
-        if (single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk
-            const Ray<R> outer = tr.ray;
-            const int32_t outer_inst = tr.cur_inst;
-            tr.ray = object_ray();
-            tr.cur_inst = int32_t(first);
+        if (single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk, the walk stays in its frame
+            const Ray<R> obj = object_ray();
             cnt.prim();
-            trav_test_record(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min, tr.ray);
-            tr.ray = outer;
-            tr.cur_inst = outer_inst;
-            trav_pop(tr, wray, stack);
+            trav_test_record(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min, obj, int32_t(first));
+            trav_pop<NI>(tr, wray, stack);
             return;
         }
-        stack.set(tr.sp++, STACK_SENTINEL);
-        trav_set_ray(tr, object_ray(), stack);
-        tr.cur_inst = int32_t(first);
-        tr.node = inst_root;
+        if constexpr (!NI) { // (a scene whose walk never changes frames has no instance with a tree: FlatScene::walk_changes_frames)
+            stack.set(tr.sp++, STACK_SENTINEL);
+            trav_set_ray(tr, object_ray(), stack);
+            tr.cur_inst = int32_t(first);
+            tr.node = inst_root;
+        }
         return;
     }
     if constexpr (WHOLE_LEAF) {
         for (uint32_t k = 0; k < count; ++k) {
             cnt.prim();
-            trav_test_record(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray);
+            trav_test_record(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         }
         trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
-        trav_test_record(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray);
+        trav_test_record(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }
 }

@@ -985,8 +985,10 @@ struct Lowering {
             fprintf(stderr, "[lower] textures + materials %.1f ms, collect %.1f ms, top tree (%zu items) %.1f ms, 4-wide collapse (%zu -> %zu records) %.1f ms\n", ms(t_start, t_mats), ms(t_mats, t_collected),
                     top.size(), ms(t_collected, t_built), size_t(fs.total_nodes2()), size_t(fs.total_nodes4()), ms(t_built, now()));
         for (const auto& in : fs.insts) fs.needs_general = fs.needs_general || in.n_ops > FAST_INSTANCE_OPS;
-        // (a record with neither a tree nor a single wrapped record is a bare chain — the way back for the hit records of world-space copies: no leaf refers to it)
-        for (const auto& in : fs.insts) fs.walk_changes_frames = fs.walk_changes_frames || in.root != -1 || in.single_leaf != 0;
+        // (a record without a tree is a bare chain — the way back for the hit records of world-space copies: no leaf refers to it — or a single
+        // wrapped record, which the leaf step tests in place: neither takes the walk out of its frame)
+        for (const auto& in : fs.insts) fs.walk_changes_frames = fs.walk_changes_frames || (in.root != -1 && in.single_leaf == 0);
+        for (const auto& in : fs.insts) fs.has_instance_leaves = fs.has_instance_leaves || in.root != -1 || in.single_leaf != 0;
         for (const auto& md : fs.media) fs.needs_general = fs.needs_general || md.b_count > 1 || md.n_outer > 0;
         return 0;
     }

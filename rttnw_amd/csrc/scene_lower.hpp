@@ -90,7 +90,8 @@ struct FlatScene {
     int32_t top_root = 0;
     uint32_t stack_depth = 4;         // entries a lane's traversal stack can need (exact bound for the 4-wide trees)
     uint32_t n_prims_in_bvh = 0;
-    bool walk_changes_frames = false; // some tree holds an instance leaf (a wrapped group or record the walk enters): false = the walk never leaves world space
+    bool has_instance_leaves = false; // some tree holds an instance leaf at all (a wrapped group, or a single wrapped record tested in place)
+    bool walk_changes_frames = false; // some tree holds an instance with a tree of its own (a wrapped group the walk enters): false = the walk never leaves world space
     uint32_t n_world_copies = 0;      // spheres of transformed groups that the walk tests as world-space copies in the top tree (scene_lower.cpp collect)
 };
 

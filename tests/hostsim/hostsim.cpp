@@ -263,7 +263,7 @@ static void walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const r
                         const Ray<float> saved = tr.ray;
                         tr.ray = to_object<true>(hs.view.insts[prev.inst], ps.ray);
                         tr.cur_inst = prev.inst;
-                        trav_test_record(tr, hs.view, ref_kind(prev.prim), ref_index(prev.prim), float(p->t_min), tr.ray);
+                        trav_test_record(tr, hs.view, ref_kind(prev.prim), ref_index(prev.prim), float(p->t_min), tr.ray, tr.cur_inst);
                         tr.ray = saved; tr.cur_inst = -1;
                     }
                     uint32_t trips = 0;

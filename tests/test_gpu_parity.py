@@ -355,11 +355,12 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
     monkeypatch.setenv("RTTNW_KERNEL", "plain")
     p.collect_counters = 0
     lin, rgba, st = gpu_render(gpu, sc, cam, p)
-    assert ((st.reserved & 4) != 0) == ((st.reserved & 2) != 0 and st.n_nodes <= 16 and (st.reserved & 8) == 0), (st.reserved, st.n_nodes)
-    assert ((st.reserved & 4) != 0) == (name == "cornell_box")
-    # (bit 3: a walk that never changes frames — spheres_1m; final_scene, whose only instance record is the bare chain of the cluster's world-space
-    # copies; smoke_cornell_box, whose rotated boxes are medium boundaries, not solids in a tree)
-    assert ((st.reserved & 8) != 0) == (name != "cornell_box" and (st.reserved & 2) != 0), st.reserved   # (the LDS form of this kernel has that instantiation)
+    assert ((st.reserved & 4) != 0) == ((st.reserved & 2) != 0 and st.n_nodes <= 16), (st.reserved, st.n_nodes)
+    assert ((st.reserved & 4) != 0) == (name in ("cornell_box", "smoke_cornell_box"))
+    # (bit 3: a walk that never changes frames — all four: spheres_1m has no wrapper; final_scene's only instance record is the bare chain of the cluster's
+    # world-space copies; cornell_box's two blocks are single wrapped records tested in place; smoke_cornell_box's rotated boxes are medium boundaries)
+    assert ((st.reserved & 8) != 0) == ((st.reserved & 2) != 0), st.reserved   # (the LDS form of this kernel has that instantiation)
+    assert ((st.reserved & 16) != 0) == (name == "cornell_box"), st.reserved   # (bit 4: ... the one that tests single wrapped records in place)
     if precision == abi.F64:
         assert np.array_equal(lin, out["plain"][0]) and np.array_equal(rgba, out["plain"][1])
     else:
@@ -367,7 +368,7 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
     # ... and the decoupled kernel's: a scene without any instance record takes the instantiation whose walk never changes frames (bit 3)
     monkeypatch.setenv("RTTNW_KERNEL", "wave")
     lin, rgba, st = gpu_render(gpu, sc, cam, p)
-    assert ((st.reserved & 8) != 0) == (name != "cornell_box"), st.reserved
+    assert ((st.reserved & 8) != 0) == (name != "cornell_box"), st.reserved   # (cornell_box's two wrapped blocks are instance leaves: that kernel keeps its instance code for them)
     if precision == abi.F64:
         assert np.array_equal(lin, out["wave"][0]) and np.array_equal(rgba, out["wave"][1])
     else:

@@ -558,7 +558,7 @@ def test_T2_at_baseline_size(gpu, oracle, scenes_lib, earth, name, crops, lsb_ea
     assert n_same64 / n_px >= 0.999 and n_close64 / n_px >= 0.99, (name, n_same64 / n_px, n_close64 / n_px)
 
 
-@pytest.mark.parametrize("precision", [abi.F64, abi.F32], ids=["f64", "f32"])
+@pytest.mark.parametrize("precision", [abi.F64, abi.F32, abi.F64_STRICT], ids=["f64", "f32", "f64strict"])
 def test_render_multi_equals_single_render(gpu, scenes_lib, earth, precision):
     """rttnw_render_multi — tile partition, per-device streams, gather, un-tile behind ONE C-ABI call — with one rank and
     with 2, 3 and 8 logical ranks on device 0: bit-identical to rttnw_render (a box with one GPU exercises everything
@@ -587,10 +587,18 @@ def test_graph_shapes_the_trait_objects_allow(gpu, oracle, shape, bvh):
     sg.set_world(graph_shapes.SHAPES[shape](sg))
     sg.commit()
     so, cam, p = graph_shapes.build(oracle, shape)
+    # RTTNW_F64_STRICT first, through a shutter of [0, 1]: where the default lowering holds world-space copies this makes the second lowering
+    # (reference_frame_scene) — which the wider shutter of the next render must then throw away and make again
+    cam01 = abi.CameraDesc.from_buffer_copy(cam)
+    cam01.open_time, cam01.close_time = 0.0, 1.0
+    _, ps = graph_shapes.build(oracle, shape, precision=abi.F64_STRICT)[1:]
+    assert np.isfinite(gpu_render(gpu, sg, cam01, ps)[0]).all()
     lin, rgba, _ = gpu_render(gpu, sg, cam, p)
     lo, ro, _ = rto.render(so, cam, p)
     assert (np.abs(lin - lo).max(axis=2) <= T1_ABS).mean() >= 0.999, (shape, np.abs(lin - lo).max())
     assert (rgba == ro).all(axis=2).mean() >= 0.999
+    lin_s, rgba_s, _ = gpu_render(gpu, sg, cam, ps)                                  # ... and the strict build equals the oracle on every pixel
+    assert np.abs(lin_s - lo).max() <= 1e-12 * max(1.0, lo.max()) and np.array_equal(rgba_s, ro), (shape, np.abs(lin_s - lo).max())
     _, cam32, p32 = graph_shapes.build(oracle, shape, spp=64, precision=abi.F32)
     lin32, _, _ = gpu_render(gpu, sg, cam32, p32)
     lo64, _, _ = rto.render(so, cam32, graph_shapes.build(oracle, shape, spp=64)[2])

@@ -57,9 +57,12 @@ def report(tag, r):
 base = report("trips 2N+L (kernel)", run(0, 2, 0))
 for a in (1, 3):
     report("trips %dN+L" % a, run(0, a, 0))
-for thr in (64, 96, 128, 160, 192):
+for a in (2, 3):
+    c = report("stash in trip, %dN+L" % a, run(3, a, 0))
+    print("      against the kernel's: %s" % " ".join("%+.1f%%" % (100 * (x / y - 1)) for x, y in zip(c, base)))
+for thr in (160,):
     c = report("vote leaf>=%d/256" % thr, run(1, 0, thr))
     print("      against the kernel's: %s" % " ".join("%+.1f%%" % (100 * (x / y - 1)) for x, y in zip(c, base)))
-for a, bb in ((8, 8), (16, 8), (16, 16), (24, 16), (32, 16), (16, 24)):
+for a, bb in ((8, 8),):
     c = report("drain nodes<%d leaves<%d" % (a, bb), run(2, a, bb))
     print("      against the kernel's: %s" % " ".join("%+.1f%%" % (100 * (x / y - 1)) for x, y in zip(c, base)))

@@ -361,6 +361,34 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
                 if (policy == 0) {
                     for (int k = 0; k < a; ++k) node_step();
                     leaf_step();
+                } else if (policy == 3) {
+                    // the kernel's trip with a leaf STASHED inside the trip: a lane that arrives at a one-record leaf in a node step but the last puts it
+                    // aside, takes its next pending subtree and goes on with node steps; the trip's leaf step tests the stashed record (and the leaf the
+                    // lane stands at waits for the next trip).  `a` node steps per trip.
+                    std::vector<int32_t> stash(64, 0);
+                    for (int k = 0; k < a; ++k) {
+                        node_step();
+                        if (k + 1 < a) {
+                            uint32_t li = 0;
+                            for (auto& l : L) {
+                                const uint32_t me = li++;
+                                if (l.done || stash[me] != 0) continue;
+                                const int32_t nd = l.tr.node;
+                                if (nd < 0 && nd != TRAV_DONE && nd != CHILD_EMPTY && leaf_kind(nd) != PRIM_INSTANCE && leaf_count(nd) == 1) {
+                                    stash[me] = nd;
+                                    trav_pop(l.tr, l.ps.ray, l.stack);
+                                }
+                            }
+                        }
+                    }
+                    uint32_t n = 0, li = 0;
+                    for (auto& l : L) {
+                        const uint32_t me = li++;
+                        if (l.done) continue;
+                        if (stash[me] != 0) { cnt.prim(); trav_test_record(l.tr, hs.view, leaf_kind(stash[me]), leaf_first(stash[me]), t_min, l.tr.ray, l.tr.cur_inst); ++n; }
+                        else if (at_leaf(l)) { trav_leaf_step(l.tr, hs.view, l.ps.ray, t_min, l.stack, cnt); ++n; }
+                    }
+                    if (n) { out[3]++; out[4] += n; }
                 } else if (policy == 1) {
                     if (nn == 0 || (nl != 0 && nl * 256u >= uint32_t(b) * (nn + nl))) leaf_step(); else node_step();
                 } else {

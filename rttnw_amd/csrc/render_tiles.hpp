@@ -84,9 +84,11 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     // scenes (cornell_box, final_scene: <= ~1k nodes), the decoupled form on deep BVHs where traversal lengths vary
     // most (1M spheres).  RTTNW_KERNEL=plain|plainglobal|wave overrides the choice (experiments only).
     const char* kv = getenv("RTTNW_KERNEL");
-    // (crossover measured on spheres_1m-like scenes of 2e4 - 2.5e5 spheres, 512x512 spp 256: f32 at ~24 k 4-wide nodes — 19.6 k:
-    // 3105 against 2972 Msamples/s, 28.3 k: 2258 against 2452 — f64 at ~50 k — 28.3 k: 2022 against 1740, 50.9 k: 1284 against 1318)
-    bool plain = flat.total_nodes4() < (sizeof(R) == 4 ? 24576u : 49152u);
+    // (crossover measured on spheres_1m-like scenes of 4e3 - 1e5 spheres, 512x512 spp 256, lane-owns-path against decoupled, Msamples/s.  Round 3: f32 at
+    // ~24 k 4-wide nodes, f64 at ~50 k.  After round 4 — quantised records, no instance code, 13-real path slots, the f64 unit split — the decoupled kernel
+    // takes over much earlier: f32 5.7 k nodes 7158 / 6646, 9.9 k 5272 / 5403, 15.4 k 3917 / 4460, 28.3 k 2273 / 3184; f64 9.9 k 4776 / 4039, 15.4 k
+    // 3559 / 3340, 19.6 k 2818 / 2898, 28.3 k 1979 / 2332, 50.9 k 1223 / 1722)
+    bool plain = flat.total_nodes4() < (sizeof(R) == 4 ? 8192u : 16384u);
     if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     if (!prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));

@@ -376,7 +376,7 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
 
 
 def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib):
-    """A scene beyond the measured crossover (24 576 four-wide nodes in f32, 49 152 in f64) selects the decoupled kernel by itself; it
+    """A scene beyond the measured crossover (8 192 four-wide nodes in f32, 16 384 in f64) selects the decoupled kernel by itself; it
     must agree with the forced lane-owns-path form."""
     sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=150000)
     cam, p = util.params_for(setup, 64, 64, 4, precision=abi.F32, seed=3)

@@ -26,6 +26,10 @@
                         // for a while.  At the round's end — no slot tests, no instance code, 13-real path slots — the f32 kernel moves 6.2 TB/s and little else,
                         // and half the node bytes are worth +10 %: spheres_1m f32 433 -> 476 Msamples/s on these records; the half-precision ones are gone.)
 #endif
+#ifndef RT_WAVE_RETIRE
+#define RT_WAVE_RETIRE 8 // finished rays that end a burst while rays are queued (the hand-over of their lanes).  Round 4's end, spheres_1m f64 / f32 Msamples/s:
+                         // 4 / 6 / 8 / 12 / 16 / 24 / 32 -> 342 / 340 / 342 / 339 / 336 / 323 / 308 and 490 / 484 / 489 / 489 / 483 / 464 / 449
+#endif
 #ifndef RT_WAVE_STEPS
 #define RT_WAVE_STEPS 5 // node steps per trip of the decoupled kernel's bursts (2 / 3 / 4 / 6: 302 / 321 / 325 / 330 Msamples/s in round 1; round 4's end, spheres_1m
                         // f64 / strict / f32 with 4 / 5 / 6: 334 / 340 / 332, 331 / 332 / 331, 481 / 481 / 476; 8: f32 442)
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
         // the vote cost about as much as a node step, and plain trips beat it: spheres_1m 306 -> 330 Msamples/s,
         // final_scene through this kernel 916 -> 1084.  Node steps per trip 2 / 3 / 4 / 6: 302 / 321 / 325 / 330.)
         {
-            const uint32_t retire_batch = ray_n != 0u ? 16u : 64u;
+            const uint32_t retire_batch = ray_n != 0u ? uint32_t(RT_WAVE_RETIRE) : 64u;
             if constexpr (COUNT) dbg[8] += 1;
             for (;;) {
                 const bool walking = has_ray && tr.node != TRAV_DONE;

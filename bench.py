@@ -324,6 +324,14 @@ def main():
                       "hbm_algorithmic": hbm_alg, "valu": valu}
             if traffic is not None and secs > 0:
                 common["traffic_frac_of_hbm_peak"] = round(traffic / secs / 1e9 / HBM_PEAK_GBPS, 5)
+            # the scalars a reader of the line wants first, flat (nested objects may be dropped by whoever parses the line): SURVEY 8(d)'s byte
+            # fraction whatever `bound` says, and — while a PMC summary of this kernel source is committed — what the counters say beside it
+            common["hbm_alg_frac"] = hbm_alg["frac"]
+            common["hbm_alg_gbps"] = hbm_alg["achieved"]
+            common["lane_utilisation"] = valu["lane_utilisation"] if valu else None
+            common["issue_utilisation"] = valu["issue_utilisation"] if valu else None
+            common["valu_insts_per_sample"] = valu["wave_instructions_per_sample"] if valu else None
+            common["traffic_over_algorithmic"] = round(traffic / hbm_alg["alg_bytes_per_launch"], 4) if traffic is not None and hbm_alg["alg_bytes_per_launch"] else None
             # what bounds the kernel: memory when the node records are walked in HBM / Infinity Cache (the decoupled kernel:
             # counter traffic ~ algorithmic bytes), vector-instruction issue when they are LDS-resident (counter traffic ~1 % of peak)
             if lds_resident and valu is not None:
@@ -359,11 +367,15 @@ def main():
     value = wl.samples_total / (ms_per_step * 1e-3) / 1e6
     roof = wl.roofline(precision, kernel_ms)
 
-    # ---- the same workload through the other precision's kernels, its own multi-step timing
-    other = None
+    # ---- the same workload through the other precision's kernels, its own multi-step timing; and through the IEEE-strict build of the f64
+    # kernels (RTTNW_F64_STRICT: nothing contracted, every object tested in the reference's frame — the build whose pixels ARE the CPU
+    # reference's, tests/test_gpu_parity.py::test_f64_strict_takes_the_oracles_decisions)
+    other = strict = None
     if not args.no_other:
         oprec = abi.F64 if precision == abi.F32 else abi.F32
         other = wl.record(oprec, max(1, min(args.steps, 5)), 1)
+        if precision != abi.F64_STRICT and world == 1 and share is None:
+            strict = wl.record(abi.F64_STRICT, max(1, min(args.steps, 5)), 1)
 
     def cpu_sample(w, seconds, name):
         """The CPU oracle on the host cores for a bounded sample of workload `w` at its full frame and geometry: calibrate at 1 spp, then
@@ -405,6 +417,8 @@ def main():
             rec["config"] = w2.config()
             if first == abi.F64_STRICT:
                 rec["f64_kernels"] = w2.record(abi.F64, args.sub_steps, 1)
+            else:
+                rec["f64strict_kernels"] = w2.record(abi.F64_STRICT, args.sub_steps, 1)
             rec["f32_kernels"] = w2.record(abi.F32, args.sub_steps, 1)
             if rank == 0 and args.cpu_seconds > 0:
                 rec["cpu_baseline"] = cpu_sample(w2, min(args.cpu_seconds, 6.0), name)
@@ -432,6 +446,8 @@ def main():
             "cpu_baseline": cpu,
             ("f64_kernels" if precision == abi.F32 else "f32_kernels"): other,
         }
+        if strict is not None:
+            out["f64strict_kernels"] = strict
         out.update(subs)
         print(json.dumps(out), flush=True)
     if use_dist:

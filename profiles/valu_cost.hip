@@ -38,7 +38,29 @@ template <int KIND> __device__ __forceinline__ void body(float (&f)[8], double (
     if constexpr (KIND == 20) asm volatile("v_fma_mix_f32 %0, %1, %0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(f[i]) : "v"(u[i]));   \
     if constexpr (KIND == 21) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(f[i]) : "v"(u[i]));                                            \
     if constexpr (KIND == 22) asm volatile("v_min_f32 %0, %0, %0" : "+v"(f[i]));                                                        \
-    if constexpr (KIND == 23) asm volatile("v_mov_b32 %0, %1" : "=v"(f[i]) : "v"(u[i]));
+    if constexpr (KIND == 23) asm volatile("v_mov_b32 %0, %1" : "=v"(f[i]) : "v"(u[i]));                                                \
+    if constexpr (KIND == 24) asm volatile("v_perm_b32 %0, %0, %1, s20" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));                            \
+    if constexpr (KIND == 25) asm volatile("v_and_or_b32 %0, %0, %1, %0" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));                           \
+    if constexpr (KIND == 26) asm volatile("v_min_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));                                  \
+    if constexpr (KIND == 27) asm volatile("v_lshl_or_b32 %0, %0, 7, %1" : "+v"(u[i]) : "v"(u[(i + 1) & 7]));                           \
+    if constexpr (KIND == 28) asm volatile("v_bfe_u32 %0, %0, 8, 8" : "+v"(u[i]));                                                      \
+    if constexpr (KIND == 29) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(f[i]) : "v"(d[i]));                                            \
+    if constexpr (KIND == 30) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[i]) : "v"(f[i]));                                            \
+    if constexpr (KIND == 31) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(f[i]));                                                        \
+    if constexpr (KIND == 32) asm volatile("v_lshlrev_b32 %0, 7, %0" : "+v"(u[i]));                                                     \
+    if constexpr (KIND == 33) asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(u[i]));                                               \
+    if constexpr (KIND == 34) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(f[i]) : "v"(u[i]));                                         \
+    if constexpr (KIND == 35) asm volatile("v_add_u32 %0, %0, %0" : "+v"(u[i]));                                                        \
+    if constexpr (KIND == 36) asm volatile("v_lshl_add_u32 %0, %0, 2, %0" : "+v"(u[i]));                                                \
+    if constexpr (KIND == 37) asm volatile("v_div_scale_f64 %0, vcc, %0, %0, %0" : "+v"(d[i]) : : "vcc");                               \
+    if constexpr (KIND == 38) asm volatile("v_div_fmas_f64 %0, %0, %0, %0" : "+v"(d[i]) : : "vcc");                                     \
+    if constexpr (KIND == 39) asm volatile("v_div_fixup_f64 %0, %0, %0, %0" : "+v"(d[i]));                                              \
+    if constexpr (KIND == 40) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[i]) : "v"(u[i]));                                            \
+    if constexpr (KIND == 41) asm volatile("v_cmp_lt_u32 vcc, %0, %0" : : "v"(u[i]) : "vcc");                                           \
+    if constexpr (KIND == 42) asm volatile("v_and_b32 %0, %0, %0" : "+v"(u[i]));                                                        \
+    if constexpr (KIND == 43) asm volatile("v_sqrt_f32 %0, %0" : "+v"(f[i]));                                                           \
+    if constexpr (KIND == 44) asm volatile("v_fmac_f32 %0, %0, %0" : "+v"(f[i]));                                                       \
+    if constexpr (KIND == 45) asm volatile("v_mad_u32_u24 %0, %0, %0, %0" : "+v"(u[i]));
     REP8(ONE)
 #undef ONE
 }
@@ -124,5 +146,8 @@ int main(int argc, char** argv) {
     ROW(0, "v_fma_f32") ROW(15, "v_max3_f32") ROW(11, "v_cmp_lt_f32") ROW(14, "v_cvt_f32_ubyte1") ROW(13, "v_rcp_f32")
     ROW(7, "v_xor_b32") ROW(8, "v_cndmask_b32") ROW(18, "v_add_co_u32") ROW(19, "v_bcnt_u32_b32") ROW(4, "v_mul_lo_u32") ROW(5, "v_mul_hi_u32") ROW(6, "v_mad_u64_u32") ROW(9, "v_lshrrev_b64")
     ROW(1, "v_fma_f64") ROW(2, "v_add_f64") ROW(3, "v_mul_f64") ROW(10, "v_cmp_lt_f64") ROW(16, "v_cvt_f64_u32") ROW(12, "v_rcp_f64") ROW(17, "v_sqrt_f64") ROW(20, "v_fma_mix_f32") ROW(21, "v_cvt_f32_f16") ROW(22, "v_min_f32") ROW(23, "v_mov_b32")
+    ROW(24, "v_perm_b32") ROW(25, "v_and_or_b32") ROW(26, "v_min_u32") ROW(27, "v_lshl_or_b32") ROW(28, "v_bfe_u32") ROW(29, "v_cvt_f32_f64") ROW(30, "v_cvt_f64_f32") ROW(31, "v_mul_f32")
+    ROW(32, "v_lshlrev_b32") ROW(33, "v_cndmask_b32 vcc") ROW(34, "v_cvt_f32_ubyte0") ROW(35, "v_add_u32") ROW(36, "v_lshl_add_u32") ROW(37, "v_div_scale_f64") ROW(38, "v_div_fmas_f64")
+    ROW(39, "v_div_fixup_f64") ROW(40, "v_cvt_f32_u32") ROW(41, "v_cmp_lt_u32") ROW(42, "v_and_b32") ROW(43, "v_sqrt_f32") ROW(44, "v_fmac_f32") ROW(45, "v_mad_u32_u24")
     return 0;
 }

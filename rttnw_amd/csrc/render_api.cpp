@@ -124,7 +124,10 @@ int reference_frame_scene(::rttnw_scene* s, const FlatScene*& flat) {
         if (on_device)
             if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
         std::unique_ptr<FlatScene> ref(new FlatScene());
-        if (int rc = lower_scene(s->graph, *ref, err, on_device ? &device_builder : nullptr, s->flat.time0, s->flat.time1, 0)) { set_last_error(err); return rc; }
+        // RTTNW_STRICT_GROUP_TREES=1 (experiments / tests): the round-4 form — the copies stay in their groups' trees and the walk enters them
+        const char* gt = getenv("RTTNW_STRICT_GROUP_TREES");
+        const int ref_mode = gt && gt[0] == '1' ? 0 : 2;
+        if (int rc = lower_scene(s->graph, *ref, err, on_device ? &device_builder : nullptr, s->flat.time0, s->flat.time1, ref_mode)) { set_last_error(err); return rc; }
         s->flat_ref = std::move(ref);
     }
     flat = s->flat_ref.get();

@@ -26,7 +26,9 @@
 // one library without their template instantiations colliding.
 #if defined(RT_STRICT_F64)
 #define RT_ARITH_NS ieee_strict
+#ifndef RT_SHARED_RECIPROCALS // (overridden in experiments only: what the IEEE quotients cost)
 #define RT_SHARED_RECIPROCALS 0
+#endif
 #else
 #define RT_ARITH_NS contracted
 #define RT_SHARED_RECIPROCALS 1
@@ -1044,10 +1046,34 @@ RT_HD void trav_node_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
 // the lockstep kernel (lanes with a one-record leaf wait instead of going on with node steps), so nothing uses it.
 // (`ray`: the ray in the frame of the record — tr.ray, the world ray itself where the walk never changes frames, or a single wrapped record's
 // object-space ray; `inst`: the instance that frame belongs to, or -1)
-template <typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
+// Leaves of kind PRIM_SPHERE_WC (the lowering RTTNW_F64_STRICT renders; the host build of the core knows them too): the world-space copy of a sphere
+// that lives under Translate / YRotate wrappers was found through its world-space BOX, which only culls; the test itself is the reference's —
+// the ray taken through the group's wrappers (Translate::hit hittable.rs:599-606, YRotate::hit :686-699: the walk's own to_object code) and
+// Sphere::hit (:87-109) on the object-space record, so t is the reference's bit for bit.  The copy's material slot leads to both (MAT_HOME_*).
+#if defined(RT_STRICT_F64) || !defined(__HIP_DEVICE_COMPILE__)
+#define RT_HAS_SPHERE_WC 1
+#else
+#define RT_HAS_SPHERE_WC 0
+#endif
+template <bool G, typename R> RT_HD bool sphere_wc_t(const SceneView<R>& sc, uint32_t idx, const Ray<R>& wray, R t_min, R t_max, R& t) {
+    const int32_t home = sc.sphere_mat[idx];
+    const InstanceRec<R>& in = sc.insts[(home >> MAT_HOME_INST_SHIFT) & MAT_HOME_INST_MAX];
+    const SphereRec<R> s = sc.spheres[uint32_t(home) & MAT_HOME_SPHERE_MASK];
+    const Ray<R> obj = to_object<G>(in, wray);
+    return sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, obj, t_min, t_max, t);
+}
+template <bool G = false, typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
     R t;
     int aux = 0;
-    if (prim_t(sc, kind, idx, ray, t_min, tr.closest, t, aux)) {
+    bool hit;
+#if RT_HAS_SPHERE_WC
+    if (kind == PRIM_SPHERE_WC) { // (only ever in the top tree: `ray` is the world ray)
+        hit = sphere_wc_t<G>(sc, idx, ray, t_min, tr.closest, t);
+        kind = PRIM_SPHERE; // the hit reference names the copy's record: make_record finds the object-space one from it
+    } else
+#endif
+    hit = prim_t(sc, kind, idx, ray, t_min, tr.closest, t, aux);
+    if (hit) {
         // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
         const bool loses_tie = tr.found && t == tr.closest &&
                                prim_seq(sc, kind, idx) < prim_seq(sc, ref_kind(tr.best.prim), ref_index(tr.best.prim));
@@ -1077,7 +1103,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
         if (single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk, the walk stays in its frame
             const Ray<R> obj = object_ray();
             cnt.prim();
-            trav_test_record(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min, obj, int32_t(first));
+            trav_test_record<Cnt::GENERAL>(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min, obj, int32_t(first));
             trav_pop<NI>(tr, wray, stack);
             return;
         }
@@ -1092,12 +1118,12 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     if constexpr (WHOLE_LEAF) {
         for (uint32_t k = 0; k < count; ++k) {
             cnt.prim();
-            trav_test_record(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+            trav_test_record<Cnt::GENERAL>(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         }
         trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
-        trav_test_record(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+        trav_test_record<Cnt::GENERAL>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }
 }

@@ -25,6 +25,8 @@ enum : uint32_t {
     PRIM_BOX = 3,           // Cube (six rectangles, one record) — hittable.rs:549-592
     PRIM_INSTANCE = 4,      // Translate / YRotate chain over a sub-BVH — hittable.rs:594-722
     PRIM_MEDIUM = 5,        // ConstantMedium (never inside the BVH; hit-reference kind only)
+    PRIM_SPHERE_WC = 6,     // leaf kind only, RTTNW_F64_STRICT's lowering only: world-space copies of a transformed group's spheres — culled by their
+                            // world-space boxes, TESTED in the group's frame (rt_core.hpp sphere_wc_t); their records lie in the sphere arrays
     PRIM_NONE = 7
 };
 

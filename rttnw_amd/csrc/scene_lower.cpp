@@ -226,7 +226,7 @@ struct Lowering {
             for (size_t c = a; c < b; ++c) {
                 std::array<uint32_t, 4> k{0, 0, 0, 0};
                 for (size_t i = c * grain; i < std::min(n, (c + 1) * grain); ++i)
-                    if (items[i].kind <= PRIM_BOX) ++k[items[i].kind];
+                    if (rec_array(items[i].kind) < 4u) ++k[rec_array(items[i].kind)];
                 start[c + 1] = k;
             }
         });
@@ -240,7 +240,7 @@ struct Lowering {
                 std::array<uint32_t, 4> at = start[c];
                 for (size_t i = c * grain; i < std::min(n, (c + 1) * grain); ++i) {
                     const Item& it = items[i];
-                    idx_out[i] = it.kind == PRIM_INSTANCE ? uint32_t(it.obj) : at[it.kind]++;
+                    idx_out[i] = it.kind == PRIM_INSTANCE ? uint32_t(it.obj) : at[rec_array(it.kind)]++;
                 }
             }
         });
@@ -253,8 +253,11 @@ struct Lowering {
                 if (items[i].kind != PRIM_INSTANCE) emit_at(items[i], idx[i]);
         });
     }
+    // which of the four record arrays (sphere, moving, rect, box) an item's record goes to; 4: none (an instance)
+    static uint32_t rec_array(uint32_t kind) { return kind == PRIM_SPHERE_WC ? uint32_t(PRIM_SPHERE) : (kind <= PRIM_BOX ? kind : 4u); }
     uint32_t emit(const Item& it) {
         switch (it.kind) {
+        case PRIM_SPHERE_WC:
         case PRIM_SPHERE: fs.spheres.emplace_back(); fs.sphere_mat.emplace_back(); fs.sphere_seq.emplace_back(); return emit_at(it, uint32_t(fs.spheres.size() - 1));
         case PRIM_MOVING_SPHERE: fs.moving.emplace_back(); return emit_at(it, uint32_t(fs.moving.size() - 1));
         case PRIM_RECT: fs.rects.emplace_back(); return emit_at(it, uint32_t(fs.rects.size() - 1));
@@ -266,6 +269,7 @@ struct Lowering {
     uint32_t emit_at(const Item& it, uint32_t at) {
         const GraphObj& o = g.objs[it.obj];
         switch (it.kind) {
+        case PRIM_SPHERE_WC:
         case PRIM_SPHERE: {
             if (it.world_copy >= 0) {
                 const WorldSphere& w = world_spheres[it.world_copy];
@@ -315,7 +319,7 @@ struct Lowering {
         for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
     }
 
-    static bool groupable(uint32_t kind) { return kind == PRIM_SPHERE || kind == PRIM_RECT || kind == PRIM_BOX; }
+    static bool groupable(uint32_t kind) { return kind == PRIM_SPHERE || kind == PRIM_RECT || kind == PRIM_BOX || kind == PRIM_SPHERE_WC; }
 
     // ---- binned-SAH build over items[lo, hi), in two phases.
     // split(): decides the topology — bins, partitions `items` in place (afterwards the items stand in leaf order) and notes
@@ -599,6 +603,7 @@ struct Lowering {
     ItemVec* top_items = nullptr;
     std::vector<WorldSphere> world_spheres;
     bool move_spheres = true;         // false keeps them in their groups' trees (lower_scene's world_spheres; RTTNW_WORLD_SPHERES)
+    bool test_in_group_frame = false; // lower_scene's world_spheres == 2: the copies are leaves of kind PRIM_SPHERE_WC — culled in world space, tested in their group's frame
     int world_spheres_arg = -1;       // lower_scene's argument: -1 = the default above or the environment's word
 
     bool append_ops(Chain& c, const InstanceRec<double>& in) {
@@ -706,7 +711,7 @@ struct Lowering {
                         wb.lo[k] = w.c[k] - pad; wb.hi[k] = w.c[k] + pad;
                     }
                     world_spheres.push_back(w);
-                    Item copy{PRIM_SPHERE, it.obj, wb, it.seq};
+                    Item copy{test_in_group_frame ? uint32_t(PRIM_SPHERE_WC) : uint32_t(PRIM_SPHERE), it.obj, wb, it.seq};
                     copy.world_copy = int32_t(world_spheres.size() - 1);
                     top_items->push_back(copy);
                     moved = true;
@@ -927,8 +932,8 @@ struct Lowering {
         const auto t_start = now();
         lower_textures_materials();
         const auto t_mats = now();
-        if (world_spheres_arg >= 0) move_spheres = world_spheres_arg != 0;
-        else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
+        if (world_spheres_arg >= 0) { move_spheres = world_spheres_arg != 0; test_in_group_frame = world_spheres_arg == 2; }
+        else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) { move_spheres = std::atoi(e) != 0; test_in_group_frame = std::atoi(e) == 2; }
         ItemVec top;
         top_items = &top;
         collect(g.world, top, Chain{});

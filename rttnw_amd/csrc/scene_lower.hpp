@@ -99,7 +99,9 @@ struct FlatScene {
 // replaces the host binned-SAH build for every tree of two or more leaves by the device builder (bvh_build.hpp); those
 // trees stay on the device.
 // `world_spheres`: 1 / 0 = test the spheres of transformed groups as world-space copies in the top tree / leave them in their groups' trees, in
-// the frame the reference tests them in (what RTTNW_F64_STRICT renders); -1 = the default (1, or RTTNW_WORLD_SPHERES).
+// the frame the reference tests them in; 2 = what RTTNW_F64_STRICT renders: the copies' world-space boxes in the top tree (culling never shapes
+// a result), the sphere test itself in the group's frame, through the group's wrappers as in hittable.rs:599-606,686-699 (leaf kind
+// PRIM_SPHERE_WC); -1 = the default (1, or RTTNW_WORLD_SPHERES).
 int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const DeviceBvhApi* device = nullptr, double time0 = 0.0,
                 double time1 = 1.0, int world_spheres = -1);
 

@@ -159,7 +159,10 @@ enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, 
 // LDS stack entries of the decoupled kernel: 16 for f32; 12 for f64, whose queues are twice as wide — with 16 a 256-thread
 // block needs 58 368 B and only TWO fit in a CU's 160 KB, i.e. 2 waves/SIMD however few registers the kernel is held to;
 // with 12 it is 54 272 B and three fit (the spill strip in global memory takes the rare deeper entries).
-template <typename R> __host__ __device__ constexpr uint32_t wave_stack_entries() { return sizeof(R) == 8 ? 12u : LDS_STACK_ENTRIES; }
+#ifndef RT_F64_WAVE_STACK
+#define RT_F64_WAVE_STACK 12
+#endif
+template <typename R> __host__ __device__ constexpr uint32_t wave_stack_entries() { return sizeof(R) == 8 ? uint32_t(RT_F64_WAVE_STACK) : LDS_STACK_ENTRIES; }
 template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
     return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (wave_stack_entries<R>() + 1u) * 64u * 4u; // stack: + the spare slot
 }

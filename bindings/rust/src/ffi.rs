@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTTNW_ABI_VERSION: c_int = 2;
+pub const RTTNW_ABI_VERSION: c_int = 3;
 
 /// Opaque scene handle.
 #[repr(C)]
@@ -32,6 +32,8 @@ pub const RTTNW_QUIRKS_REFERENCE: u32 = RTTNW_QUIRK_YROTATE_BACKROT;
 pub const RTTNW_BVH_HOST_SAH: u32 = 0;
 pub const RTTNW_BVH_DEVICE_LBVH: u32 = 1;
 pub const RTTNW_BVH_DEVICE_SAH: u32 = 2;
+pub const RTTNW_BVH_AUTO: u32 = 3;
+pub const RTTNW_BVH_AUTO_DEVICE_LEAVES: u32 = 100000;
 
 /// `CameraDescriptor` — src/math/camera.rs:5-15
 #[repr(C)]

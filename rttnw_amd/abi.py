@@ -11,7 +11,8 @@ ERR_NAMES = {-1: "RTTNW_ERR_INVALID", -2: "RTTNW_ERR_STATE", -3: "RTTNW_ERR_UNSU
 
 XY, XZ, YZ = 0, 1, 2
 F64, F32, F64_STRICT = 0, 1, 2
-BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_DEVICE_SAH = 0, 1, 2
+BVH_HOST_SAH, BVH_DEVICE_LBVH, BVH_DEVICE_SAH, BVH_AUTO = 0, 1, 2, 3
+ABI_VERSION = 3  # include/rttnw_hip.h RTTNW_ABI_VERSION
 QUIRK_YROTATE_BACKROT = 1
 QUIRKS_REFERENCE = QUIRK_YROTATE_BACKROT
 

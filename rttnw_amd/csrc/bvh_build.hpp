@@ -48,6 +48,8 @@ struct DeviceBvhApi {
     std::function<int(const BuildPrim* prims, size_t n, const float* centroid_bounds, DeviceTree& out, std::string& err)> build;
     // add base4 to the inner child indices of the tree's 4-wide records (and remember base4 / base2 in the tree)
     std::function<int(DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& err)> rebase;
+    // trees of fewer leaves are built on the host (RTTNW_BVH_AUTO: include/rttnw_hip.h RTTNW_BVH_AUTO_DEVICE_LEAVES; the explicit device builders: 2)
+    size_t min_leaves = 2;
 };
 // Copy a device tree's records to the host (inspection, other devices): out4 / out2 may be null.
 int device_tree_download(const DeviceTree& tree, Bvh4Node* out4, BvhNode* out2, std::string& err);

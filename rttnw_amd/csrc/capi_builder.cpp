@@ -197,9 +197,14 @@ int rttnw_scene_commit(rttnw_scene* s) {
     if (s->committed) return RTTNW_OK; // idempotent
     std::string err;
     rt::DeviceBvhApi device_builder;
-    const bool on_device = s->bvh_builder != RTTNW_BVH_HOST_SAH;
+    bool on_device = s->bvh_builder != RTTNW_BVH_HOST_SAH;
     if (on_device)
-        if (int brc = rt::device_bvh_builder(s, device_builder, err)) return fail(brc, err.c_str());
+        if (int brc = rt::device_bvh_builder(s, device_builder, err)) {
+            // (RTTNW_BVH_AUTO without a device builder — the host test build of this file — builds on the host; in the library itself a missing
+            // device fails the commit a few lines down: there is no CPU render path)
+            if (s->bvh_builder != RTTNW_BVH_AUTO) return fail(brc, err.c_str());
+            on_device = false;
+        }
     const auto t0 = std::chrono::steady_clock::now();
     s->build_kernel_ms = 0;
     int rc = rt::lower_scene(s->graph, s->flat, err, on_device ? &device_builder : nullptr);
@@ -213,7 +218,7 @@ int rttnw_scene_commit(rttnw_scene* s) {
 
 int rttnw_scene_set_bvh_builder(rttnw_scene* s, uint32_t builder) {
     if (int rc = check_open(s)) return rc;
-    if (builder != RTTNW_BVH_HOST_SAH && builder != RTTNW_BVH_DEVICE_LBVH && builder != RTTNW_BVH_DEVICE_SAH) return fail(RTTNW_ERR_INVALID, "unknown BVH builder");
+    if (builder != RTTNW_BVH_HOST_SAH && builder != RTTNW_BVH_DEVICE_LBVH && builder != RTTNW_BVH_DEVICE_SAH && builder != RTTNW_BVH_AUTO) return fail(RTTNW_ERR_INVALID, "unknown BVH builder");
     s->bvh_builder = builder;
     return RTTNW_OK;
 }

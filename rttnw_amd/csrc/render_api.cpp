@@ -58,9 +58,10 @@ int device_bvh_builder(::rttnw_scene* s, DeviceBvhApi& out, std::string& err) {
         return RTTNW_ERR_HIP;
     }
     out.build = [s](const BuildPrim* prims, size_t n, const float* centroid_bounds, DeviceTree& tree, std::string& e) {
-        return lbvh_build_device_tree(prims, n, centroid_bounds, s->bvh_builder == RTTNW_BVH_DEVICE_SAH, tree, &s->build_kernel_ms, e);
+        return lbvh_build_device_tree(prims, n, centroid_bounds, s->bvh_builder != RTTNW_BVH_DEVICE_LBVH, tree, &s->build_kernel_ms, e);
     };
     out.rebase = [](DeviceTree& tree, uint32_t base4, uint32_t base2, std::string& e) { return device_tree_rebase(tree, base4, base2, e); };
+    out.min_leaves = s->bvh_builder == RTTNW_BVH_AUTO ? RTTNW_BVH_AUTO_DEVICE_LEAVES : 2u;
     return 0;
 }
 
@@ -332,10 +333,14 @@ static bool g_comms_atexit = false;
 // never calls it still leaves RCCL in order — before the HIP runtime's own teardown, which atexit runs later: LIFO).
 static void destroy_comms() {
     std::lock_guard<std::mutex> lock(g_comms_mutex);
+    // (at exit, under a host that tears its own HIP context down first — Python with torch —, the runtime may already be finalising: then
+    // only the host structures are released; RCCL's own teardown has nothing left to talk to)
+    int n_dev = 0;
+    const bool runtime_alive = hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0;
     for (MultiComms* c : g_comms) {
         std::lock_guard<std::mutex> use(c->in_use);
         for (ncclComm_t comm : c->comms)
-            if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+            if (comm && g_rccl.CommDestroy && runtime_alive) (void)g_rccl.CommDestroy(comm);
         c->comms.clear();
     }
     for (MultiComms* c : g_comms) delete c;

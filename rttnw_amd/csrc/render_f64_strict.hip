@@ -4,6 +4,10 @@
 // reference's — the mode the full-size parity tests pin bit for bit, and a caller's choice when reproducibility against the CPU
 // build matters more than the 5-10 % the contracted build gains.
 #define RT_STRICT_F64 1
+#if defined(__FAST_MATH__)
+#error "render_f64_strict.hip must not be built with fast-math flags: its results are the CPU reference's bit for bit"
+#endif
+#pragma clang fp contract(off) // (beside the Makefile's trailing -ffp-contract=off: honoured should the unit ever be built under fast-honor-pragmas)
 #include "render_tiles.hpp"
 
 namespace rt {

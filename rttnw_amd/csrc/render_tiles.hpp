@@ -66,7 +66,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         }
         (void)hipGetLastError(); // clear the sticky out-of-memory
         const size_t one_group = size_t(rc.my_tiles) * 64 * std::min<uint32_t>(16u, total_chunks) * 3 * sizeof(R);
-        if (d->partial && d->partial_bytes >= one_group) { // no larger buffer to be had: split the render by the one in hand
+        // (not under RTTNW_CHUNK_SUM_BUDGET: launch_chunks() would size the launches by the environment's budget again, not by the buffer in hand)
+        if (d->partial && d->partial_bytes >= one_group && !getenv("RTTNW_CHUNK_SUM_BUDGET")) { // no larger buffer to be had: split the render by the one in hand
             per_launch = launch_chunks(uint64_t(rc.my_tiles) * 64, 3 * sizeof(R), total_chunks, d->partial_bytes);
             if (!getenv("RTTNW_CHUNK_SUM_BUDGET")) d->chunk_budget = std::max<uint64_t>(d->partial_bytes, 1ull << 30);
             break;
@@ -98,7 +99,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
         int blocks_per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, TRACE_BLOCK, lds_bytes));
-        blocks_per_cu = std::max(1, std::min(blocks_per_cu, 8));
+        // (the runtime's answer counts LDS in finer units than the hardware allocates it in: trace_kernels.hpp lds_blocks_per_cu)
+        blocks_per_cu = std::max(1, std::min(std::min(blocks_per_cu, 8), int(lds_blocks_per_cu(uint32_t(lds_bytes)))));
         // what the chip holds at once (no inter-workgroup dependency, so a little over-subscription is harmless),
         // but never more waves than there is work for
         grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + 3) / 4));

@@ -451,6 +451,11 @@ template <int FORM, typename R> RT_HD SlabRay<R> slab_ray(V3<R> o, V3<R> d) {
     }
     return sr;
 }
+// 1 / d of axis a as the walk's slab tests hold it
+template <typename R> RT_HD float slab_inv_of(const SlabRay<R>& sr, int a) {
+    if constexpr (sizeof(R) == 8) return sr.inv[a];
+    else return a == 0 ? sr.inv.x : (a == 1 ? sr.inv.y : sr.inv.z);
+}
 // A 4-wide record as a lane holds it for a node step: the NEAR and the FAR plane of every axis for the four children
 // (which of lo / hi is the near one depends on the sign of the ray direction only, so the lane fetches them by address —
 // NodePlanes::near_q, set once per walk — instead of selecting per child), and the four child slots.
@@ -867,8 +872,28 @@ template <typename R, typename Stack> RT_HD void trav_set_ray(Trav<R>& tr, const
 #pragma unroll
     for (int a = 0; a < 3; ++a) tr.near_off[a] = stack.plane_off(near_piece(a, tr.sr));
 }
-template <typename R, typename Stack> RT_HD void trav_begin(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, const Stack& stack) {
-    trav_set_ray(tr, wray, stack);
+// A ray NOTHING can cull: on every axis its plane distances are NaN (a NaN / infinite origin or direction, a zero direction, |o / d| beyond the
+// floats) — maxNum / minNum drop them all, so even the inverted box of an UNUSED node slot "passes" (the node steps do not test the slot itself,
+// RT_NODE_EMPTY_CHECK).  Such a walk would push three entries per node, past the bound the lowering sized the stacks by (FlatScene::stack_depth
+// counts real children).  One axis with a finite, non-zero 1 / d and a finite o / d is enough for every unused slot to miss (entry +inf, exit -inf).
+// A ray without one is not walked at all: no hit, closest = NaN — which path_shade turns into a NaN path value, the NaN pixel the reference
+// renders from such a ray (main.rs:219-225 then writes 0).  Checked once per world.hit(), not per node.
+template <typename R> RT_HD bool slab_ray_can_be_culled(const SlabRay<R>& sr, V3<R> o) {
+    const R oo[3] = {o.x, o.y, o.z};
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = slab_inv_of(sr, a);
+        float oi;
+        if constexpr (sizeof(R) == 8) oi = sr.oinv[a]; else oi = float(oo[a]) * inv;
+        any = any || (rt_fabs(oi) < __builtin_huge_valf() && rt_fabs(inv) > 0.f && rt_fabs(inv) < __builtin_huge_valf());
+    }
+    return any;
+}
+// trav_begin() in two halves — the walk's cursor, and what the ray contributes to its slab tests — for the kernel that SUSPENDS walks across its
+// shade phases (trace_kernels.hpp trace_kernel_plain, RT_ASYNC_SHADE): only the cursor lives through a shade phase, the slab constants are made
+// again from the path's ray when the walk goes on.
+template <typename R> RT_HD void trav_init(Trav<R>& tr, const SceneView<R>& sc) {
     tr.closest = Lim<R>::max(); // world.hit(ray, t_min, f64::MAX) — main.rs:33
     tr.best.prim = make_ref(PRIM_NONE, 0);
     tr.best.inst = -1;
@@ -878,6 +903,14 @@ template <typename R, typename Stack> RT_HD void trav_begin(Trav<R>& tr, const S
     tr.cur_inst = -1;
     tr.leaf_k = 0;
     tr.found = false;
+}
+template <typename R> RT_HD void trav_reject_unwalkable(Trav<R>& tr, const Ray<R>& wray) {
+    if (!slab_ray_can_be_culled(tr.sr, wray.o)) { tr.node = TRAV_DONE; tr.closest = Lim<R>::inf() - Lim<R>::inf(); }
+}
+template <typename R, typename Stack> RT_HD void trav_begin(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, const Stack& stack) {
+    trav_set_ray(tr, wray, stack);
+    trav_init(tr, sc);
+    trav_reject_unwalkable(tr, wray);
 }
 
 // Take the next pending subtree off the stack (leaving an instance when its sentinel comes up).
@@ -905,10 +938,6 @@ RT_HD void pair_swap(uint32_t& ka, int32_t& ca, uint32_t& kb, int32_t& cb) { // 
     ka = k0; kb = k1; ca = c0; cb = c1;
 }
 // ---- helpers of the step over QUANTISED records (rt_types.hpp Bvh4QNode; trav_node_step4q below) ----
-template <typename R> RT_HD float slab_inv_of(const SlabRay<R>& sr, int a) {
-    if constexpr (sizeof(R) == 8) return sr.inv[a];
-    else return a == 0 ? sr.inv.x : (a == 1 ? sr.inv.y : sr.inv.z);
-}
 RT_HD float bits_float(uint32_t u) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __uint_as_float(u);
@@ -1548,17 +1577,30 @@ RT_HD void path_begin(PathState<R>& ps, const CameraRec<R>& cam, const RenderCon
 // reals fewer alive across the BVH walk (six registers in the f64 kernels) and out of the decoupled kernel's path-state pool.
 // path_shade(): the part after the BVH walk (media, hit record, emitted/scatter, bookkeeping).
 // Returns true while the path is alive.
+// A path's value is a ROUNDED product: the kernels add it to their job's sum in code of their own (trace_kernels.hpp), and under -ffp-contract=fast
+// the compiler would fuse `sum + throughput * emitted` into one fma in one kernel form and not in another — the forms' images would differ in the
+// last place (tests/test_gpu_parity.py::test_kernel_forms_agree holds them bit-identical).  The empty asm makes the product a value of its own.
+template <typename R> RT_HD void keep_rounded(V3<R>& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z));
+#else
+    (void)v;
+#endif
+}
 template <typename R, typename Cnt>
 RT_HD bool path_shade(PathState<R>& ps, const SceneView<R>& sc, const RenderConsts& rc, V3<R> background, R t_min, bool found,
                       R closest, HitRef best, Cnt& cnt) {
     HitRecord<R> rec;
     if (!world_hit_finish(sc, ps.ray, t_min, ps.key, ps.bounce, rc.quirks, found, closest, best, rec, cnt)) {
         ps.radiance = ps.throughput * background;
+        if (closest != closest) ps.radiance = V3<R>(closest, closest, closest); // a ray that was not walked (trav_begin): a NaN path, like the reference's
+        keep_rounded(ps.radiance);
         return false;
     }
     V3<R> att, emitted;
     bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, emitted, cnt);
     ps.radiance = ps.throughput * emitted;
+    keep_rounded(ps.radiance);
     if (!cont) return false;
     ps.throughput = ps.throughput * att;
     ps.bounce += 1;

@@ -32,7 +32,7 @@ struct rttnw_scene {
     std::unique_ptr<rt::FlatScene> flat_ref;
     bool committed = false;
     uint32_t n_media = 0;
-    uint32_t bvh_builder = 0;      // RTTNW_BVH_*
+    uint32_t bvh_builder = 3;      // RTTNW_BVH_* (RTTNW_BVH_AUTO)
     double lower_ms = 0;           // host wall time of rttnw_scene_commit's lowering (BVH builds included)
     double build_kernel_ms = 0;    // device time of the BVH build kernels (device builder only)
     rt::DeviceState* device = nullptr;              // state on the device that was current at commit

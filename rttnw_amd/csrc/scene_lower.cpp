@@ -504,7 +504,7 @@ struct Lowering {
             box_out = Box3();
             return int32_t(fs.nodes.size() - 1);
         }
-        if (builder && items.size() >= 2) {
+        if (builder && items.size() >= std::max<size_t>(2, builder->min_leaves)) {
             // external builder (device LBVH): every item is a one-record leaf; records are emitted in item order
             RecVec<BuildPrim> prims(items.size()); // (not initialised: every leaf is written below)
             std::vector<uint32_t> idx;
@@ -1010,7 +1010,9 @@ static bool fits_lds_form(const FlatScene& f) {
     return lds_form_bytes(f.total_nodes4(), f.stack_depth, 1024) <= 160 * 1024;
 }
 int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const DeviceBvhApi* builder, double time0, double time1, int world_spheres) {
-    const bool small = g.objs.size() <= 8192 && builder == nullptr;
+    // (small scenes: the finest leaf size whose tree still fits the LDS form, below — host-built trees only, i.e. no device builder or RTTNW_BVH_AUTO's,
+    // which leaves every tree of such a scene to the host)
+    const bool small = g.objs.size() <= 8192 && (builder == nullptr || builder->min_leaves > 8192);
     const char* forced = getenv("RTTNW_MAX_LEAF"); // experiments: force the leaf size of the host SAH build (1, 2 or 4)
     for (size_t max_leaf : {size_t(1), size_t(2), size_t(4)}) {
         if (forced && *forced && size_t(atoi(forced)) != max_leaf && max_leaf != 4) continue;

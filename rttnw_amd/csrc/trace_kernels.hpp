@@ -34,6 +34,13 @@
 #define RT_WAVE_STEPS 5 // node steps per trip of the decoupled kernel's bursts (2 / 3 / 4 / 6: 302 / 321 / 325 / 330 Msamples/s in round 1; round 4's end, spheres_1m
                         // f64 / strict / f32 with 4 / 5 / 6: 334 / 340 / 332, 331 / 332 / 331, 481 / 481 / 476; 8: f32 442)
 #endif
+#ifndef RT_ASYNC_SHADE
+#define RT_ASYNC_SHADE 1 // the lane-owns-path kernel leaves its walk loop for a shade phase once at most RT_ASYNC_SLACK walks are unfinished; those are
+                         // SUSPENDED — their lanes skip the phase and walk on in the next one (0: every round waits for its longest walk, rounds 1-4)
+#endif
+#ifndef RT_ASYNC_SLACK
+#define RT_ASYNC_SLACK 8
+#endif
 #ifndef RT_F64_BLOCK
 #define RT_F64_BLOCK 1024 // threads per block of the LDS-resident f64 kernel (4 waves/SIMD at 128 VGPRs; see the Makefile's f64 flags and profiles/r03/README.md)
 #endif
@@ -156,16 +163,29 @@ constexpr uint32_t QCAP = 128;           // capacity of a wave's ray queue and h
 enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_AX, PR_AY, PR_AZ, PR_COUNT };
 enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
 // bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
-// LDS stack entries of the decoupled kernel: 16 for f32; 12 for f64, whose queues are twice as wide — with 16 a 256-thread
-// block needs 58 368 B and only TWO fit in a CU's 160 KB, i.e. 2 waves/SIMD however few registers the kernel is held to;
-// with 12 it is 54 272 B and three fit (the spill strip in global memory takes the rare deeper entries).
+// LDS stack entries of the decoupled kernel: 16 for f32; 13 for f64, whose queues are twice as wide: THREE 256-thread blocks must fit a CU's 160 KB,
+// or the kernel runs at 2 waves per SIMD however few registers it is held to.  gfx950 hands LDS out in granules of 1280 BYTES (128 to a CU): a block
+// of 42 granules (53 760 B) fits three times, one of 54 016 B does not — measured in round 5 (profiles/r05/README.md: 445 against 344 Msamples/s
+// on spheres_1m; hipOccupancyMaxActiveBlocksPerMultiprocessor says 3 for both).  Rounds 1-4 asked for 54 272 B with 12 entries — the runtime's
+// answer was 3, SQ_WAVE_CYCLES said 2 of 3 waves were ever resident — so the f64 decoupled kernels ran a third short of their waves: the ray slot
+// queue as bytes (slots are < 128) and 13 entries make it 53 760 B exactly (the spill strip in global memory takes the rare deeper entries).
 #ifndef RT_F64_WAVE_STACK
-#define RT_F64_WAVE_STACK 12
+#define RT_F64_WAVE_STACK 13
+#endif
+#ifndef RT_WAVE_LDS_PAD
+#define RT_WAVE_LDS_PAD 0 // experiments: unused bytes per wave (where the LDS stops holding three blocks per CU)
 #endif
 template <typename R> __host__ __device__ constexpr uint32_t wave_stack_entries() { return sizeof(R) == 8 ? uint32_t(RT_F64_WAVE_STACK) : LDS_STACK_ENTRIES; }
 template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
-    return 8u * QCAP * uint32_t(sizeof(R)) + 4u * QCAP * 4u + (wave_stack_entries<R>() + 1u) * 64u * 4u; // stack: + the spare slot
+    // ray queue (7 reals) + hit t | hit prim, inst, meta (words) | ray slot (bytes) | stack: + the spare slot
+    return 8u * QCAP * uint32_t(sizeof(R)) + 3u * QCAP * 4u + QCAP + (wave_stack_entries<R>() + 1u) * 64u * 4u + RT_WAVE_LDS_PAD;
 }
+constexpr uint32_t LDS_GRANULE_BYTES = 1280u, LDS_BYTES_PER_CU = 160u * 1024u; // gfx950: 128 granules per CU
+__host__ __device__ constexpr uint32_t lds_blocks_per_cu(uint32_t block_bytes) {
+    return block_bytes == 0u ? 1024u : LDS_BYTES_PER_CU / ((block_bytes + LDS_GRANULE_BYTES - 1u) / LDS_GRANULE_BYTES * LDS_GRANULE_BYTES);
+}
+static_assert(RT_WAVE_LDS_PAD != 0 || lds_blocks_per_cu(wave_lds_bytes<double>(0) * 4u) >= 3u, "the f64 decoupled kernel's block must fit a CU's LDS three times");
+static_assert(lds_blocks_per_cu(wave_lds_bytes<float>(0) * 4u) >= 3u, "the f32 decoupled kernel's block must fit a CU's LDS three times");
 template <typename R> __host__ __device__ constexpr bool wave_walks_quantised() { return RT_WAVE_QUANT == 2 || (RT_WAVE_QUANT == 1 && sizeof(R) == 8); }
 constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
 
@@ -215,12 +235,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
     unsigned char* wbase = lds_raw + wave_in_block * wave_lds_bytes<R>(rc.stack_depth);
     R* const rq_f = reinterpret_cast<R*>(wbase);            // ray queue [7][QCAP]: o.xyz, d.xyz, time
     R* const hq_t = rq_f + 7u * QCAP;                       // hit queue: t
-    uint32_t* const rq_slot = reinterpret_cast<uint32_t*>(hq_t + QCAP);
-    int32_t* const hq_prim = reinterpret_cast<int32_t*>(rq_slot + QCAP);
+    int32_t* const hq_prim = reinterpret_cast<int32_t*>(hq_t + QCAP);
     int32_t* const hq_inst = hq_prim + QCAP;
     uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
+    uint8_t* const rq_slot = reinterpret_cast<uint8_t*>(hq_meta + QCAP); // (slots are 0 .. 127: a byte each)
     typename std::conditional<wave_walks_quantised<R>(), LdsStackQuant4<64, wave_stack_entries<R>()>, LdsStack<64, wave_stack_entries<R>()>>::type stack;
-    stack.base = (LdsIntPtr)(reinterpret_cast<int32_t*>(hq_meta + QCAP) + lane);
+    stack.base = (LdsIntPtr)(reinterpret_cast<int32_t*>(rq_slot + QCAP) + lane);
     stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x));
     stack.spill_stride = gridDim.x * TRACE_BLOCK;
 
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                 rq_f[0u * QCAP + idx] = ps.ray.o.x; rq_f[1u * QCAP + idx] = ps.ray.o.y; rq_f[2u * QCAP + idx] = ps.ray.o.z;
                 rq_f[3u * QCAP + idx] = ps.ray.d.x; rq_f[4u * QCAP + idx] = ps.ray.d.y; rq_f[5u * QCAP + idx] = ps.ray.d.z;
                 rq_f[6u * QCAP + idx] = ps.ray.time;
-                rq_slot[idx] = hslot;
+                rq_slot[idx] = uint8_t(hslot);
             }
             ray_n += uint32_t(__popcll(em));
             continue;
@@ -500,6 +520,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
     uint32_t px = 0, row = 0, s = 0, s_end = 0;
     V3<R> acc;
     PathState<R> ps;
+    bool walking = false; // RT_ASYNC_SHADE: the lane has a walk in progress (begun, or suspended by a shade phase)
+    Trav<R> tr;
 
     // counting variant only: where a wave's time and lanes go (RTTNW_DEBUG_SCHED prints it) — wave clock per phase
     // [0..3], lockstep iterations of the BVH walk [4] (with a node lane [7], with a leaf lane [8]) against the lane
@@ -534,7 +556,46 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
         if (__ballot(!done) == 0ull) break;
 
         // ---- one path per lane: regenerate or advance by one bounce
-        if constexpr (!COUNT) {
+        if constexpr (!COUNT && RT_ASYNC_SHADE != 0) {
+            // ASYNCHRONOUS SHADE PHASES (round 5).  Rounds 1-4 ran `path_step` here: every lane's whole walk, then the shade — a round lasted as long as
+            // its LONGEST walk (final_scene: 9.5 trips where the mean walk has 4.2; a node step served 20 of 64 lanes).  Now the walk loop is left once
+            // at most RT_ASYNC_SLACK walks are unfinished: the finished lanes shade, regenerate and start their next walk, the unfinished ones keep
+            // their cursor (closest hit, node, stack) and walk on beside them.  Host model of the wave (tests/hostsim policy 4, exp/wave_async.py):
+            // node-step executions -31 %, leaf-step executions -17 %, shade phases +9 %.  A lane's own sequence of steps is untouched: same image.
+            const bool fresh_path = !done && !walking && !alive && s < s_end;
+            if (fresh_path) {
+                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, px, row, s);
+                alive = true;
+            }
+            const bool fresh_walk = !done && !walking && alive;
+            if (fresh_walk) { cnt.ray(); trav_init(tr, sc); walking = true; }
+            // (the slab constants of a suspended walk are made again, in the instruction stream the fresh walks need anyway — for EVERY lane, so that
+            // the compiler sees them dead across the shade phase: nothing but the cursor lives through it.  A walk suspended inside an instance's
+            // tree keeps its own ray, and its constants with it.)
+            if constexpr (CounterSel<COUNT, GENERAL>::type::NO_INST) trav_set_ray(tr, ps.ray, stack);
+            else if (fresh_walk) trav_set_ray(tr, ps.ray, stack);
+            if (fresh_walk) trav_reject_unwalkable(tr, ps.ray);
+            for (;;) { // trips (rt_core.hpp closest_solid's loop body) until few enough walks are unfinished
+                const bool unfinished = walking && tr.node != TRAV_DONE;
+                if (unfinished) {
+#pragma unroll
+                    for (int k = 0; k < NSTEPS; ++k)
+                        if (tr.node >= 0) trav_node_step(tr, sc, ps.ray, t_min, stack, cnt);
+                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, ps.ray, t_min, stack, cnt);
+                }
+                const unsigned long long um = __ballot(walking && tr.node != TRAV_DONE);
+                if (um == 0ull) break;
+                if (uint32_t(__popcll(um)) <= uint32_t(RT_ASYNC_SLACK) && __ballot(walking && tr.node == TRAV_DONE) != 0ull) break;
+            }
+            if (walking && tr.node == TRAV_DONE) {
+                walking = false;
+                alive = path_shade(ps, sc, rc, background, t_min, tr.found, tr.closest, tr.best, cnt);
+                if (!alive) { // main.rs:216: acc + color(...)
+                    acc = acc + ps.radiance;
+                    ++s;
+                }
+            }
+        } else if constexpr (!COUNT) {
             if (!done) {
                 if (!alive && s < s_end) {
                     path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, px, row, s);

@@ -29,7 +29,7 @@ def product():
         lib = C.CDLL(HIP_LIB)
         b = abi.Binding(lib, "rttnw_", abi.BUILDER_FUNCS)
         b.add(abi.PRODUCT_FUNCS)
-        if b.abi_version() != 2:
+        if b.abi_version() != abi.ABI_VERSION:
             raise RuntimeError("rttnw_amd: ABI version mismatch")
         _product = b
     return _product

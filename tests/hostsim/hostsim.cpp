@@ -317,6 +317,61 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
     };
     NoCounters cnt;
     std::vector<Lane> L(64);
+    if (policy == 4) {
+        // ASYNCHRONOUS SHADE (round 5): a lane whose walk is finished WAITS; the wave runs its shade phase (path_shade for the waiting lanes, then job
+        // hand-out + path begin for those whose path ended, then trav_begin) only once `b` lanes wait or no lane walks — the others keep walking through
+        // it.  Between shade phases: the kernel's trips of `a` node steps + a leaf step.  out[0] counts SHADE PHASES, out[33] the lanes they served,
+        // out[34] shade phases that began paths.
+        std::vector<uint8_t> walking(64);
+        for (uint32_t w = 0; w < n_waves; ++w) {
+            uint64_t next = uint64_t(w) * (rc.n_jobs / n_waves) / 64 * 64, end = next + jobs_per_wave;
+            for (auto& l : L) { l.alive = false; l.done = false; l.s = l.s_end = 0; }
+            std::fill(walking.begin(), walking.end(), uint8_t(0));
+            for (;;) {
+                uint32_t n_walk = 0, n_wait = 0;
+                for (uint32_t i = 0; i < 64; ++i) {
+                    if (L[i].done) continue;
+                    if (walking[i] && L[i].tr.node == TRAV_DONE) walking[i] = 0; // its walk is over: waits for the shade phase
+                    if (walking[i]) ++n_walk; else ++n_wait;
+                }
+                if (n_walk + n_wait == 0) break;
+                if (n_walk == 0 || n_wait >= uint32_t(b)) {
+                    bool began = false;
+                    uint32_t served = 0;
+                    for (uint32_t i = 0; i < 64; ++i) {
+                        Lane& l = L[i];
+                        if (l.done || walking[i]) continue;
+                        ++served;
+                        if (l.alive) {
+                            l.alive = path_shade(l.ps, hs.view, rc, background, t_min, l.tr.found, l.tr.closest, l.tr.best, cnt);
+                            if (!l.alive) { ++l.s; out[5]++; }
+                        }
+                        while (!l.alive && l.s >= l.s_end) {
+                            if (next >= end || next >= rc.n_jobs) { l.done = true; break; }
+                            const JobInfo ji = job_decode(rc, uint32_t(next++));
+                            l.px = ji.px; l.row = ji.row; l.s = ji.s; l.s_end = ji.s_end;
+                        }
+                        if (l.done) continue;
+                        if (!l.alive) { path_begin(l.ps, camr, rc, l.px, l.row, l.s); l.alive = true; began = true; }
+                        trav_begin(l.tr, hs.view, l.ps.ray, l.stack);
+                        walking[i] = 1;
+                        out[32]++;
+                    }
+                    out[0]++; out[33] += served; out[34] += began;
+                    continue;
+                }
+                for (int k = 0; k < a; ++k) {
+                    uint32_t n = 0;
+                    for (uint32_t i = 0; i < 64; ++i) if (!L[i].done && walking[i] && L[i].tr.node >= 0) { trav_node_step(L[i].tr, hs.view, L[i].ps.ray, t_min, L[i].stack, cnt); ++n; }
+                    if (n) { out[1]++; out[2] += n; }
+                }
+                uint32_t n = 0;
+                for (uint32_t i = 0; i < 64; ++i) if (!L[i].done && walking[i] && L[i].tr.node < 0 && L[i].tr.node != TRAV_DONE) { trav_leaf_step(L[i].tr, hs.view, L[i].ps.ray, t_min, L[i].stack, cnt); ++n; }
+                if (n) { out[3]++; out[4] += n; }
+            }
+        }
+        return;
+    }
     for (uint32_t w = 0; w < n_waves; ++w) {
         uint64_t next = uint64_t(w) * (rc.n_jobs / n_waves) / 64 * 64, end = next + jobs_per_wave;
         for (auto& l : L) { l.alive = false; l.done = false; l.s = l.s_end = 0; }

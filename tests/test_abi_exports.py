@@ -35,7 +35,7 @@ def test_scenes_library_exports():
 
 def test_builder_table_matches_direct_symbols():
     b = library.product()
-    assert b.abi_version() == 2
+    assert b.abi_version() == abi.ABI_VERSION == 3
     table = C.cast(b.builder(), C.POINTER(C.c_void_p * len(abi.BUILDER_FUNCS))).contents
     for i, (name, _, _) in enumerate(abi.BUILDER_FUNCS):
         direct = C.cast(getattr(b.lib, "rttnw_" + name), C.c_void_p).value

@@ -37,12 +37,13 @@ def product_probe(fn, binding, sc, cam, p, px, row, sample, max_out=64):
     return out[:n * PROBE_STRIDE].reshape(n, PROBE_STRIDE)
 
 
-def compare_paths(probe, oracle_probe, pairs, tol=1e-9):
+def compare_paths(probe, oracle_probe, pairs, tol=1e-9, growth=1.0):
     """Every bounce of every (px, row, sample): t, p, normal, front_face equal within `tol` (relative to the magnitude of
-    the coordinate) for the first three bounces and within tol x 8^(k - 2) at bounce k > 2, capped at 1e-4 (a last-place difference
-    — the world-space test of a transformed group's spheres, a fused multiply-add — is a different ray after the bounce: it grows by
-    ~(1 + distance / radius) per bounce off a small sphere, x10 in final_scene's cluster; the DECISIONS — front face, material,
-    scattered or absorbed, bounce count — stay exact at every depth), the same material at every hit (the oracle reports graph ids, the product flat indices: the
+    the coordinate) AT EVERY DEPTH.  `growth` > 1 — only for the contracted build on the scenes whose small spheres amplify a last-place
+    difference (the world-space test of a transformed group's spheres, a fused multiply-add: a different ray after the bounce, growing by
+    ~(1 + distance / radius) per bounce, x10 in final_scene's cluster) — loosens the bound to tol x growth^(k - 2) at bounce k > 2, capped
+    at 1e-4; RTTNW_F64_STRICT probes are held to 1e-12 flat (tests/test_gpu_parity.py).  The DECISIONS — front face, material,
+    scattered or absorbed, bounce count — are exact at every depth; the same material at every hit (the oracle reports graph ids, the product flat indices: the
     mapping must be one-to-one and order preserving), (u, v) equal wherever the product computes them (it skips them
     when no texture reads them).  Returns (paths, bounces compared, material map)."""
     mat_map, bounces = {}, 0
@@ -52,7 +53,7 @@ def compare_paths(probe, oracle_probe, pairs, tol=1e-9):
         assert len(a) == len(b), ("bounce count", px, row, s, len(a), len(b))
         for k in range(len(a)):
             scale = max(1.0, np.abs(b[k, 0:4]).max())
-            tol_k = min(1e-4, tol * 8.0 ** max(0, k - 2))
+            tol_k = min(max(tol, 1e-4), tol * growth ** max(0, k - 2))
             assert np.abs(a[k, 0:7] - b[k, 0:7]).max() <= tol_k * scale, ("t/p/normal", px, row, s, k, a[k, 0:7], b[k, 0:7])
             assert a[k, 10] == b[k, 10], ("front_face", px, row, s, k)
             if a[k, 8] != 0.0 or a[k, 9] != 0.0:

@@ -126,7 +126,8 @@ def main():
     ap.add_argument("--no-sub", action="store_true", help="skip the cornell_box / spheres_1m sub-records of the default run")
     ap.add_argument("--sub-steps", type=int, default=3, help="timed steps of each sub-record (after one warm-up step)")
     ap.add_argument("--spp-chunk", type=int, default=0, help="samples per work item (0 = the library's tapered schedule)")
-    ap.add_argument("--bvh", default="sah", choices=["sah", "lbvh", "dsah"], help="BVH builder at commit: host binned SAH (default), device LBVH, device binned SAH")
+    ap.add_argument("--bvh", default="auto", choices=["auto", "sah", "lbvh", "dsah"],
+                    help="BVH builder at commit: auto (the library's default: host binned SAH below 100 000 leaves per tree, device binned SAH from there), host binned SAH, device LBVH, device binned SAH")
     ap.add_argument("--dump-image", default=None, metavar="PATH.npz", help="rank 0 saves the last timed step's frame (linear, rgba8): tests compare it with a single-rank render")
     ap.add_argument("--share", default=None, metavar="R/W",
                     help="trace ONE rank's share (rank R of a W-way partition) of the N = W workload on this GPU, no gather: "
@@ -194,7 +195,7 @@ def main():
             self.spp = self.spp1 * world  # weak scaling: fixed per-GPU work
             t0 = time.time()
             self.sc, self.setup = S.build(gpu, scenes, self.scene_name, earth, self.param,
-                                          bvh={"lbvh": abi.BVH_DEVICE_LBVH, "dsah": abi.BVH_DEVICE_SAH}.get(args.bvh))
+                                          bvh={"sah": abi.BVH_HOST_SAH, "lbvh": abi.BVH_DEVICE_LBVH, "dsah": abi.BVH_DEVICE_SAH}.get(args.bvh))
             self.build_s = time.time() - t0
             self.binfo = self.sc.build_info()
             self.info = abi.Stats()
@@ -205,7 +206,7 @@ def main():
                 self.samples_total = self.samples_rank                       # --share: this rank's rate
             # (the committed PMC summaries are of the default configuration: whole frame on one GPU, host SAH trees, default schedule)
             self.default_run = (world == 1 and share is None and not spp_override and not size_override and not args.spp_chunk
-                                and args.bvh == "sah")
+                                and args.bvh == "auto")
 
         def counted(self, prec):
             """Counted rays / node visits / primitive tests / texels per sample (counted, not modelled), by the
@@ -244,8 +245,14 @@ def main():
             elapsed = time.perf_counter() - t0
             ms_per_step = elapsed * 1e3 / max(1, steps)
             kernel_ms = float(np.mean(kms)) if kms else 0.0
+            self.rank_kernel_ms = None
             if use_dist:
                 t = torch.tensor([ms_per_step, kernel_ms], dtype=torch.float64, device="cpu" if one_device else "cuda")
+                # every rank's own kernel time, for the spread (an imbalance of the tile partition would show here, not in the maximum)
+                each = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+                dist.all_gather(each, t)
+                ks = [float(e[1]) for e in each]
+                self.rank_kernel_ms = {"min": round(min(ks), 3), "mean": round(sum(ks) / len(ks), 3), "max": round(max(ks), 3)}
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 ms_per_step, kernel_ms = float(t[0]), float(t[1])
             if args.dump_image and rank == 0 and share is None:
@@ -362,8 +369,32 @@ def main():
     wl = Workload(workload, args.spp, args.size)
     precision = {"f32": abi.F32, "f64": abi.F64, "f64strict": abi.F64_STRICT}[args.precision]
 
+    # ---- N > 1: what ONE GPU does with the same frame at the per-GPU sample count — rank 0 alone traces the whole 1600x1600 frame at
+    # spp = 1250 (one step after one warm-up; the other ranks wait at the barrier), so that the line carries its own single-GPU reference on
+    # the same frame (the N = 1 bench line is the 800x800 headline frame: ~1.7 % apart per GPU) and the efficiency read off it is not inflated
+    per_gpu_reference = None
+    if use_dist and world > 1:
+        assert dist.get_world_size() == world == args.gpus, "bench: %d ranks joined, WORLD_SIZE %d, --gpus %d" % (dist.get_world_size(), world, args.gpus)
+        if rank == 0:
+            cam1, p1 = S.params_for(wl.setup, wl.W, wl.H, wl.spp1, precision=precision, tile_rank=0, tile_world=1, seed=1, spp_chunk=args.spp_chunk)
+            r1 = render.DeviceRenderer(wl.sc, cam1, p1)
+            r1.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            st1 = abi.Stats()
+            r1.trace(st1)
+            r1.collect()
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t1) * 1e3
+            per_gpu_reference = {"workload": "%s %dx%d spp=%d on ONE GPU (rank 0 alone, 1 step)" % (wl.scene_name, wl.W, wl.H, wl.spp1),
+                                 "value": round(float(wl.W) * wl.H * wl.spp1 / (ms1 * 1e-3) / 1e6, 3), "unit": "Msamples/s",
+                                 "ms_per_step": round(ms1, 3), "kernel_ms": round(st1.kernel_ms, 3)}
+            del r1
+        dist.barrier()
+
     # ---- timed region (the reported precision)
     ms_per_step, kernel_ms = wl.timed(precision, args.steps, args.warmup)
+    rank_kernel_ms = wl.rank_kernel_ms
     value = wl.samples_total / (ms_per_step * 1e-3) / 1e6
     roof = wl.roofline(precision, kernel_ms)
 
@@ -448,6 +479,13 @@ def main():
         }
         if strict is not None:
             out["f64strict_kernels"] = strict
+        if use_dist:
+            out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_expected": args.gpus,
+                                  "rank_kernel_ms": rank_kernel_ms}
+        if per_gpu_reference is not None:
+            # (the driver computes its own efficiency from the N = 1, 2, 4, 8 lines; this one is against the SAME frame on one GPU of this run)
+            per_gpu_reference["scaling_efficiency"] = round(value / (world * per_gpu_reference["value"]), 4)
+            out["per_gpu_reference"] = per_gpu_reference
         out.update(subs)
         print(json.dumps(out), flush=True)
     if use_dist:

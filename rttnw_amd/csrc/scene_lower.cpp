@@ -167,6 +167,7 @@ struct Lowering {
     int rc = 0;
     const DeviceBvhApi* builder = nullptr; // the device builder, or null: host binned SAH
     size_t max_leaf = 4; // records per leaf of the host SAH build (lower_scene picks it)
+    double leaf_cost = 1.0; // what testing a leaf's record costs in node fetches (RTTNW_SAH_LEAF_COST, experiments: < 1 folds more leaves)
     double time0 = 0.0, time1 = 1.0; // shutter interval the moving spheres' boxes must cover
 
     Lowering(const SceneGraph& graph, FlatScene& flat, std::string& error, const DeviceBvhApi* bvh_builder, size_t leaf_records, double t0, double t1)
@@ -408,7 +409,7 @@ struct Lowering {
         if (can_leaf) {
             // SAH: leaf cost n * A vs. split cost A (one node fetch) + children
             double a = box.area();
-            if (best_axis < 0 || !(best_cost + a < double(n) * a)) return make_leaf_here();
+            if (best_axis < 0 || !(best_cost + a < double(n) * a * leaf_cost)) return make_leaf_here();
         }
         size_t mid;
         if (best_axis >= 0) {
@@ -932,6 +933,7 @@ struct Lowering {
         const auto t_start = now();
         lower_textures_materials();
         const auto t_mats = now();
+        if (const char* e = getenv("RTTNW_SAH_LEAF_COST")) { const double v = std::atof(e); if (v > 0) leaf_cost = v; }
         if (world_spheres_arg >= 0) { move_spheres = world_spheres_arg != 0; test_in_group_frame = world_spheres_arg == 2; }
         else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) { move_spheres = std::atoi(e) != 0; test_in_group_frame = std::atoi(e) == 2; }
         ItemVec top;

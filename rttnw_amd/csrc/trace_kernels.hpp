@@ -38,8 +38,14 @@
 #define RT_ASYNC_SHADE 1 // the lane-owns-path kernel leaves its walk loop for a shade phase once at most RT_ASYNC_SLACK walks are unfinished; those are
                          // SUSPENDED — their lanes skip the phase and walk on in the next one (0: every round waits for its longest walk, rounds 1-4)
 #endif
+#ifndef RT_ASYNC_WHOLE_LEAF
+#define RT_ASYNC_WHOLE_LEAF 0 // 1: a leaf step tests all (<= 4) records of the leaf instead of one
+#endif
 #ifndef RT_ASYNC_SLACK
 #define RT_ASYNC_SLACK 8
+#endif
+#ifndef RT_WAVE_WHOLE_LEAF
+#define RT_WAVE_WHOLE_LEAF 0 // decoupled kernels: a leaf step tests all (<= 4) records of the leaf instead of one
 #endif
 #ifndef RT_F64_BLOCK
 #define RT_F64_BLOCK 1024 // threads per block of the LDS-resident f64 kernel (4 waves/SIMD at 128 VGPRs; see the Makefile's f64 flags and profiles/r03/README.md)
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 #pragma unroll
                     for (int k = 0; k < RT_WAVE_STEPS; ++k)
                         if (tr.node >= 0) trav_node_step(tr, sc, wray, t_min, stack, cnt);
-                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, wray, t_min, stack, cnt);
+                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step<RT_WAVE_WHOLE_LEAF != 0>(tr, sc, wray, t_min, stack, cnt);
                 }
                 if (uint32_t(__popcll(__ballot(has_ray && tr.node == TRAV_DONE))) >= retire_batch) break;
             }
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
 #pragma unroll
                     for (int k = 0; k < NSTEPS; ++k)
                         if (tr.node >= 0) trav_node_step(tr, sc, ps.ray, t_min, stack, cnt);
-                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step(tr, sc, ps.ray, t_min, stack, cnt);
+                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step<RT_ASYNC_WHOLE_LEAF != 0>(tr, sc, ps.ray, t_min, stack, cnt);
                 }
                 const unsigned long long um = __ballot(walking && tr.node != TRAV_DONE);
                 if (um == 0ull) break;

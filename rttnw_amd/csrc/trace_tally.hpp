@@ -90,11 +90,14 @@ __device__ __forceinline__ void plain_round_tallied(bool done, bool& alive, uint
         tk3b = clock64();
         if (!hit) {
             ps.radiance = ps.throughput * background;
+            if (closest != closest) ps.radiance = V3<R>(closest, closest, closest); // (as path_shade: a ray that was not walked)
+            keep_rounded(ps.radiance);
             alive = false;
         } else {
             V3<R> att, emitted;
             const bool cont = shade(sc, rec, ps.key, ps.bounce, ps.ray, att, emitted, cnt);
             ps.radiance = ps.throughput * emitted;
+            keep_rounded(ps.radiance); // (as path_shade: the path's value is a rounded product in every kernel form)
             if (cont) { ps.throughput = ps.throughput * att; ps.bounce += 1; }
             alive = cont && ps.bounce < rc.max_depth;
         }

@@ -812,9 +812,71 @@ def test_bench_n_ranks_rehearsed_on_one_gpu(gpu, scenes_lib, earth, tmp_path, wo
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["steps"] == 1 and d["unit"] == "Msamples/s"
     assert d["config"]["workload"].startswith("final_scene 1600x1600 spp=%d " % (3 * world)), d["config"]["workload"]
     assert abs(d["value"] - 1600 * 1600 * 3 * world / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-3 * d["value"]
+    # the line names the ranks that really joined, every rank's kernel time, and its own single-GPU reference on the SAME frame (round 5)
+    assert d["distributed"]["world_size"] == world == d["distributed"]["ranks_expected"] and d["distributed"]["backend"] == "gloo"
+    rk = d["distributed"]["rank_kernel_ms"]
+    assert 0 < rk["min"] <= rk["mean"] <= rk["max"] == pytest.approx(d["roofline"]["kernel_ms"], rel=1e-6)
+    ref = d["per_gpu_reference"]
+    assert ref["workload"].startswith("final_scene 1600x1600 spp=3 ") and ref["value"] > 0
+    assert ref["scaling_efficiency"] == pytest.approx(d["value"] / (world * ref["value"]), rel=1e-3)
     sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)
     cam, p = util.params_for(setup, 1600, 1600, 3 * world, precision=abi.F64, seed=1)
     lin, rgba, _ = gpu_render(gpu, sc, cam, p)
     got = np.load(dump)
     assert np.array_equal(got["linear"], lin) and np.array_equal(got["rgba8"], rgba)
 
+
+
+def test_config1_cornell_200_spp50_whole_frame(gpu, oracle, scenes_lib):
+    """BASELINE configs[0] at its literal size — cornell_box 200x200 spp 50 (scenes.rs:157-196; main.rs:137-150: its camera at aspect 1) — the ONE
+    configuration small enough for the oracle to render WHOLE (2 Msamples): every pixel of the frame held to the CPU restatement, not crops.
+    RTTNW_F64_STRICT: every pixel within 1e-12, RGBA8 identical, the same number of world.hit() calls.  The contracted f64 kernels: T1 (1e-9 on
+    >= 99.9 % of the pixels, RGBA8 likewise).  The f32 kernels: T2 (every pixel within 6 sigma / sqrt(spp) + 1/256 of the oracle's, the frame's
+    mean within 0.5 %)."""
+    sg, setup = util.build(gpu, scenes_lib, "cornell_box")
+    so, _ = util.build(oracle, scenes_lib, "cornell_box")
+    cam, p = util.params_for(setup, 200, 200, 50, precision=abi.F64_STRICT, collect_counters=1)
+    lo, ro, st_o = rto.render(so, cam, p)
+    assert lo.shape == (200, 200, 3) and st_o.samples == 200 * 200 * 50
+    lin, rgba, st = gpu_render(gpu, sg, cam, p)
+    assert st.samples == st_o.samples and st.rays == st_o.rays
+    assert np.abs(lin - lo).max() <= 1e-12 * max(1.0, lo.max()), np.abs(lin - lo).max()
+    assert np.array_equal(rgba, ro)
+    p.collect_counters = 0
+    lin_t, rgba_t, _ = gpu_render(gpu, sg, cam, p)                     # the timed instantiation: the same frame bit for bit
+    assert np.array_equal(lin_t, lin) and np.array_equal(rgba_t, rgba)
+    p.precision = abi.F64
+    lin64, rgba64, _ = gpu_render(gpu, sg, cam, p)
+    d = np.abs(lin64 - lo).max(axis=2)
+    assert (d <= T1_ABS).mean() >= 0.999 and (rgba64 == ro).all(axis=2).mean() >= 0.999, (d.max(), (d > T1_ABS).sum())
+    p.precision = abi.F32
+    lin32, rgba32, _ = gpu_render(gpu, sg, cam, p)
+    # per-pixel spread of a 50-sample mean: from the oracle frame's own neighbourhood statistics it is <= ~0.9 per channel on this scene
+    # (light 15, albedo <= 0.73); f32 and f64 share every draw's leading 24 bits, so they differ by branch flips only: far inside the bound
+    assert np.abs(lin32 - lo).max() <= 6.0 * 1.0 / np.sqrt(50) + 1.0 / 256, np.abs(lin32 - lo).max()
+    assert abs(lin32.mean() - lo.mean()) <= 5e-3 * lo.mean()
+    assert (np.abs(rgba32.astype(int) - ro.astype(int)) <= 1).all(axis=2).mean() >= 0.99
+
+
+@pytest.mark.parametrize("precision", [abi.F64, abi.F64_STRICT, abi.F32], ids=["f64", "f64strict", "f32"])
+def test_rays_nothing_can_cull_do_not_leave_the_stack(gpu, scenes_lib, earth, precision):
+    """Degenerate cameras (lookfrom == lookat; view_up along the view): every primary ray is NaN, no plane distance is a number, and the inverted
+    box of an unused node slot would 'pass' its slab test — three pushes per node, past the bound the LDS stacks are sized by (the round-4 advisor's
+    finding).  Such a ray is not walked (rt_core.hpp slab_ray_can_be_culled): the render returns, the pixels are what the reference writes for NaN
+    (main.rs:219-225: 0) or black, and the NEXT render of the same scene is still right (nothing was overwritten)."""
+    for name in ("cornell_box", "final_scene"):
+        sc, setup = util.build(gpu, scenes_lib, name, earth)
+        cam_ok, p = util.params_for(setup, 48, 40, 4, precision=precision, seed=3)
+        lin_ok, rgba_ok, _ = gpu_render(gpu, sc, cam_ok, p)
+        for degenerate in ("lookfrom_is_lookat", "view_up_along_the_view"):
+            cam, _ = util.params_for(setup, 48, 40, 4, precision=precision, seed=3)
+            for k in range(3):
+                if degenerate == "lookfrom_is_lookat":
+                    cam.lookat[k] = cam.lookfrom[k]
+                else:
+                    cam.view_up[k] = cam.lookat[k] - cam.lookfrom[k]
+            lin, rgba, st = gpu_render(gpu, sc, cam, p)
+            assert (np.isnan(lin) | (lin == 0)).all(), (name, degenerate)
+            assert (rgba[..., :3] == 0).all() and (rgba[..., 3] == 255).all(), (name, degenerate)
+        lin2, rgba2, _ = gpu_render(gpu, sc, cam_ok, p)
+        assert np.array_equal(lin2, lin_ok) and np.array_equal(rgba2, rgba_ok), name

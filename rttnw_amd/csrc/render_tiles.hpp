@@ -89,7 +89,10 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     // ~24 k 4-wide nodes, f64 at ~50 k.  After round 4 — quantised records, no instance code, 13-real path slots, the f64 unit split — the decoupled kernel
     // takes over much earlier: f32 5.7 k nodes 7158 / 6646, 9.9 k 5272 / 5403, 15.4 k 3917 / 4460, 28.3 k 2273 / 3184; f64 9.9 k 4776 / 4039, 15.4 k
     // 3559 / 3340, 19.6 k 2818 / 2898, 28.3 k 1979 / 2332, 50.9 k 1223 / 1722)
-    bool plain = flat.total_nodes4() < (sizeof(R) == 4 ? 8192u : 16384u);
+    // (round 5 — asynchronous shade phases in the lane-owns-path kernel, the f64 decoupled kernel at three blocks per CU: f32 9.9 k nodes 5441 / 5350,
+    // 15.4 k 4180 / 4483, 19.6 k 3400 / 3911; f64 9.9 k 5168 / 4898, 15.4 k 3960 / 4153, 19.6 k 3166 / 3667; RTTNW_F64_STRICT 15.4 k 4015 / 4110 —
+    // profiles/r05/README.md: both cross at ~13 k records)
+    bool plain = flat.total_nodes4() < 13000u;
     if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     if (!prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));

@@ -1492,6 +1492,9 @@ RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, 
     emitted = V3<R>();
     // albedo / emission texture of the three textured kinds, evaluated in ONE place (Perlin is ~350 instructions)
     V3<R> colour;
+    // (round 5: a noise texture evaluated by the WHOLE wave — lane l the corner l & 7 of octave l >> 3 of one requesting lane's point, sums in the
+    // reference's order, bit-identical — was built and measured: final_scene f64 +0.6 %, strict -2.4 %, cornell_box, which has no noise, -12 % through
+    // the registers the extra code takes in a kernel that spills: profiles/r05/README.md.  Not kept.)
     if (m.type == MAT_DIFFUSE_LIGHT || m.type == MAT_LAMBERTIAN || m.type == MAT_ISOTROPIC) colour = material_color(sc, m, rec, cnt);
     if (m.type == MAT_DIFFUSE_LIGHT) { // material.rs:242-250
         emitted = colour;

@@ -18,6 +18,19 @@
 // No CPU fallback: every entry point needs a HIP device.
 #pragma once
 #include "render_common.hpp"
+#ifndef RT_ASYNC_SHADE
+#define RT_ASYNC_SHADE 1 // the lane-owns-path kernel leaves its walk loop for a shade phase once at most RT_ASYNC_SLACK walks are unfinished; those are
+                         // SUSPENDED — their lanes skip the phase and walk on in the next one (0: every round waits for its longest walk, rounds 1-4)
+#endif
+#ifndef RT_ASYNC_WHOLE_LEAF
+#define RT_ASYNC_WHOLE_LEAF 0 // 1: a leaf step tests all (<= 4) records of the leaf instead of one
+#endif
+#ifndef RT_ASYNC_SLACK
+#define RT_ASYNC_SLACK 8
+#endif
+#ifndef RT_WAVE_WHOLE_LEAF
+#define RT_WAVE_WHOLE_LEAF 0 // decoupled kernels: a leaf step tests all (<= 4) records of the leaf instead of one
+#endif
 #include "trace_tally.hpp"
 
 #ifndef RT_WAVE_QUANT
@@ -33,19 +46,6 @@
 #ifndef RT_WAVE_STEPS
 #define RT_WAVE_STEPS 5 // node steps per trip of the decoupled kernel's bursts (2 / 3 / 4 / 6: 302 / 321 / 325 / 330 Msamples/s in round 1; round 4's end, spheres_1m
                         // f64 / strict / f32 with 4 / 5 / 6: 334 / 340 / 332, 331 / 332 / 331, 481 / 481 / 476; 8: f32 442)
-#endif
-#ifndef RT_ASYNC_SHADE
-#define RT_ASYNC_SHADE 1 // the lane-owns-path kernel leaves its walk loop for a shade phase once at most RT_ASYNC_SLACK walks are unfinished; those are
-                         // SUSPENDED — their lanes skip the phase and walk on in the next one (0: every round waits for its longest walk, rounds 1-4)
-#endif
-#ifndef RT_ASYNC_WHOLE_LEAF
-#define RT_ASYNC_WHOLE_LEAF 0 // 1: a leaf step tests all (<= 4) records of the leaf instead of one
-#endif
-#ifndef RT_ASYNC_SLACK
-#define RT_ASYNC_SLACK 8
-#endif
-#ifndef RT_WAVE_WHOLE_LEAF
-#define RT_WAVE_WHOLE_LEAF 0 // decoupled kernels: a leaf step tests all (<= 4) records of the leaf instead of one
 #endif
 #ifndef RT_F64_BLOCK
 #define RT_F64_BLOCK 1024 // threads per block of the LDS-resident f64 kernel (4 waves/SIMD at 128 VGPRs; see the Makefile's f64 flags and profiles/r03/README.md)
@@ -528,6 +528,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
     PathState<R> ps;
     bool walking = false; // RT_ASYNC_SHADE: the lane has a walk in progress (begun, or suspended by a shade phase)
     Trav<R> tr;
+    uint32_t tally_trips = 0; // (counting variant: trips of the lane's walk so far)
 
     // counting variant only: where a wave's time and lanes go (RTTNW_DEBUG_SCHED prints it) — wave clock per phase
     // [0..3], lockstep iterations of the BVH walk [4] (with a node lane [7], with a leaf lane [8]) against the lane
@@ -587,8 +588,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
 #pragma unroll
                     for (int k = 0; k < NSTEPS; ++k)
                         if (tr.node >= 0) trav_node_step(tr, sc, ps.ray, t_min, stack, cnt);
-                    if (tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step<RT_ASYNC_WHOLE_LEAF != 0>(tr, sc, ps.ray, t_min, stack, cnt);
                 }
+                // (serving the lanes at a leaf by CLASS of record kind — the cube's ~200 instructions run for 2 lanes of 64 on final_scene — only once enough
+                // lanes wait at a class was modelled at -8.8 % instructions and measured at -1.4 % / -4.5 % (f64 / f32): profiles/r05/README.md)
+                if (unfinished && tr.node < 0 && tr.node != TRAV_DONE) trav_leaf_step<RT_ASYNC_WHOLE_LEAF != 0>(tr, sc, ps.ray, t_min, stack, cnt);
                 const unsigned long long um = __ballot(walking && tr.node != TRAV_DONE);
                 if (um == 0ull) break;
                 if (uint32_t(__popcll(um)) <= uint32_t(RT_ASYNC_SLACK) && __ballot(walking && tr.node == TRAV_DONE) != 0ull) break;
@@ -616,7 +619,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
                 }
             }
         } else { // the same steps, with the wave clock read between the phases and the lockstep loop tallied (trace_tally.hpp)
+#if RT_ASYNC_SHADE
+            plain_phase_tallied<NSTEPS>(done, alive, walking, tr, tally_trips, px, row, s, s_end, acc, ps, cam, rc, sc, background, t_min, stack, cnt, prof, counters, lane, tk0);
+#else
             plain_round_tallied(done, alive, px, row, s, s_end, acc, ps, cam, rc, sc, background, t_min, stack, cnt, prof, counters, lane, tk0);
+#endif
         }
     }
 

@@ -317,6 +317,8 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
     };
     NoCounters cnt;
     std::vector<Lane> L(64);
+    const uint32_t leaf_policy = jobs_per_wave >> 28;
+    jobs_per_wave &= 0x0FFFFFFFu;
     if (policy == 4) {
         // ASYNCHRONOUS SHADE (round 5): a lane whose walk is finished WAITS; the wave runs its shade phase (path_shade for the waiting lanes, then job
         // hand-out + path begin for those whose path ended, then trav_begin) only once `b` lanes wait or no lane walks — the others keep walking through
@@ -365,9 +367,45 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
                     for (uint32_t i = 0; i < 64; ++i) if (!L[i].done && walking[i] && L[i].tr.node >= 0) { trav_node_step(L[i].tr, hs.view, L[i].ps.ray, t_min, L[i].stack, cnt); ++n; }
                     if (n) { out[1]++; out[2] += n; }
                 }
-                uint32_t n = 0;
-                for (uint32_t i = 0; i < 64; ++i) if (!L[i].done && walking[i] && L[i].tr.node < 0 && L[i].tr.node != TRAV_DONE) { trav_leaf_step(L[i].tr, hs.view, L[i].ps.ray, t_min, L[i].stack, cnt); ++n; }
-                if (n) { out[3]++; out[4] += n; }
+                // the leaf step.  jobs_per_wave's top bits select a LEAF POLICY (experiments): 0 every lane at a leaf is served (the kernel's); 1 only the
+                // record kind with the most lanes waiting is served (the others wait for a later trip) unless no lane is at a node any more; 2 a kind is
+                // served when >= 8 lanes wait at it, or no lane is at a node, else it waits.  out[6 + set]: leaf steps by the set of kinds they served,
+                // out[40 + k]: lane-steps served of kind k.
+                uint32_t cnt_k[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_node_lanes = 0;
+                for (uint32_t i = 0; i < 64; ++i) {
+                    if (L[i].done || !walking[i]) continue;
+                    const int32_t nd = L[i].tr.node;
+                    if (nd >= 0) ++n_node_lanes;
+                    else if (nd != TRAV_DONE) ++cnt_k[nd == CHILD_EMPTY ? 7u : (leaf_kind(nd) & 7u)];
+                }
+                uint32_t serve = 0xFFu;
+                if (leaf_policy == 1 && n_node_lanes != 0) {
+                    uint32_t best = 0;
+                    for (uint32_t k = 1; k < 8; ++k) if (cnt_k[k] > cnt_k[best]) best = k;
+                    serve = 1u << best;
+                } else if (leaf_policy == 2 && n_node_lanes != 0) {
+                    serve = 0;
+                    for (uint32_t k = 0; k < 8; ++k) if (cnt_k[k] >= 8u || k == 7u) serve |= 1u << k;
+                } else if (leaf_policy == 15 && n_node_lanes != 0) { // thresholds for the two classes from HOSTSIM_LEAF_THR="cheap,expensive"
+                    uint32_t ta = 1, tb = 6;
+                    if (const char* e = getenv("HOSTSIM_LEAF_THR")) sscanf(e, "%u,%u", &ta, &tb);
+                    serve = 1u << 7;
+                    if (cnt_k[PRIM_SPHERE] + cnt_k[PRIM_RECT] >= ta) serve |= (1u << PRIM_SPHERE) | (1u << PRIM_RECT);
+                    if (cnt_k[PRIM_MOVING_SPHERE] + cnt_k[PRIM_BOX] + cnt_k[PRIM_INSTANCE] >= tb) serve |= (1u << PRIM_MOVING_SPHERE) | (1u << PRIM_BOX) | (1u << PRIM_INSTANCE);
+                } else if (leaf_policy >= 3 && n_node_lanes != 0) {
+                    // two classes: spheres, rectangles and empty slots are always served; the EXPENSIVE kinds (moving sphere, cube, instance) together once
+                    // `leaf_policy` lanes wait at them (or no lane is at a node)
+                    serve = (1u << PRIM_SPHERE) | (1u << PRIM_RECT) | (1u << 7);
+                    if (cnt_k[PRIM_MOVING_SPHERE] + cnt_k[PRIM_BOX] + cnt_k[PRIM_INSTANCE] >= leaf_policy) serve |= (1u << PRIM_MOVING_SPHERE) | (1u << PRIM_BOX) | (1u << PRIM_INSTANCE);
+                }
+                uint32_t n = 0, kinds = 0;
+                for (uint32_t i = 0; i < 64; ++i) if (!L[i].done && walking[i] && L[i].tr.node < 0 && L[i].tr.node != TRAV_DONE) {
+                    const uint32_t k = L[i].tr.node == CHILD_EMPTY ? 7u : (leaf_kind(L[i].tr.node) & 7u);
+                    if (!(serve >> k & 1u)) continue;
+                    if (k < 5) { kinds |= 1u << k; out[40 + k]++; }
+                    trav_leaf_step(L[i].tr, hs.view, L[i].ps.ray, t_min, L[i].stack, cnt); ++n;
+                }
+                if (n) { out[3]++; out[4] += n; out[6 + (kinds & 15u)]++; out[48 + ((kinds >> 4) & 1u)]++; }
             }
         }
         return;

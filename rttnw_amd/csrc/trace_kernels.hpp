@@ -13,8 +13,8 @@
 //     conflict-free ds_read/ds_write_b32); small scenes keep the node records there too.
 //   * job sums go to a partial buffer; a resolve kernel adds a pixel's chunks in chunk order, so the
 //     image is bit-identical whatever the scheduling, the grid size or the number of GPUs.
-// Two forms of the loop: trace_kernel_plain (a lane owns a path) and trace_kernel (paths decoupled
-// from lanes through wave-private queues, for trees that live in HBM).
+// Two forms of the loop (KERNELS.md): trace_kernel_plain (a lane owns a path; shade phases asynchronous to the walks) and
+// trace_kernel (paths decoupled from lanes through wave-private queues, for trees that live in HBM).
 // No CPU fallback: every entry point needs a HIP device.
 #pragma once
 #include "render_common.hpp"
@@ -451,10 +451,12 @@ RT_WAVE_DECL(false, SHAPES_FAST) RT_WAVE_DECL(false, SHAPES_GENERAL) RT_WAVE_DEC
 #undef RT_WAVE_DECL
 #endif
 
-// The plain form of the same loop: a lane OWNS a path (and its job) and alternates "regenerate or advance by one
-// bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch.  Simpler, less
-// bookkeeping per ray, but every lane waits for the longest BVH walk of the wave at every bounce.  Kept beside the
-// decoupled kernel because which of the two is faster depends on the scene (DESIGN.md "Kernels").
+// The plain form of the same loop: a lane OWNS a path (and its job): path state stays in registers, no queues.  Rounds 1-4 alternated
+// "regenerate or advance by one bounce" (rt_core.hpp path_step = whole BVH walk + shade) with the wave-aggregated job fetch, and every lane
+// waited for the longest BVH walk of the wave at every bounce.  Since round 5 (RT_ASYNC_SHADE) the walk loop is left for a SHADE PHASE once
+// at most RT_ASYNC_SLACK walks are unfinished: the finished lanes shade, regenerate and start their next walk, the unfinished ones keep
+// their cursor and walk on beside them.  Kept beside the decoupled kernel because which of the two is faster depends on the scene
+// (render_tiles.hpp: the crossover is at ~13 000 four-wide records; KERNELS.md).
 // NSTEPS: node steps per trip round the walk loop (rt_core.hpp closest_solid): RT_NODE_STEPS, or 3 for tiny top trees (render_tiles.hpp).
 template <typename R, bool COUNT, int BLOCK, bool LDSN, int GENERAL, int NSTEPS = RT_NODE_STEPS> // GENERAL: SHAPES_FAST / SHAPES_GENERAL / SHAPES_NONE, as above
 // (the 256-thread form — nodes in global memory — asks for at least 3 waves/SIMD like the decoupled kernel: its f64 code,

@@ -70,9 +70,11 @@ enum rttnw_plane { RTTNW_XY = 0, RTTNW_XZ = 1, RTTNW_YZ = 2 };
  *              RTTNW_F64 (built with fused multiply-adds and shared reciprocals) agrees to rounding only — which a scene that
  *              amplifies rounding (config 5: a million small spheres, ~100x per bounce) turns into different paths after a few
  *              bounces.  It also tests every object in the frame the reference tests it in: a scene whose default lowering holds
- *              world-space copies of transformed groups' spheres is lowered a second time without them at its first strict render
- *              (final_scene: every pixel within 1e-12 of the CPU reference at 800x800 spp 5000, RGBA8 identical).  Same buffers as
- *              RTTNW_F64 (doubles); 5-10 % slower on the issue-bound scenes, 15 % on final_scene. */
+ *              world-space copies of transformed groups' spheres is lowered a second time at its first strict render — the copies'
+ *              world-space BOXES stay in the top tree (culling never shapes a result), the sphere test itself is made through the
+ *              group's wrappers as in hittable.rs:599-606,686-699 (final_scene: every pixel within 1e-12 of the CPU reference at
+ *              800x800 spp 5000, RGBA8 identical).  Same buffers as RTTNW_F64 (doubles); 5-10 % slower on cornell_box, 15-18 % on
+ *              final_scene (what it costs, measured: IEEE quotients 6 %, no contraction 3 %, registers the rest), nothing on config 5. */
 enum rttnw_precision { RTTNW_F64 = 0, RTTNW_F32 = 1, RTTNW_F64_STRICT = 2 };
 
 /* Bit flags for `rttnw_params.quirks`. */

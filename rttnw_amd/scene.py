@@ -119,7 +119,7 @@ class Scene:
         check(self.b.scene_set_world(self.handle, lst), self.b, "scene_set_world")
 
     def set_bvh_builder(self, which):
-        """abi.BVH_HOST_SAH (default), abi.BVH_DEVICE_LBVH or abi.BVH_DEVICE_SAH; before commit / build_named."""
+        """abi.BVH_AUTO (default), abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH or abi.BVH_DEVICE_SAH; before commit / build_named."""
         check(self.b.scene_set_bvh_builder(self.handle, int(which)), self.b, "scene_set_bvh_builder")
 
     def build_info(self):
@@ -166,7 +166,8 @@ def make_params(width, height, spp, *, background=(0.0, 0.0, 0.0), seed=1, preci
 
 def build(binding, scenes_lib, name, earth=None, param=0, seed=0x5EED0001, bvh=None):
     """One of the catalogue scenes (host/scenes.cpp, the scenes.rs mirror) built through `binding` and committed:
-    (Scene, SceneSetup).  `bvh`: abi.BVH_HOST_SAH (default), abi.BVH_DEVICE_LBVH or abi.BVH_DEVICE_SAH."""
+    (Scene, SceneSetup).  `bvh`: None = the library's default (abi.BVH_AUTO: host SAH below 100 000 leaves per tree, device SAH above),
+    or abi.BVH_HOST_SAH, abi.BVH_DEVICE_LBVH, abi.BVH_DEVICE_SAH."""
     sc = Scene(binding, seed, scenes_binding=scenes_lib)
     if bvh is not None:
         sc.set_bvh_builder(bvh)

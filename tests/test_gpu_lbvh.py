@@ -158,6 +158,30 @@ def test_builder_choice_is_frozen_by_commit(gpu):
     assert gpu.scene_set_bvh_builder(sc2.handle, abi.BVH_DEVICE_SAH) == 0
 
 
+def test_default_builder_picks_by_tree_size(gpu, scenes_lib, earth):
+    """RTTNW_BVH_AUTO (ABI 3, the default): trees below RTTNW_BVH_AUTO_DEVICE_LEAVES = 100 000 leaves are built on the host (no device build
+    time; the small-scene leaf tuning applies: final_scene keeps the host build's records), larger ones by the device SAH builder — and the
+    image is the host-built tree's, bit for bit."""
+    sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)                      # default builder
+    info = sc.build_info()
+    assert info.builder == abi.BVH_AUTO and info.device_ms == 0.0
+    sh, _ = util.build(gpu, scenes_lib, "final_scene", earth, bvh=abi.BVH_HOST_SAH)
+    assert sh.build_info().n_nodes == info.n_nodes
+    sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=120000)
+    info = sc.build_info()
+    assert info.builder == abi.BVH_AUTO and info.device_ms > 0.0
+    small, _ = util.build(gpu, scenes_lib, "spheres_1m", param=60000)
+    assert small.build_info().device_ms == 0.0
+    sd, _ = util.build(gpu, scenes_lib, "spheres_1m", param=120000, bvh=abi.BVH_DEVICE_SAH)
+    sh, _ = util.build(gpu, scenes_lib, "spheres_1m", param=120000, bvh=abi.BVH_HOST_SAH)
+    assert sd.build_info().n_nodes == info.n_nodes
+    for prec in (abi.F64, abi.F32):
+        cam, p = util.params_for(setup, 48, 40, 4, precision=prec, seed=5)
+        a, ra, _ = render.render_host(sc, cam, p)
+        b, rb, _ = render.render_host(sh, cam, p)
+        assert np.array_equal(a, b) and np.array_equal(ra, rb)
+
+
 @DEVICE_BUILDERS
 def test_full_size_config5_invariants(gpu, scenes_lib, builder):
     """BASELINE config 5 at its full size (10^6 spheres, 1024x1024) is beyond the oracle's reference-shaped builder, so

@@ -1664,7 +1664,10 @@ RT_HD void tile_unpermute(uint32_t permuted, FastDiv div_tiles_x, uint32_t& tx, 
 // Jobs are numbered group-major: group g = chunks [16 g, 16 g + 16) of every pixel of the rank, then inside a group
 // the 2x2 blocks in tile order.  Chunks past the last one are padding (empty jobs).  `sum_index` is where the job's
 // sequential sum goes: chunk-major over (tile, pixel-in-tile), the layout resolve_kernel reads.
-constexpr uint32_t JOB_BLOCK_LG = 1;                                  // 2x2 pixels
+#ifndef RT_JOB_BLOCK_LG
+#define RT_JOB_BLOCK_LG 1 // (re-measured under round 5's shade phases, final_scene f64 / cornell_box f64: 0 = 1 pixel x 64 chunks, 2 = 4x4 x 4: profiles/r05/README.md)
+#endif
+constexpr uint32_t JOB_BLOCK_LG = RT_JOB_BLOCK_LG;                    // 2x2 pixels
 constexpr uint32_t JOB_GROUP_CHUNKS = 64u >> (2u * JOB_BLOCK_LG);      // 16 chunks
 struct JobInfo {
     uint32_t px, row, s, s_end;

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
             // ASYNCHRONOUS SHADE PHASES (round 5).  Rounds 1-4 ran `path_step` here: every lane's whole walk, then the shade — a round lasted as long as
             // its LONGEST walk (final_scene: 9.5 trips where the mean walk has 4.2; a node step served 20 of 64 lanes).  Now the walk loop is left once
             // at most RT_ASYNC_SLACK walks are unfinished: the finished lanes shade, regenerate and start their next walk, the unfinished ones keep
-            // their cursor (closest hit, node, stack) and walk on beside them.  Host model of the wave (tests/hostsim policy 4, exp/wave_async.py):
+            // their cursor (closest hit, node, stack) and walk on beside them.  Host model of the wave (tests/hostsim policy 4, profiles/experiments/wave_async.py):
             // node-step executions -31 %, leaf-step executions -17 %, shade phases +9 %.  A lane's own sequence of steps is untouched: same image.
             const bool fresh_path = !done && !walking && !alive && s < s_end;
             if (fresh_path) {

@@ -91,9 +91,10 @@ impl SceneBuilder {
     pub fn translate(&mut self, item: Hit, offset: [f64; 3]) -> Result<Hit> { id(unsafe { ffi::rttnw_translate(self.raw, item.0, offset.as_ptr()) }).map(Hit) }
     pub fn rotate_y(&mut self, item: Hit, angle_degrees: f64) -> Result<Hit> { id(unsafe { ffi::rttnw_rotate_y(self.raw, item.0, angle_degrees) }).map(Hit) }
     pub fn constant_medium(&mut self, boundary: Hit, density: f64, phase: Tex) -> Result<Hit> { id(unsafe { ffi::rttnw_constant_medium(self.raw, boundary.0, density, phase.0) }).map(Hit) }
-    /// Build the BVHs on the device instead of on the host (large or frequently rebuilt scenes); before `commit`.
+    /// Force where the BVHs are built; before `commit`.  Without this call the library decides per tree (`RTTNW_BVH_AUTO`: host below
+    /// 100 000 leaves, the device's binned-SAH build above).
     pub fn device_bvh(&mut self, on: bool) -> Result<()> {
-        ok(unsafe { ffi::rttnw_scene_set_bvh_builder(self.raw, if on { ffi::RTTNW_BVH_DEVICE_LBVH } else { ffi::RTTNW_BVH_HOST_SAH }) })
+        ok(unsafe { ffi::rttnw_scene_set_bvh_builder(self.raw, if on { ffi::RTTNW_BVH_DEVICE_SAH } else { ffi::RTTNW_BVH_HOST_SAH }) })
     }
     /// `Scene { world, .. }` is complete: lower, build, upload.
     pub fn commit(mut self, world: Hit) -> Result<Scene> {

@@ -339,12 +339,26 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
                 if (n_walk + n_wait == 0) break;
                 if (n_walk == 0 || n_wait >= uint32_t(b)) {
                     bool began = false;
-                    uint32_t served = 0;
+                    uint32_t served = 0, phase_cls = 0;
                     for (uint32_t i = 0; i < 64; ++i) {
                         Lane& l = L[i];
                         if (l.done || walking[i]) continue;
                         ++served;
                         if (l.alive) {
+                            // which material branches of shade() this phase runs (out[50 + class]: phases with the class present, out[56 + class]: lanes):
+                            // 0 lambertian / isotropic / light with a solid colour, 1 metal, 2 dielectric, 3 noise texture, 4 image texture, 5 checker
+                            if (l.tr.found) {
+                                HitRecord<R> rec;
+                                NoCounters c2;
+                                PathState<R> tmp = l.ps;
+                                if (world_hit_finish(hs.view, tmp.ray, t_min, tmp.key, tmp.bounce, rc.quirks, l.tr.found, l.tr.closest, l.tr.best, rec, c2)) {
+                                    const MaterialRec<R>& m = hs.view.mats[rec.mat];
+                                    uint32_t cls = m.type == MAT_METAL ? 1u : (m.type == MAT_DIELECTRIC ? 2u : 0u);
+                                    if (cls == 0u && m.tex >= 0) { const int32_t tt = hs.view.texs[m.tex].type; cls = tt == TEX_NOISE ? 3u : (tt == TEX_IMAGE ? 4u : (tt == TEX_CHECKER ? 5u : 0u)); }
+                                    if (!(phase_cls >> cls & 1u)) { phase_cls |= 1u << cls; out[50 + cls]++; }
+                                    out[56 + cls]++;
+                                }
+                            }
                             l.alive = path_shade(l.ps, hs.view, rc, background, t_min, l.tr.found, l.tr.closest, l.tr.best, cnt);
                             if (!l.alive) { ++l.s; out[5]++; }
                         }

@@ -323,6 +323,8 @@ def main():
             rname = "float" if prec == abi.F32 else "double"
             ns = "rt::ieee_strict" if prec == abi.F64_STRICT else "rt::contracted"   # (rt_core.hpp: the two builds of the arithmetic)
             shapes = (3 if (form & 16) else 2) if (form & 8) else 0   # bits 3, 4: the instantiations for walks that never change frames (rt_core.hpp SHAPES_NONE / SHAPES_SINGLE)
+            if (form & 32) and shapes:
+                shapes += 2                                               # bit 5: their LEAN flavours (SHAPES_NONE_NT = 4 / SHAPES_SINGLE_NT = 5: no moving sphere, no medium, solid colours)
             kernel = ("%s::trace_kernel<%s, false, %d>" % (ns, rname, shapes) if (form & 1) != 0 else
                       "%s::trace_kernel_plain<%s, false, %s, %d, %d>" % (ns, rname, "1024, true" if lds_resident else "256, false", shapes, node_steps))
             common = {"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": round(kernel_ms, 3),

@@ -8,7 +8,7 @@ inline namespace RT_ARITH_NS {
 #define RT_WAVE_INST(COUNT, GENERAL)                                                                                                              \
     template __global__ void trace_kernel<double, COUNT, GENERAL>(SceneView<double>, CameraRec<double>, RenderConsts, double, double, double, double, \
                                                                   double*, unsigned long long*, DeviceCounters*, double*, uint32_t*, uint32_t, int32_t*);
-RT_WAVE_INST(false, SHAPES_FAST) RT_WAVE_INST(false, SHAPES_GENERAL) RT_WAVE_INST(false, SHAPES_NONE) RT_WAVE_INST(true, SHAPES_FAST) RT_WAVE_INST(true, SHAPES_GENERAL)
+RT_WAVE_INST(false, SHAPES_FAST) RT_WAVE_INST(false, SHAPES_GENERAL) RT_WAVE_INST(false, SHAPES_NONE) RT_WAVE_INST(false, SHAPES_NONE_NT) RT_WAVE_INST(true, SHAPES_FAST) RT_WAVE_INST(true, SHAPES_GENERAL)
 #undef RT_WAVE_INST
 } // namespace RT_ARITH_NS
 } // namespace rt

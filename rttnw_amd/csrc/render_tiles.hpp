@@ -116,6 +116,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     };
     bool three_steps = false; // the lane-owns-path kernel's instantiation with three node steps per trip (tiny top trees)
     bool no_inst = false;     // the decoupled kernel's instantiation for scenes without instance records
+    bool no_time = false;     // ... and the LEAN flavour of the frame-less instantiations (no moving sphere, no medium, solid colours only: rt_core.hpp SHAPES_*_NT)
     // One pass: trace kernel over the pass's jobs, then the resolve step.
     auto trace_pass = [&]() -> int {
         const size_t n_jobs = rc.n_jobs;
@@ -161,8 +162,12 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             const bool lds_no_inst = want_lds && !gen && !count && !flat.walk_changes_frames;
             three_steps = want_lds && n4 <= 16u && RT_NODE_STEPS == 2;
             const bool tiny_tree = three_steps && !count; // (the counting variant's tallied loop is written for two: same steps per lane, same counters)
+            // (... and, of those two, the LEAN flavour where the scene holds no moving sphere, no medium and only solid colours: rt_core.hpp SHAPES_*_NT)
+            no_time = flat.lean();
             const void* kernel =
+                lds_no_inst && !flat.has_instance_leaves && no_time ? (tiny_tree ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE_NT, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE_NT>) :
                 lds_no_inst && !flat.has_instance_leaves ? (tiny_tree ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_NONE>) :
+                lds_no_inst && no_time ? (tiny_tree ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_SINGLE_NT, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_SINGLE_NT>) :
                 lds_no_inst ? (tiny_tree ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_SINGLE, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_SINGLE>) :
                 tiny_tree ? (gen ? (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_GENERAL, RT_TINY_TREE_STEPS> : (const void*)trace_kernel_plain<R, false, LDS_BLOCK, true, SHAPES_FAST, RT_TINY_TREE_STEPS>) :
                 want_lds ? (count ? (gen ? (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, true> : (const void*)trace_kernel_plain<R, true, LDS_BLOCK, true, false>)
@@ -195,8 +200,10 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             }
             // (a scene without any instance record takes the instantiation whose walk never changes frames, rt_core.hpp SHAPES_NONE)
             no_inst = !gen && !count && !flat.has_instance_leaves;
+            no_time = flat.lean();
             auto kernel = count ? (gen ? trace_kernel<R, true, SHAPES_GENERAL> : trace_kernel<R, true, SHAPES_FAST>)
-                                : (gen ? trace_kernel<R, false, SHAPES_GENERAL> : (no_inst ? trace_kernel<R, false, SHAPES_NONE> : trace_kernel<R, false, SHAPES_FAST>));
+                                : (gen ? trace_kernel<R, false, SHAPES_GENERAL>
+                                       : (no_inst ? (no_time ? trace_kernel<R, false, SHAPES_NONE_NT> : trace_kernel<R, false, SHAPES_NONE>) : trace_kernel<R, false, SHAPES_FAST>));
             const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
             size_t grid = 1;
             if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
@@ -260,6 +267,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         // roofline calls issue-bound)
         stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u) | (plain && three_steps ? 4u : 0u) | (!flat.needs_general && (plain ? !flat.walk_changes_frames && rc.lds_nodes != 0u : !flat.has_instance_leaves) ? 8u : 0u) |
                           (!flat.needs_general && plain && !flat.walk_changes_frames && rc.lds_nodes != 0u && flat.has_instance_leaves ? 16u : 0u);
+        if ((stats->reserved & 8u) != 0u && flat.lean()) stats->reserved |= 32u; // bit 5: ... in the LEAN flavour (rt_core.hpp SHAPES_*_NT)
     }
     return RTTNW_OK;
 }

@@ -307,11 +307,18 @@ template <typename R> RT_HD V3<R> random_in_unit_space(uint64_t key, uint32_t bo
 // 168 for its third wave: scratch 120 -> 52 B per lane, spheres_1m f64 310 -> 325 Msamples/s, RTTNW_F64_STRICT 300 -> 320.
 // SHAPES_SINGLE is the same where instance leaves do exist but all are single wrapped records (cornell_box: +2.9 % in f64, +4 % in the strict build): it
 // keeps the branch that tests such a record in place, which SHAPES_NONE scenes are better off without (final_scene f32: 1 %).
-enum : int { SHAPES_FAST = 0, SHAPES_GENERAL = 1, SHAPES_NONE = 2, SHAPES_SINGLE = 3 };
+// Round 5: SHAPES_NONE_NT / SHAPES_SINGLE_NT are the same two for LEAN scenes — no MovingSphere (nothing reads Ray::time), no ConstantMedium, every
+// material a solid colour (cornell_box, spheres_1m, random_scene without its moving spheres ...): the moving-sphere code, the media loop with its log, the
+// texture chain with its three sines / Perlin turbulence / image lookup and the spheres' (u, v) with their acos / atan2 are COMPILED OUT, and with them
+// the registers they hold in the f64 kernels, which run at their register cap (every spilled register is a scratch access per shade phase: cornell_box f64
+// +3 % for two registers, +6 % for five, profiles/r05/README.md) — and the ray time's one of the thirteen reals of the decoupled kernel's path slots.
+enum : int { SHAPES_FAST = 0, SHAPES_GENERAL = 1, SHAPES_NONE = 2, SHAPES_SINGLE = 3, SHAPES_NONE_NT = 4, SHAPES_SINGLE_NT = 5 };
 template <int G> struct NoCountersT {
     static constexpr bool GENERAL = G == SHAPES_GENERAL;
-    static constexpr bool NO_INST = G == SHAPES_NONE || G == SHAPES_SINGLE; // the walk never changes frames
-    static constexpr bool NO_INST_LEAF = G == SHAPES_NONE;                  // ... and meets no instance leaf at all
+    static constexpr bool NO_INST = G == SHAPES_NONE || G == SHAPES_SINGLE || G == SHAPES_NONE_NT || G == SHAPES_SINGLE_NT; // the walk never changes frames
+    static constexpr bool NO_INST_LEAF = G == SHAPES_NONE || G == SHAPES_NONE_NT;                                            // ... and meets no instance leaf at all
+    static constexpr bool NO_TIME = G == SHAPES_NONE_NT || G == SHAPES_SINGLE_NT;                                            // nothing reads Ray::time ...
+    static constexpr bool LEAN = NO_TIME;                                                                                    // ... and the scene has no medium and no texture but solid colours
     RT_HD void ray() {}
     RT_HD void node() {}
     RT_HD void prim() {}
@@ -319,8 +326,10 @@ template <int G> struct NoCountersT {
 };
 template <int G> struct LaneCountersT {
     static constexpr bool GENERAL = G == SHAPES_GENERAL;
-    static constexpr bool NO_INST = G == SHAPES_NONE || G == SHAPES_SINGLE;
-    static constexpr bool NO_INST_LEAF = G == SHAPES_NONE;
+    static constexpr bool NO_INST = G == SHAPES_NONE || G == SHAPES_SINGLE || G == SHAPES_NONE_NT || G == SHAPES_SINGLE_NT;
+    static constexpr bool NO_INST_LEAF = G == SHAPES_NONE || G == SHAPES_NONE_NT;
+    static constexpr bool NO_TIME = G == SHAPES_NONE_NT || G == SHAPES_SINGLE_NT;
+    static constexpr bool LEAN = NO_TIME;
     uint32_t rays = 0, nodes = 0, prims = 0, texels = 0;
     RT_HD void ray() { ++rays; }
     RT_HD void node() { ++nodes; }
@@ -806,7 +815,7 @@ template <typename R> RT_HD void rect_ab(int plane, const Ray<R>& ray, R t, R& a
 }
 
 // One primitive, t only (+ `aux`: the winning face of a box).  `ray` is in the primitive's space.
-template <typename R>
+template <bool NO_TIME = false, typename R>
 RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray<R>& ray, R t_min, R t_max, R& t, int& aux) {
     if (kind == PRIM_SPHERE) {
         SphereRec<R> s = sc.spheres[idx];
@@ -818,7 +827,7 @@ RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray
         const RectRec<R> r = sc.rects[idx];
         R a, b;
         return rect_t(r.plane, r.a0, r.a1, r.b0, r.b1, r.k, ray, t_min, t_max, t, a, b);
-    } else if (kind == PRIM_MOVING_SPHERE) {
+    } else if (!NO_TIME && kind == PRIM_MOVING_SPHERE) { // (NO_TIME: the scene has none)
         const MovingSphereRec<R> m = sc.moving[idx];
         return sphere_t(moving_center(m, ray.time), m.r, ray, t_min, t_max, t);
     }
@@ -1091,7 +1100,7 @@ template <bool G, typename R> RT_HD bool sphere_wc_t(const SceneView<R>& sc, uin
     const Ray<R> obj = to_object<G>(in, wray);
     return sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, obj, t_min, t_max, t);
 }
-template <bool G = false, typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
+template <bool G = false, bool NO_TIME = false, typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
     R t;
     int aux = 0;
     bool hit;
@@ -1101,7 +1110,7 @@ template <bool G = false, typename R> RT_HD void trav_test_record(Trav<R>& tr, c
         kind = PRIM_SPHERE; // the hit reference names the copy's record: make_record finds the object-space one from it
     } else
 #endif
-    hit = prim_t(sc, kind, idx, ray, t_min, tr.closest, t, aux);
+    hit = prim_t<NO_TIME>(sc, kind, idx, ray, t_min, tr.closest, t, aux);
     if (hit) {
         // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
         const bool loses_tie = tr.found && t == tr.closest &&
@@ -1132,7 +1141,7 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
         if (single_leaf != 0) { // one wrapped record: test it here in object space — no sentinel, no one-node tree to walk, the walk stays in its frame
             const Ray<R> obj = object_ray();
             cnt.prim();
-            trav_test_record<Cnt::GENERAL>(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min, obj, int32_t(first));
+            trav_test_record<Cnt::GENERAL, Cnt::NO_TIME>(tr, sc, leaf_kind(single_leaf), leaf_first(single_leaf), t_min, obj, int32_t(first));
             trav_pop<NI>(tr, wray, stack);
             return;
         }
@@ -1147,12 +1156,12 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     if constexpr (WHOLE_LEAF) {
         for (uint32_t k = 0; k < count; ++k) {
             cnt.prim();
-            trav_test_record<Cnt::GENERAL>(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+            trav_test_record<Cnt::GENERAL, Cnt::NO_TIME>(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         }
         trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
-        trav_test_record<Cnt::GENERAL>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+        trav_test_record<Cnt::GENERAL, Cnt::NO_TIME>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }
 }
@@ -1206,7 +1215,7 @@ template <typename R> RT_HD void sphere_uv(V3<R> p, R& u, R& v) { // hittable.rs
 // an image texture — possibly under a checker — ever reads them: they are computed only then.  Same results.
 RT_HD bool uv_is_read(int32_t mat_ref) { return (mat_ref & MAT_UV_FLAG) != 0; } // decided by the lowering, see MAT_UV_FLAG
 
-template <bool G, typename R>
+template <bool G, bool NO_TIME = false, typename R> // (NO_TIME = a LEAN scene, rt_core.hpp SHAPES_*_NT: no texture reads (u, v) either)
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim);
     uint32_t idx = ref_index(ref.prim);
@@ -1228,8 +1237,8 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         rec.u = R(0); rec.v = R(0);
         // (f64: deferring these ~250 instructions to the image texture's texel choice, made in f32 wherever f32 is certain of the
         // texel and in f64 otherwise, was built, bit-identical and 1 % SLOWER — profiles/r03/README.md)
-        if (uv_is_read(mref)) sphere_uv(outward, rec.u, rec.v);
-    } else if (kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
+        if (!NO_TIME && uv_is_read(mref)) sphere_uv(outward, rec.u, rec.v);
+    } else if (!NO_TIME && kind == PRIM_MOVING_SPHERE) { // hittable.rs:217-221
         const MovingSphereRec<R> m = sc.moving[idx];
         rec.p = ray.at(t);
         outward = (rec.p - moving_center(m, ray.time)) / m.r;
@@ -1238,7 +1247,7 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
     } else if (kind == PRIM_RECT) { // hittable.rs:515-519
         const RectRec<R> r = sc.rects[idx];
         rec.u = R(0); rec.v = R(0);
-        if (uv_is_read(r.mat)) {
+        if (!NO_TIME && uv_is_read(r.mat)) {
             R a, b;
             rect_ab(r.plane, ray, t, a, b);
             rec.u = rt_div(a - r.a0, r.a1 - r.a0);
@@ -1251,7 +1260,7 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         const BoxRec<R> bx = sc.boxes[idx];
         const int plane = ref.aux >> 1;
         rec.u = R(0); rec.v = R(0);
-        if (uv_is_read(bx.mat)) {
+        if (!NO_TIME && uv_is_read(bx.mat)) {
             R a, b;
             rect_ab(plane, ray, t, a, b);
             R a0 = plane == 2 ? bx.mn[1] : bx.mn[0], a1 = plane == 2 ? bx.mx[1] : bx.mx[0];
@@ -1286,8 +1295,9 @@ template <typename R, typename Cnt>
 RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, uint64_t key, uint32_t bounce, uint32_t quirks,
                             bool found, R closest, HitRef best, HitRecord<R>& rec, Cnt& cnt) {
     int32_t medium = -1;
-    const R world_length = sc.n_media > 0 ? magnitude(ray.d) : R(0); // |direction|: once for all media (hittable.rs:760)
-    for (int32_t m = 0; m < sc.n_media; ++m) {
+    const int32_t n_media = Cnt::LEAN ? 0 : sc.n_media; // (a LEAN scene has none: the loop and its log are compiled out)
+    const R world_length = n_media > 0 ? magnitude(ray.d) : R(0); // |direction|: once for all media (hittable.rs:760)
+    for (int32_t m = 0; m < n_media; ++m) {
         const MediumRec<R> md = sc.media[m];
         Ray<R> bray = ray;
         if (md.inst >= 0) bray = to_object<Cnt::GENERAL>(sc.insts[md.inst], ray);
@@ -1379,7 +1389,7 @@ RT_HD bool world_hit_finish(const SceneView<R>& sc, const Ray<R>& ray, R t_min, 
                 unwind_record<true>(in, md.n_outer, ray.d, quirks, rec.p, rec.normal, rec.front_face);
             }
     } else {
-        make_record<Cnt::GENERAL>(sc, ray, best, closest, quirks, rec);
+        make_record<Cnt::GENERAL, Cnt::NO_TIME>(sc, ray, best, closest, quirks, rec);
     }
     return true;
 }
@@ -1495,7 +1505,10 @@ RT_HD bool shade(const SceneView<R>& sc, const HitRecord<R>& rec, uint64_t key, 
     // (round 5: a noise texture evaluated by the WHOLE wave — lane l the corner l & 7 of octave l >> 3 of one requesting lane's point, sums in the
     // reference's order, bit-identical — was built and measured: final_scene f64 +0.6 %, strict -2.4 %, cornell_box, which has no noise, -12 % through
     // the registers the extra code takes in a kernel that spills: profiles/r05/README.md.  Not kept.)
-    if (m.type == MAT_DIFFUSE_LIGHT || m.type == MAT_LAMBERTIAN || m.type == MAT_ISOTROPIC) colour = material_color(sc, m, rec, cnt);
+    if (m.type == MAT_DIFFUSE_LIGHT || m.type == MAT_LAMBERTIAN || m.type == MAT_ISOTROPIC) {
+        if constexpr (Cnt::LEAN) colour = V3<R>(m.albedo); // (every material of a LEAN scene is a solid colour: lowered into the material record)
+        else colour = material_color(sc, m, rec, cnt);
+    }
     if (m.type == MAT_DIFFUSE_LIGHT) { // material.rs:242-250
         emitted = colour;
         return false;

@@ -93,6 +93,14 @@ struct FlatScene {
     bool has_instance_leaves = false; // some tree holds an instance leaf at all (a wrapped group, or a single wrapped record tested in place)
     bool walk_changes_frames = false; // some tree holds an instance with a tree of its own (a wrapped group the walk enters): false = the walk never leaves world space
     uint32_t n_world_copies = 0;      // spheres of transformed groups that the walk tests as world-space copies in the top tree (scene_lower.cpp collect)
+    // A LEAN scene: no MovingSphere, no ConstantMedium, every material a solid colour (lowered into its record: tex < 0) — the kernels have
+    // instantiations without the code of any of them (rt_core.hpp SHAPES_NONE_NT / SHAPES_SINGLE_NT).
+    bool lean() const {
+        if (!moving.empty() || !media.empty()) return false;
+        for (const auto& m : mats)
+            if (m.tex >= 0) return false;
+        return true;
+    }
 };
 
 // Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.  `device` (optional)

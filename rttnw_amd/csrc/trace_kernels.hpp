@@ -68,7 +68,8 @@ template <uint32_t STRIDE, uint32_t ENTRIES = LDS_STACK_ENTRIES> struct LdsStack
     static constexpr int SLAB_F32 = SLAB_EXACT; // node records in global memory: the f32 kernels' exact slab test (rt_core.hpp)
     static constexpr int SPARE = int(ENTRIES); // a lane's extra LDS slot: target of the node step's masked-off stores
     LdsIntPtr base;        // &lds[threadIdx.x]
-    GlobalIntPtr spill;    // &spill_buffer[global thread]
+    GlobalIntPtr spill;    // &spill_buffer[global thread]  (a wave-uniform base with the thread index added at the rare access saves the two registers
+                           // and cost final_scene f64 3 %: 1653 -> 1599, the pushes' code in the node step grows)
     uint32_t spill_stride; // threads of the launch
     __device__ __forceinline__ void set(int i, int32_t v) {
         if (uint32_t(i) < ENTRIES) base[uint32_t(i) * STRIDE] = v;
@@ -295,7 +296,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
             if (on && !fresh) {
                 ps.ray.o = V3<R>(pr[size_t(PR_OX) * n_slots], pr[size_t(PR_OY) * n_slots], pr[size_t(PR_OZ) * n_slots]);
                 ps.ray.d = V3<R>(pr[size_t(PR_DX) * n_slots], pr[size_t(PR_DY) * n_slots], pr[size_t(PR_DZ) * n_slots]);
-                ps.ray.time = pr[size_t(PR_TIME) * n_slots];
+                if constexpr (!decltype(cnt)::NO_TIME) ps.ray.time = pr[size_t(PR_TIME) * n_slots]; // (a scene in which nothing reads the time does not carry it)
+                else ps.ray.time = R(0);
                 ps.throughput = V3<R>(pr[size_t(PR_TX) * n_slots], pr[size_t(PR_TY) * n_slots], pr[size_t(PR_TZ) * n_slots]);
                 ps.key = (unsigned long long)pu[size_t(PU_KEY_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_KEY_HI) * n_slots] << 32);
                 ps.bounce = pu[size_t(PU_BOUNCE) * n_slots];
@@ -361,13 +363,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
             if (emit) { // the slot's next ray: path state back to memory, ray onto the queue
                 pr[size_t(PR_OX) * n_slots] = ps.ray.o.x; pr[size_t(PR_OY) * n_slots] = ps.ray.o.y; pr[size_t(PR_OZ) * n_slots] = ps.ray.o.z;
                 pr[size_t(PR_DX) * n_slots] = ps.ray.d.x; pr[size_t(PR_DY) * n_slots] = ps.ray.d.y; pr[size_t(PR_DZ) * n_slots] = ps.ray.d.z;
-                pr[size_t(PR_TIME) * n_slots] = ps.ray.time;
+                if constexpr (!decltype(cnt)::NO_TIME) pr[size_t(PR_TIME) * n_slots] = ps.ray.time;
                 pr[size_t(PR_TX) * n_slots] = ps.throughput.x; pr[size_t(PR_TY) * n_slots] = ps.throughput.y; pr[size_t(PR_TZ) * n_slots] = ps.throughput.z;
                 pu[size_t(PU_BOUNCE) * n_slots] = ps.bounce;
                 const uint32_t idx = ray_n + uint32_t(__popcll(em & lanes_below));
                 rq_f[0u * QCAP + idx] = ps.ray.o.x; rq_f[1u * QCAP + idx] = ps.ray.o.y; rq_f[2u * QCAP + idx] = ps.ray.o.z;
                 rq_f[3u * QCAP + idx] = ps.ray.d.x; rq_f[4u * QCAP + idx] = ps.ray.d.y; rq_f[5u * QCAP + idx] = ps.ray.d.z;
-                rq_f[6u * QCAP + idx] = ps.ray.time;
+                if constexpr (!decltype(cnt)::NO_TIME) rq_f[6u * QCAP + idx] = ps.ray.time;
                 rq_slot[idx] = uint8_t(hslot);
             }
             ray_n += uint32_t(__popcll(em));
@@ -384,7 +386,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                 const uint32_t e = ray_n - 1u - rank;
                 wray.o = V3<R>(rq_f[0u * QCAP + e], rq_f[1u * QCAP + e], rq_f[2u * QCAP + e]);
                 wray.d = V3<R>(rq_f[3u * QCAP + e], rq_f[4u * QCAP + e], rq_f[5u * QCAP + e]);
-                wray.time = rq_f[6u * QCAP + e];
+                if constexpr (!decltype(cnt)::NO_TIME) wray.time = rq_f[6u * QCAP + e];
+                else wray.time = R(0);
                 slot = rq_slot[e];
                 cnt.ray();
                 trav_begin(tr, sc, wray, stack);
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 #define RT_WAVE_DECL(COUNT, GENERAL)                                                                                                                      \
     extern template __global__ void trace_kernel<double, COUNT, GENERAL>(SceneView<double>, CameraRec<double>, RenderConsts, double, double, double, double, \
                                                                          double*, unsigned long long*, DeviceCounters*, double*, uint32_t*, uint32_t, int32_t*);
-RT_WAVE_DECL(false, SHAPES_FAST) RT_WAVE_DECL(false, SHAPES_GENERAL) RT_WAVE_DECL(false, SHAPES_NONE) RT_WAVE_DECL(true, SHAPES_FAST) RT_WAVE_DECL(true, SHAPES_GENERAL)
+RT_WAVE_DECL(false, SHAPES_FAST) RT_WAVE_DECL(false, SHAPES_GENERAL) RT_WAVE_DECL(false, SHAPES_NONE) RT_WAVE_DECL(false, SHAPES_NONE_NT) RT_WAVE_DECL(true, SHAPES_FAST) RT_WAVE_DECL(true, SHAPES_GENERAL)
 #undef RT_WAVE_DECL
 #endif
 
@@ -524,8 +527,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
 
     bool has_job = false, alive = false, done = false;
     unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
-    unsigned long long job = 0;
-    uint32_t px = 0, row = 0, s = 0, s_end = 0;
+    uint32_t job = 0;    // where the lane's job writes its sum (JobInfo::sum_index: below 2^32, plan_jobs)
+    uint32_t pxrow = 0;  // the job's pixel, px | row << 16 (the image is at most 65535 wide and high: render_api.cpp validate) — one register, not two:
+                         // the f64 instantiations run at their register cap and every spilled one is a scratch access per phase (cornell_box f64: three
+                         // registers fewer = +6 %, profiles/r05/README.md)
+    uint32_t s = 0, s_end = 0;
     V3<R> acc;
     PathState<R> ps;
     bool walking = false; // RT_ASYNC_SHADE: the lane has a walk in progress (begun, or suspended by a shade phase)
@@ -544,18 +550,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
         const unsigned long long mask = __ballot(need);
         if (mask != 0ull) {
             if (need && has_job) { // retire the finished job: its sequential sum
-                R* dst = partial + job * 3ull;
+                R* dst = partial + (unsigned long long)job * 3ull;
                 dst[0] = acc.x; dst[1] = acc.y; dst[2] = acc.z;
                 has_job = false;
             }
             const unsigned long long mine = wave_take_jobs(mask, lane, batch_next, batch_end, job_counter);
             if (need) {
-                job = mine;
-                if (job >= n_jobs) {
+                if (mine >= n_jobs) {
                     done = true;
                 } else {
-                    const JobInfo ji = job_decode(rc, uint32_t(job));
-                    px = ji.px; row = ji.row; s = ji.s; s_end = ji.s_end;
+                    const JobInfo ji = job_decode(rc, uint32_t(mine));
+                    pxrow = ji.px | (ji.row << 16); s = ji.s; s_end = ji.s_end;
                     job = ji.sum_index; // from here on: where the job's sum goes
                     acc = V3<R>();
                     has_job = ji.real; // padding jobs have no sum to write
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
             // node-step executions -31 %, leaf-step executions -17 %, shade phases +9 %.  A lane's own sequence of steps is untouched: same image.
             const bool fresh_path = !done && !walking && !alive && s < s_end;
             if (fresh_path) {
-                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, px, row, s);
+                path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, pxrow & 0xFFFFu, pxrow >> 16, s);
                 alive = true;
             }
             const bool fresh_walk = !done && !walking && alive;
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
         } else if constexpr (!COUNT) {
             if (!done) {
                 if (!alive && s < s_end) {
-                    path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, px, row, s);
+                    path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), rc, pxrow & 0xFFFFu, pxrow >> 16, s);
                     alive = true;
                 }
                 if (alive) {
@@ -622,9 +627,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK == 256 ? 3 : 1) void trace_kernel_plai
             }
         } else { // the same steps, with the wave clock read between the phases and the lockstep loop tallied (trace_tally.hpp)
 #if RT_ASYNC_SHADE
-            plain_phase_tallied<NSTEPS>(done, alive, walking, tr, tally_trips, px, row, s, s_end, acc, ps, cam, rc, sc, background, t_min, stack, cnt, prof, counters, lane, tk0);
+            plain_phase_tallied<NSTEPS>(done, alive, walking, tr, tally_trips, pxrow & 0xFFFFu, pxrow >> 16, s, s_end, acc, ps, cam, rc, sc, background, t_min, stack, cnt, prof, counters, lane, tk0);
 #else
-            plain_round_tallied(done, alive, px, row, s, s_end, acc, ps, cam, rc, sc, background, t_min, stack, cnt, prof, counters, lane, tk0);
+            plain_round_tallied(done, alive, pxrow & 0xFFFFu, pxrow >> 16, s, s_end, acc, ps, cam, rc, sc, background, t_min, stack, cnt, prof, counters, lane, tk0);
 #endif
         }
     }

@@ -232,7 +232,7 @@ def test_config5_spheres_1m_at_its_size_vs_oracle(gpu, oracle, scenes_lib):
     for name, prec in (("strict", abi.F64_STRICT), ("f64", abi.F64), ("f32", abi.F32)):
         cam, p = util.params_for(setup, w, h, spp, precision=prec)
         lin, rgba, st = gpu_render(gpu, sg, cam, p)
-        assert st.samples == w * h * spp and st.reserved == 9 and np.isfinite(lin).all(), name   # the decoupled kernel (bit 0), the instantiation without instance code (bit 3)
+        assert st.samples == w * h * spp and st.reserved == 41 and np.isfinite(lin).all(), name   # the decoupled kernel (bit 0), the instantiation without instance code (bit 3) in its LEAN flavour (bit 5: no moving sphere, no medium, solid colours)
         out[name] = (lin, rgba)
     cam, p64 = util.params_for(setup, w, h, spp, precision=abi.F64)
     n_px = n_bound32 = n_lsb64 = 0
@@ -371,6 +371,7 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
     # world-space copies; cornell_box's two blocks are single wrapped records tested in place; smoke_cornell_box's rotated boxes are medium boundaries)
     assert ((st.reserved & 8) != 0) == ((st.reserved & 2) != 0), st.reserved   # (the LDS form of this kernel has that instantiation)
     assert ((st.reserved & 16) != 0) == (name == "cornell_box"), st.reserved   # (bit 4: ... the one that tests single wrapped records in place)
+    assert ((st.reserved & 32) != 0) == ((st.reserved & 8) != 0 and name in ("cornell_box", "spheres_1m")), st.reserved   # (bit 5: ... in the LEAN flavour: no moving sphere, no medium, solid colours only)
     same((lin, rgba), out["plain"], "timed plain")
     monkeypatch.setenv("RTTNW_KERNEL", "plainglobal")
     lin, rgba, st = gpu_render(gpu, sc, cam, p)

@@ -161,13 +161,31 @@ __device__ __forceinline__ unsigned long long wave_take_jobs(unsigned long long 
     return job;
 }
 
+#ifndef RT_POOL_NT
+#define RT_POOL_NT 0
+#endif
+template <typename T> __device__ __forceinline__ T pool_ld(const T* p) {
+#if RT_POOL_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename T, typename V> __device__ __forceinline__ void pool_st(T* p, V v) {
+#if RT_POOL_NT
+    __builtin_nontemporal_store(T(v), p);
+#else
+    *p = T(v);
+#endif
+}
 constexpr int TRACE_BLOCK = 256;
 constexpr uint32_t SLOTS_PER_WAVE = 128; // paths owned by one wave64: 64 being traversed + up to 64 queued
 constexpr uint32_t QCAP = 128;           // capacity of a wave's ray queue and hit queue (entries)
+static_assert(QCAP == SLOTS_PER_WAVE, "a slot has at most one ray or hit in flight: the queues never hold more entries than the wave has slots");
 
 // Path state of a slot, in global memory (L2-resident), struct-of-arrays over all slots of the launch.
 // (no radiance: a path's value is the term of its last bounce, rt_core.hpp path_shade — round 4; 13 reals a slot instead of 16)
-enum : uint32_t { PR_OX = 0, PR_OY, PR_OZ, PR_DX, PR_DY, PR_DZ, PR_TIME, PR_TX, PR_TY, PR_TZ, PR_AX, PR_AY, PR_AZ, PR_COUNT };
+enum : uint32_t { PR_TX = 0, PR_TY, PR_TZ, PR_AX, PR_AY, PR_AZ, PR_COUNT }; // (the slot's RAY stays in LDS from its emit to its shade: the wave's ray arena, below)
 enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, PU_JOB_LO, PU_JOB_HI, PU_COUNT };
 // bytes of LDS one wave needs: ray queue (7 reals + slot), hit queue (t + prim + inst + meta), traversal stacks
 // LDS stack entries of the decoupled kernel: 16 for f32; 13 for f64, whose queues are twice as wide: THREE 256-thread blocks must fit a CU's 160 KB,
@@ -240,8 +258,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
     typename CounterSel<COUNT, GENERAL>::type cnt;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
     unsigned char* wbase = lds_raw + wave_in_block * wave_lds_bytes<R>(rc.stack_depth);
-    R* const rq_f = reinterpret_cast<R*>(wbase);            // ray queue [7][QCAP]: o.xyz, d.xyz, time
-    R* const hq_t = rq_f + 7u * QCAP;                       // hit queue: t
+    // RAY ARENA [7][SLOTS_PER_WAVE]: o.xyz, d.xyz, time of every slot's current ray, INDEXED BY SLOT — written when the ray is emitted, read by the lane
+    // that walks it and again by the shade of its hit; the queues carry slot numbers only.  (Rounds 2-4 queued the ray by queue position and kept a copy
+    // in the slot's global state for the shade to read back: 2 x 7 of a slot's 13 reals per bounce, and this kernel waits on L2-miss lines.)
+    R* const ra = reinterpret_cast<R*>(wbase);
+    R* const hq_t = ra + 7u * SLOTS_PER_WAVE;               // hit queue: t
     int32_t* const hq_prim = reinterpret_cast<int32_t*>(hq_t + QCAP);
     int32_t* const hq_inst = hq_prim + QCAP;
     uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
@@ -294,13 +315,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
             unsigned long long job = ~0ull;
             V3<R> acc;
             if (on && !fresh) {
-                ps.ray.o = V3<R>(pr[size_t(PR_OX) * n_slots], pr[size_t(PR_OY) * n_slots], pr[size_t(PR_OZ) * n_slots]);
-                ps.ray.d = V3<R>(pr[size_t(PR_DX) * n_slots], pr[size_t(PR_DY) * n_slots], pr[size_t(PR_DZ) * n_slots]);
-                if constexpr (!decltype(cnt)::NO_TIME) ps.ray.time = pr[size_t(PR_TIME) * n_slots]; // (a scene in which nothing reads the time does not carry it)
+                ps.ray.o = V3<R>(ra[0u * SLOTS_PER_WAVE + hslot], ra[1u * SLOTS_PER_WAVE + hslot], ra[2u * SLOTS_PER_WAVE + hslot]);
+                ps.ray.d = V3<R>(ra[3u * SLOTS_PER_WAVE + hslot], ra[4u * SLOTS_PER_WAVE + hslot], ra[5u * SLOTS_PER_WAVE + hslot]);
+                if constexpr (!decltype(cnt)::NO_TIME) ps.ray.time = ra[6u * SLOTS_PER_WAVE + hslot]; // (a scene in which nothing reads the time does not carry it)
                 else ps.ray.time = R(0);
-                ps.throughput = V3<R>(pr[size_t(PR_TX) * n_slots], pr[size_t(PR_TY) * n_slots], pr[size_t(PR_TZ) * n_slots]);
-                ps.key = (unsigned long long)pu[size_t(PU_KEY_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_KEY_HI) * n_slots] << 32);
-                ps.bounce = pu[size_t(PU_BOUNCE) * n_slots];
+                ps.throughput = V3<R>(pool_ld(pr + size_t(PR_TX) * n_slots), pool_ld(pr + size_t(PR_TY) * n_slots), pool_ld(pr + size_t(PR_TZ) * n_slots));
+                ps.key = (unsigned long long)pool_ld(pu + size_t(PU_KEY_LO) * n_slots) | ((unsigned long long)pool_ld(pu + size_t(PU_KEY_HI) * n_slots) << 32);
+                ps.bounce = pool_ld(pu + size_t(PU_BOUNCE) * n_slots);
                 HitRef best;
                 best.prim = hq_prim[e];
                 best.inst = hq_inst[e];
@@ -311,11 +332,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                                found, hq_t[e], best, cnt)) {
                     emit = true; // next world.hit of the same path
                 } else {         // main.rs:216: acc + color(...)
-                    pxrow = pu[size_t(PU_PXROW) * n_slots];
-                    smp = pu[size_t(PU_S) * n_slots];
-                    smp_end = pu[size_t(PU_SEND) * n_slots];
-                    job = (unsigned long long)pu[size_t(PU_JOB_LO) * n_slots] | ((unsigned long long)pu[size_t(PU_JOB_HI) * n_slots] << 32);
-                    acc = V3<R>(pr[size_t(PR_AX) * n_slots], pr[size_t(PR_AY) * n_slots], pr[size_t(PR_AZ) * n_slots]) + ps.radiance;
+                    pxrow = pool_ld(pu + size_t(PU_PXROW) * n_slots);
+                    smp = pool_ld(pu + size_t(PU_S) * n_slots);
+                    smp_end = pool_ld(pu + size_t(PU_SEND) * n_slots);
+                    job = (unsigned long long)pool_ld(pu + size_t(PU_JOB_LO) * n_slots) | ((unsigned long long)pool_ld(pu + size_t(PU_JOB_HI) * n_slots) << 32);
+                    acc = V3<R>(pool_ld(pr + size_t(PR_AX) * n_slots), pool_ld(pr + size_t(PR_AY) * n_slots), pool_ld(pr + size_t(PR_AZ) * n_slots)) + ps.radiance;
                     ++smp;
                     need_sample = true;
                 }
@@ -349,27 +370,24 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
             }
             if (need_sample && !slot_done) { // main.rs:212-215: the job's next sample
                 path_begin(ps, kernarg_reload<CameraRec<R>>(offsetof(TraceArgsHead<R>, cam)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), pxrow & 0xFFFFu, pxrow >> 16, smp);
-                pu[size_t(PU_KEY_LO) * n_slots] = uint32_t(ps.key);
-                pu[size_t(PU_KEY_HI) * n_slots] = uint32_t(ps.key >> 32);
-                pu[size_t(PU_PXROW) * n_slots] = pxrow;
-                pu[size_t(PU_S) * n_slots] = smp;
-                pu[size_t(PU_SEND) * n_slots] = smp_end;
-                pu[size_t(PU_JOB_LO) * n_slots] = uint32_t(job);
-                pu[size_t(PU_JOB_HI) * n_slots] = uint32_t(job >> 32);
-                pr[size_t(PR_AX) * n_slots] = acc.x; pr[size_t(PR_AY) * n_slots] = acc.y; pr[size_t(PR_AZ) * n_slots] = acc.z;
+                pool_st(pu + size_t(PU_KEY_LO) * n_slots, uint32_t(ps.key));
+                pool_st(pu + size_t(PU_KEY_HI) * n_slots, uint32_t(ps.key >> 32));
+                pool_st(pu + size_t(PU_PXROW) * n_slots, pxrow);
+                pool_st(pu + size_t(PU_S) * n_slots, smp);
+                pool_st(pu + size_t(PU_SEND) * n_slots, smp_end);
+                pool_st(pu + size_t(PU_JOB_LO) * n_slots, uint32_t(job));
+                pool_st(pu + size_t(PU_JOB_HI) * n_slots, uint32_t(job >> 32));
+                pool_st(pr + size_t(PR_AX) * n_slots, acc.x); pool_st(pr + size_t(PR_AY) * n_slots, acc.y); pool_st(pr + size_t(PR_AZ) * n_slots, acc.z);
                 emit = true;
             }
             const unsigned long long em = __ballot(emit);
             if (emit) { // the slot's next ray: path state back to memory, ray onto the queue
-                pr[size_t(PR_OX) * n_slots] = ps.ray.o.x; pr[size_t(PR_OY) * n_slots] = ps.ray.o.y; pr[size_t(PR_OZ) * n_slots] = ps.ray.o.z;
-                pr[size_t(PR_DX) * n_slots] = ps.ray.d.x; pr[size_t(PR_DY) * n_slots] = ps.ray.d.y; pr[size_t(PR_DZ) * n_slots] = ps.ray.d.z;
-                if constexpr (!decltype(cnt)::NO_TIME) pr[size_t(PR_TIME) * n_slots] = ps.ray.time;
-                pr[size_t(PR_TX) * n_slots] = ps.throughput.x; pr[size_t(PR_TY) * n_slots] = ps.throughput.y; pr[size_t(PR_TZ) * n_slots] = ps.throughput.z;
-                pu[size_t(PU_BOUNCE) * n_slots] = ps.bounce;
+                pool_st(pr + size_t(PR_TX) * n_slots, ps.throughput.x); pool_st(pr + size_t(PR_TY) * n_slots, ps.throughput.y); pool_st(pr + size_t(PR_TZ) * n_slots, ps.throughput.z);
+                pool_st(pu + size_t(PU_BOUNCE) * n_slots, ps.bounce);
                 const uint32_t idx = ray_n + uint32_t(__popcll(em & lanes_below));
-                rq_f[0u * QCAP + idx] = ps.ray.o.x; rq_f[1u * QCAP + idx] = ps.ray.o.y; rq_f[2u * QCAP + idx] = ps.ray.o.z;
-                rq_f[3u * QCAP + idx] = ps.ray.d.x; rq_f[4u * QCAP + idx] = ps.ray.d.y; rq_f[5u * QCAP + idx] = ps.ray.d.z;
-                if constexpr (!decltype(cnt)::NO_TIME) rq_f[6u * QCAP + idx] = ps.ray.time;
+                ra[0u * SLOTS_PER_WAVE + hslot] = ps.ray.o.x; ra[1u * SLOTS_PER_WAVE + hslot] = ps.ray.o.y; ra[2u * SLOTS_PER_WAVE + hslot] = ps.ray.o.z;
+                ra[3u * SLOTS_PER_WAVE + hslot] = ps.ray.d.x; ra[4u * SLOTS_PER_WAVE + hslot] = ps.ray.d.y; ra[5u * SLOTS_PER_WAVE + hslot] = ps.ray.d.z;
+                if constexpr (!decltype(cnt)::NO_TIME) ra[6u * SLOTS_PER_WAVE + hslot] = ps.ray.time;
                 rq_slot[idx] = uint8_t(hslot);
             }
             ray_n += uint32_t(__popcll(em));
@@ -384,11 +402,11 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
             const uint32_t rank = uint32_t(__popcll(nm & lanes_below));
             if (!has_ray && rank < take) {
                 const uint32_t e = ray_n - 1u - rank;
-                wray.o = V3<R>(rq_f[0u * QCAP + e], rq_f[1u * QCAP + e], rq_f[2u * QCAP + e]);
-                wray.d = V3<R>(rq_f[3u * QCAP + e], rq_f[4u * QCAP + e], rq_f[5u * QCAP + e]);
-                if constexpr (!decltype(cnt)::NO_TIME) wray.time = rq_f[6u * QCAP + e];
-                else wray.time = R(0);
                 slot = rq_slot[e];
+                wray.o = V3<R>(ra[0u * SLOTS_PER_WAVE + slot], ra[1u * SLOTS_PER_WAVE + slot], ra[2u * SLOTS_PER_WAVE + slot]);
+                wray.d = V3<R>(ra[3u * SLOTS_PER_WAVE + slot], ra[4u * SLOTS_PER_WAVE + slot], ra[5u * SLOTS_PER_WAVE + slot]);
+                if constexpr (!decltype(cnt)::NO_TIME) wray.time = ra[6u * SLOTS_PER_WAVE + slot];
+                else wray.time = R(0);
                 cnt.ray();
                 trav_begin(tr, sc, wray, stack);
                 has_ray = true;

@@ -204,7 +204,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             auto kernel = count ? (gen ? trace_kernel<R, true, SHAPES_GENERAL> : trace_kernel<R, true, SHAPES_FAST>)
                                 : (gen ? trace_kernel<R, false, SHAPES_GENERAL>
                                        : (no_inst ? (no_time ? trace_kernel<R, false, SHAPES_NONE_NT> : trace_kernel<R, false, SHAPES_NONE>) : trace_kernel<R, false, SHAPES_FAST>));
-            const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth)) * (TRACE_BLOCK / 64);
+            const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth, !count && !gen && no_inst && no_time)) * (TRACE_BLOCK / 64);
             size_t grid = 1;
             if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
             const size_t n_slots = grid * (TRACE_BLOCK / 64) * SLOTS_PER_WAVE;

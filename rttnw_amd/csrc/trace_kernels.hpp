@@ -179,8 +179,14 @@ template <typename T, typename V> __device__ __forceinline__ void pool_st(T* p, 
 #endif
 }
 constexpr int TRACE_BLOCK = 256;
-constexpr uint32_t SLOTS_PER_WAVE = 128; // paths owned by one wave64: 64 being traversed + up to 64 queued
-constexpr uint32_t QCAP = 128;           // capacity of a wave's ray queue and hit queue (entries)
+#ifndef RT_SLOTS
+#define RT_SLOTS 128
+#endif
+#ifndef RT_WAVE_LEAN_BLOCKS
+#define RT_WAVE_LEAN_BLOCKS 3
+#endif
+constexpr uint32_t SLOTS_PER_WAVE = RT_SLOTS; // paths owned by one wave64: 64 being traversed + up to 64 queued
+constexpr uint32_t QCAP = RT_SLOTS;           // capacity of a wave's ray queue and hit queue (entries)
 static_assert(QCAP == SLOTS_PER_WAVE, "a slot has at most one ray or hit in flight: the queues never hold more entries than the wave has slots");
 
 // Path state of a slot, in global memory (L2-resident), struct-of-arrays over all slots of the launch.
@@ -201,9 +207,9 @@ enum : uint32_t { PU_KEY_LO = 0, PU_KEY_HI, PU_BOUNCE, PU_PXROW, PU_S, PU_SEND, 
 #define RT_WAVE_LDS_PAD 0 // experiments: unused bytes per wave (where the LDS stops holding three blocks per CU)
 #endif
 template <typename R> __host__ __device__ constexpr uint32_t wave_stack_entries() { return sizeof(R) == 8 ? uint32_t(RT_F64_WAVE_STACK) : LDS_STACK_ENTRIES; }
-template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth) {
+template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint32_t stack_depth, bool no_time = false) {
     // ray queue (7 reals) + hit t | hit prim, inst, meta (words) | ray slot (bytes) | stack: + the spare slot
-    return 8u * QCAP * uint32_t(sizeof(R)) + 3u * QCAP * 4u + QCAP + (wave_stack_entries<R>() + 1u) * 64u * 4u + RT_WAVE_LDS_PAD;
+    return (no_time ? 7u : 8u) * QCAP * uint32_t(sizeof(R)) + 3u * QCAP * 4u + QCAP + (wave_stack_entries<R>() + 1u) * 64u * 4u + RT_WAVE_LDS_PAD;
 }
 constexpr uint32_t LDS_GRANULE_BYTES = 1280u, LDS_BYTES_PER_CU = 160u * 1024u; // gfx950: 128 granules per CU
 __host__ __device__ constexpr uint32_t lds_blocks_per_cu(uint32_t block_bytes) {
@@ -212,7 +218,8 @@ __host__ __device__ constexpr uint32_t lds_blocks_per_cu(uint32_t block_bytes) {
 static_assert(RT_WAVE_LDS_PAD != 0 || lds_blocks_per_cu(wave_lds_bytes<double>(0) * 4u) >= 3u, "the f64 decoupled kernel's block must fit a CU's LDS three times");
 static_assert(lds_blocks_per_cu(wave_lds_bytes<float>(0) * 4u) >= 3u, "the f32 decoupled kernel's block must fit a CU's LDS three times");
 template <typename R> __host__ __device__ constexpr bool wave_walks_quantised() { return RT_WAVE_QUANT == 2 || (RT_WAVE_QUANT == 1 && sizeof(R) == 8); }
-constexpr uint32_t HIT_FRESH = 0x80u; // hit-queue meta: slot (7 bits) | FRESH | box face << 8
+constexpr uint32_t HIT_FRESH = 0x100u; // hit-queue meta: slot (8 bits) | FRESH | box face << 9
+static_assert(SLOTS_PER_WAVE <= 256u, "slot numbers travel as bytes");
 
 // The per-pixel sample loop of main.rs:202-229 as ONE persistent kernel in which PATHS ARE DECOUPLED FROM LANES.
 //
@@ -249,7 +256,7 @@ static_assert(alignof(SceneView<float>) <= 8 && alignof(CameraRec<double>) <= 8 
 template <typename R, bool COUNT, int GENERAL> // GENERAL: SHAPES_FAST (0) / SHAPES_GENERAL (1) / SHAPES_NONE (2: the scene has no instance record, rt_core.hpp)
 // (at least 3 waves/SIMD: 170 VGPRs — the f32 code needs 164; the f64 code, allowed 256, ran at 2 waves/SIMD and waited on
 // the fabric: spheres_1m f64 167 -> 264 Msamples/s with 140 registers spilled; 4 waves/SIMD: 205)
-__global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+__global__ __launch_bounds__(TRACE_BLOCK, GENERAL == SHAPES_NONE_NT ? RT_WAVE_LEAN_BLOCKS : 3) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,
@@ -257,12 +264,12 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
     extern __shared__ __align__(16) unsigned char lds_raw[];
     typename CounterSel<COUNT, GENERAL>::type cnt;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    unsigned char* wbase = lds_raw + wave_in_block * wave_lds_bytes<R>(rc.stack_depth);
+    unsigned char* wbase = lds_raw + wave_in_block * wave_lds_bytes<R>(rc.stack_depth, decltype(cnt)::NO_TIME);
     // RAY ARENA [7][SLOTS_PER_WAVE]: o.xyz, d.xyz, time of every slot's current ray, INDEXED BY SLOT — written when the ray is emitted, read by the lane
     // that walks it and again by the shade of its hit; the queues carry slot numbers only.  (Rounds 2-4 queued the ray by queue position and kept a copy
     // in the slot's global state for the shade to read back: 2 x 7 of a slot's 13 reals per bounce, and this kernel waits on L2-miss lines.)
     R* const ra = reinterpret_cast<R*>(wbase);
-    R* const hq_t = ra + 7u * SLOTS_PER_WAVE;               // hit queue: t
+    R* const hq_t = ra + (decltype(cnt)::NO_TIME ? 6u : 7u) * SLOTS_PER_WAVE; // hit queue: t
     int32_t* const hq_prim = reinterpret_cast<int32_t*>(hq_t + QCAP);
     int32_t* const hq_inst = hq_prim + QCAP;
     uint32_t* const hq_meta = reinterpret_cast<uint32_t*>(hq_inst + QCAP);
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
 
     // every slot starts out needing its first job
     hq_meta[lane] = lane | HIT_FRESH;
-    hq_meta[lane + 64u] = (lane + 64u) | HIT_FRESH;
+    for (uint32_t i = lane + 64u; i < SLOTS_PER_WAVE; i += 64u) hq_meta[i] = i | HIT_FRESH;
     uint32_t ray_n = 0, hit_n = SLOTS_PER_WAVE; // wave-uniform queue fill levels
     unsigned long long batch_next = 0, batch_end = 0; // the wave's reserved batch of job indices
 
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
             const uint32_t e = hit_n - 1u - (on ? lane : 0u);
             hit_n -= m;
             const uint32_t meta = on ? hq_meta[e] : HIT_FRESH;
-            const uint32_t hslot = meta & 0x7Fu;
+            const uint32_t hslot = meta & 0xFFu;
             const bool fresh = (meta & HIT_FRESH) != 0u;
             const size_t g = gbase + hslot;
             R* const pr = pool_r + g;
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                 HitRef best;
                 best.prim = hq_prim[e];
                 best.inst = hq_inst[e];
-                best.aux = int32_t((meta >> 8) & 7u);
+                best.aux = int32_t((meta >> 9) & 7u);
                 const bool found = ref_kind(best.prim) != PRIM_NONE;
                 // (scene view and constants re-read from the kernarg segment: the traversal loop keeps only the pointers it uses)
                 if (path_shade(ps, kernarg_reload<SceneView<R>>(offsetof(TraceArgsHead<R>, sc)), kernarg_reload<RenderConsts>(offsetof(TraceArgsHead<R>, rc)), background, t_min,
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(TRACE_BLOCK, 3) void trace_kernel(SceneView<R> sc, 
                 hq_t[idx] = tr.closest;
                 hq_prim[idx] = tr.found ? tr.best.prim : make_ref(PRIM_NONE, 0);
                 hq_inst[idx] = tr.best.inst;
-                hq_meta[idx] = slot | (uint32_t(tr.best.aux) << 8);
+                hq_meta[idx] = slot | (uint32_t(tr.best.aux) << 9);
                 has_ray = false;
             }
             hit_n += uint32_t(__popcll(fm));

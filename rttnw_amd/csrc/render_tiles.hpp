@@ -92,7 +92,10 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     // (round 5 — asynchronous shade phases in the lane-owns-path kernel, the f64 decoupled kernel at three blocks per CU: f32 9.9 k nodes 5441 / 5350,
     // 15.4 k 4180 / 4483, 19.6 k 3400 / 3911; f64 9.9 k 5168 / 4898, 15.4 k 3960 / 4153, 19.6 k 3166 / 3667; RTTNW_F64_STRICT 15.4 k 4015 / 4110 —
     // profiles/r05/README.md: both cross at ~13 k records)
-    bool plain = flat.total_nodes4() < 13000u;
+    // (later in round 5 — the decoupled kernel keeps a slot's ray in LDS, +5 .. 9 %: f32 5.7 k nodes 7216 / 7620, 7.6 k 6101 / 6840, 9.9 k 5410 / 6371; f64
+    // 5.7 k 6974 / 6577, 7.6 k 5919 / 5817, 9.9 k 5150 / 5318, 15.4 k 3941 / 4450; RTTNW_F64_STRICT 7.6 k 5945 / 5783, 9.9 k 5195 / 5224: f32 crosses
+    // at ~5 k records, f64 at ~9 k)
+    bool plain = flat.total_nodes4() < (sizeof(R) == 4 ? 5000u : 9000u);
     if (kv && (std::strcmp(kv, "plain") == 0 || std::strcmp(kv, "plainglobal") == 0)) plain = true;
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     if (!prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));

@@ -385,7 +385,7 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
 
 @pytest.mark.parametrize("precision", [abi.F64_STRICT, abi.F32], ids=["f64strict", "f32"])
 def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib, precision):
-    """A scene beyond the measured crossover (13 000 four-wide nodes, both precisions: render_tiles.hpp) selects the decoupled kernel by itself; it
+    """A scene beyond the measured crossover (5 000 four-wide nodes in f32, 9 000 in f64: render_tiles.hpp) selects the decoupled kernel by itself; it
     must agree with the forced lane-owns-path form: bit for bit in the strict build; in f32 (-ffp-contract=fast: the two kernels may fuse a
     multiply-add differently, and this scene multiplies a last-place difference ~100x per bounce) as two renders of the same image — the pixels
     whose paths never left the first bounce identical, the frame's mean within 1 %."""

@@ -100,16 +100,17 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
     if (kv && std::strcmp(kv, "wave") == 0) plain = false;
     if (!prepare_only) HIP_TRY(hipMemsetAsync(d->job_counter, 0, sizeof(unsigned long long) + sizeof(DeviceCounters), stream));
     DeviceCounters* dc = reinterpret_cast<DeviceCounters*>(d->job_counter + 1);
-    auto persistent_grid = [&](const void* kernel, size_t lds_bytes, size_t waves_needed, size_t& grid) -> int {
+    auto persistent_grid = [&](const void* kernel, size_t lds_bytes, size_t waves_needed, size_t& grid, int block = TRACE_BLOCK) -> int {
         if (lds_bytes > 160 * 1024) { set_last_error("render: queues + traversal stacks do not fit in LDS"); return RTTNW_ERR_UNSUPPORTED; }
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_bytes)));
         int blocks_per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, TRACE_BLOCK, lds_bytes));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block, lds_bytes));
         // (the runtime's answer counts LDS in finer units than the hardware allocates it in: trace_kernels.hpp lds_blocks_per_cu)
         blocks_per_cu = std::max(1, std::min(std::min(blocks_per_cu, 8), int(lds_blocks_per_cu(uint32_t(lds_bytes)))));
         // what the chip holds at once (no inter-workgroup dependency, so a little over-subscription is harmless),
         // but never more waves than there is work for
-        grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + 3) / 4));
+        const size_t waves_per_block = size_t(block) / 64;
+        grid = std::max<size_t>(1, std::min<size_t>(size_t(d->num_cus) * blocks_per_cu, (waves_needed + waves_per_block - 1) / waves_per_block));
         return 0;
     };
     // stack entries beyond the LDS-resident ones, for every thread of a launch
@@ -207,15 +208,20 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             auto kernel = count ? (gen ? trace_kernel<R, true, SHAPES_GENERAL> : trace_kernel<R, true, SHAPES_FAST>)
                                 : (gen ? trace_kernel<R, false, SHAPES_GENERAL>
                                        : (no_inst ? (no_time ? trace_kernel<R, false, SHAPES_NONE_NT> : trace_kernel<R, false, SHAPES_NONE>) : trace_kernel<R, false, SHAPES_FAST>));
-            const size_t lds_bytes = size_t(wave_lds_bytes<R>(rc.stack_depth, !count && !gen && no_inst && no_time)) * (TRACE_BLOCK / 64);
+            // (the LEAN flavour: ONE block per CU of as many waves as its LDS holds — 13 in f64, where three 4-wave blocks make 12; RTTNW_WAVE_BLOCK=<threads>: experiments)
+            const bool lean_kernel = !count && !gen && no_inst && no_time;
+            const uint32_t wave_bytes = wave_lds_bytes<R>(rc.stack_depth, lean_kernel);
+            int wblock = lean_kernel ? int(wave_block_waves(wave_bytes)) * 64 : TRACE_BLOCK;
+            if (const char* e = getenv("RTTNW_WAVE_BLOCK")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0 && v <= (lean_kernel ? 1024 : TRACE_BLOCK)) wblock = v; }
+            const size_t lds_bytes = size_t(wave_bytes) * size_t(wblock / 64);
             size_t grid = 1;
-            if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid)) return g;
-            const size_t n_slots = grid * (TRACE_BLOCK / 64) * SLOTS_PER_WAVE;
+            if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid, wblock)) return g;
+            const size_t n_slots = grid * size_t(wblock / 64) * SLOTS_PER_WAVE;
             if (int g = grow(&d->pool_r, &d->pool_r_bytes, n_slots * PR_COUNT * sizeof(R))) return g;
             if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
-            if (int g = grow_spill(grid * size_t(TRACE_BLOCK), wave_stack_entries<R>())) return g;
+            if (int g = grow_spill(grid * size_t(wblock), wave_stack_entries<R>())) return g;
             if (n_jobs > 0 && !prepare_only) {
-                hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(TRACE_BLOCK), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
+                hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(uint32_t(wblock)), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
                                    R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
                                    (uint32_t*)d->pool_u, uint32_t(n_slots), (int32_t*)d->spill);
                 HIP_TRY(hipGetLastError());

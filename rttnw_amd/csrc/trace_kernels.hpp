@@ -182,9 +182,6 @@ constexpr int TRACE_BLOCK = 256;
 #ifndef RT_SLOTS
 #define RT_SLOTS 128
 #endif
-#ifndef RT_WAVE_LEAN_BLOCKS
-#define RT_WAVE_LEAN_BLOCKS 3
-#endif
 constexpr uint32_t SLOTS_PER_WAVE = RT_SLOTS; // paths owned by one wave64: 64 being traversed + up to 64 queued
 constexpr uint32_t QCAP = RT_SLOTS;           // capacity of a wave's ray queue and hit queue (entries)
 static_assert(QCAP == SLOTS_PER_WAVE, "a slot has at most one ray or hit in flight: the queues never hold more entries than the wave has slots");
@@ -214,6 +211,12 @@ template <typename R> __host__ __device__ constexpr uint32_t wave_lds_bytes(uint
 constexpr uint32_t LDS_GRANULE_BYTES = 1280u, LDS_BYTES_PER_CU = 160u * 1024u; // gfx950: 128 granules per CU
 __host__ __device__ constexpr uint32_t lds_blocks_per_cu(uint32_t block_bytes) {
     return block_bytes == 0u ? 1024u : LDS_BYTES_PER_CU / ((block_bytes + LDS_GRANULE_BYTES - 1u) / LDS_GRANULE_BYTES * LDS_GRANULE_BYTES);
+}
+// waves of ONE block that fills a CU (the LEAN flavour of the decoupled kernel): as many as the CU's LDS granules hold, at most 16 (4 per SIMD)
+__host__ __device__ constexpr uint32_t wave_block_waves(uint32_t wave_bytes) {
+    uint32_t n = 16u;
+    while (n > 4u && (n * wave_bytes + LDS_GRANULE_BYTES - 1u) / LDS_GRANULE_BYTES > LDS_BYTES_PER_CU / LDS_GRANULE_BYTES) --n;
+    return n;
 }
 static_assert(RT_WAVE_LDS_PAD != 0 || lds_blocks_per_cu(wave_lds_bytes<double>(0) * 4u) >= 3u, "the f64 decoupled kernel's block must fit a CU's LDS three times");
 static_assert(lds_blocks_per_cu(wave_lds_bytes<float>(0) * 4u) >= 3u, "the f32 decoupled kernel's block must fit a CU's LDS three times");
@@ -256,7 +259,9 @@ static_assert(alignof(SceneView<float>) <= 8 && alignof(CameraRec<double>) <= 8 
 template <typename R, bool COUNT, int GENERAL> // GENERAL: SHAPES_FAST (0) / SHAPES_GENERAL (1) / SHAPES_NONE (2: the scene has no instance record, rt_core.hpp)
 // (at least 3 waves/SIMD: 170 VGPRs — the f32 code needs 164; the f64 code, allowed 256, ran at 2 waves/SIMD and waited on
 // the fabric: spheres_1m f64 167 -> 264 Msamples/s with 140 registers spilled; 4 waves/SIMD: 205)
-__global__ __launch_bounds__(TRACE_BLOCK, GENERAL == SHAPES_NONE_NT ? RT_WAVE_LEAN_BLOCKS : 3) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
+// (the LEAN flavour — 127-129 registers in f64, ~110 in f32 — may be launched as ONE block per CU of as many waves as the CU's LDS holds, wave_block_waves():
+// its waves never synchronise with each other, so a block is only a unit of LDS allocation, and 13 f64 waves fit where three 4-wave blocks hold 12)
+__global__ __launch_bounds__(GENERAL == SHAPES_NONE_NT ? 1024 : TRACE_BLOCK, GENERAL == SHAPES_NONE_NT ? 1 : 3) void trace_kernel(SceneView<R> sc, CameraRec<R> cam, RenderConsts rc, R bg_r, R bg_g,
                                                             R bg_b, R t_min, R* __restrict__ partial,
                                                             unsigned long long* __restrict__ job_counter,
                                                             DeviceCounters* __restrict__ counters, R* __restrict__ pool_r,
@@ -276,10 +281,10 @@ __global__ __launch_bounds__(TRACE_BLOCK, GENERAL == SHAPES_NONE_NT ? RT_WAVE_LE
     uint8_t* const rq_slot = reinterpret_cast<uint8_t*>(hq_meta + QCAP); // (slots are 0 .. 127: a byte each)
     typename std::conditional<wave_walks_quantised<R>(), LdsStackQuant4<64, wave_stack_entries<R>()>, LdsStack<64, wave_stack_entries<R>()>>::type stack;
     stack.base = (LdsIntPtr)(reinterpret_cast<int32_t*>(rq_slot + QCAP) + lane);
-    stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * TRACE_BLOCK + threadIdx.x));
-    stack.spill_stride = gridDim.x * TRACE_BLOCK;
+    stack.spill = (GlobalIntPtr)(spill + (blockIdx.x * blockDim.x + threadIdx.x));
+    stack.spill_stride = gridDim.x * blockDim.x;
 
-    const uint32_t wave_global = blockIdx.x * (TRACE_BLOCK / 64) + wave_in_block;
+    const uint32_t wave_global = blockIdx.x * (blockDim.x / 64u) + wave_in_block;
     const size_t gbase = size_t(wave_global) * SLOTS_PER_WAVE;
     const unsigned long long n_jobs = rc.n_jobs;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;

@@ -407,6 +407,22 @@ def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib, precision):
         assert differ <= 0.25 and abs(lin.mean() - lin2.mean()) <= 0.01 * lin.mean(), (differ, lin.mean(), lin2.mean())
 
 
+@pytest.mark.parametrize("precision", [abi.F64_STRICT, abi.F64, abi.F32], ids=["f64strict", "f64", "f32"])
+def test_decoupled_lean_flavour_does_not_depend_on_its_block_size(gpu, scenes_lib, precision, monkeypatch):
+    """The LEAN flavour of the decoupled kernel (render_tiles.hpp: no moving sphere, no medium, solid colours — rttnw_stats.reserved bit 5) is launched
+    as ONE block per CU of as many waves as the CU's LDS holds (13 in f64, 16 in f32); its waves never synchronise, so the image cannot depend on the
+    block: 256-thread blocks (what the other flavours use) and a lone wave per block render the same bytes, in every precision."""
+    sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=60000)
+    cam, p = util.params_for(setup, 96, 64, 6, precision=precision, seed=5)
+    lin, rgba, st = gpu_render(gpu, sc, cam, p)
+    assert (st.reserved & 1) == 1 and (st.reserved & 8) != 0 and (st.reserved & 32) != 0, st.reserved
+    for block in ("256", "64", "832"):
+        monkeypatch.setenv("RTTNW_WAVE_BLOCK", block)
+        lin2, rgba2, st2 = gpu_render(gpu, sc, cam, p)
+        assert st2.reserved == st.reserved
+        assert np.array_equal(lin, lin2) and np.array_equal(rgba, rgba2), block
+
+
 def test_progressive_passes_compose(gpu, scenes_lib, earth):
     """rttnw_params.sample_begin on the device: K passes over disjoint sample ranges average to the single render."""
     sc, setup = util.build(gpu, scenes_lib, "final_scene", earth)

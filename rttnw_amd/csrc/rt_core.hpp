@@ -10,6 +10,7 @@
 #pragma once
 #include "rt_types.hpp"
 #include <math.h>
+#include <stddef.h>
 
 #ifndef RT_NODE_STEPS
 #define RT_NODE_STEPS 2 // node steps per trip round the walk loop (closest_solid)
@@ -686,6 +687,103 @@ RT_HD bool box_t(const BoxRec<R>& bx, const Ray<R>& ray, R t_min, R t_max, R& t_
     return any;
 }
 
+// Cube::hit with ONE exact quotient instead of six, where that is provably the same (round 5).  The six rectangle tests of box_t answer "which face
+// does the ray meet first inside [t_min, closest]"; for a ray that is clear of the box's edges the only face that can is known from the walk's own f32
+// plane distances (SlabRay: the constants of the node steps), and only that face's t has to be the reference's: t = (k - o) / d, the same expression
+// on the same operands, with the two range tests run on it exactly.  With N_k / F_k the near / far plane distances of axis k (approximate: |error| <=
+// 3e-7 (|t| + |o / d|), the bound derived at SlabRay<double>), tn = max N, tf = min F, N2 / F2 the second largest / smallest, and a gap
+// g = BOX_FAST_MARGIN x (sum |o_k / d_k| + |tn| + |tf|):
+//   * no face can hit when tn - tf >= g (the line passes the box: every face's point lies outside another axis' slab by g), when t_min - tf >= g
+//     (the box ends before t_min) or when tn - closest >= g (it begins beyond the incumbent);
+//   * ENTRY — tn - t_min >= g, tn - N2 >= g, tf - tn >= g: the entry face's point is inside both other slabs by g (its extents test is TRUE), every
+//     other front face's point is outside the entry axis' slab by g (FALSE), every back face lies beyond by g (a larger t: cannot win, cannot tie):
+//     the entry face if its exact t passes the two range tests, nothing otherwise;
+//   * EXIT — t_min - tn >= g (every front face's t is below t_min: the origin is inside, or ON the face it has just scattered off), F2 - tf >= g,
+//     tf - tn >= g: the exit face's point is inside the other slabs by g (TRUE), the other back faces' points outside the exit axis' slab by g
+//     (FALSE): the exit face if its exact t is in range — the ray leaving the cube it scattered off has t ~ 1e-14 < t_min there: nothing.
+// A gap of g in t is |d_a| g >= MARGIN (|o_a| + |t d_a|) in the coordinate the extents test compares — 10^11 times the rounding error of evaluating
+// o_a + t d_a in f64 (2^-52 of the same sum), 60 times the f32 error of the plane distances themselves.  Everything else — a ray within g of an
+// edge, an entry within g of t_min, any NaN / infinity (axis-parallel rays: S is not finite, no comparison holds) — takes box_t.  `face` as box_t.
+// tests/test_core_parity_cpu.py::test_fast_cube_test_is_the_six_rectangle_test holds the two to the same (hit, t, face) bit for bit.
+#ifndef RT_BOX_FAST
+#define RT_BOX_FAST 1
+#endif
+#ifndef RT_BOX_FAST_MARGIN
+#define RT_BOX_FAST_MARGIN 2e-5f
+#endif
+RT_HD float rt_med3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c));
+#endif
+}
+template <typename R> RT_HD float slab_inv32(const SlabRay<R>& sr, int a) {
+    if constexpr (sizeof(R) == 8) return sr.inv[a];
+    else return a == 0 ? sr.inv.x : (a == 1 ? sr.inv.y : sr.inv.z);
+}
+// returns 0: certainly no face hits; 1: the only face that can is (axis, use_mx), and its extents test is true; 2: not certain (box_t decides)
+template <typename R>
+RT_HD int box_classify(const BoxRec<R>& bx, const Ray<R>& ray, const SlabRay<R>& sr, R t_min, R t_max, int& axis, bool& use_mx) {
+    const R o[3] = {ray.o.x, ray.o.y, ray.o.z};
+    float nr[3], fr[3], S = 0.f;
+    bool ng[3]; // (no array is indexed by a run-time axis below: that would put it — and the walk's state around it — in scratch)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = slab_inv32(sr, a);
+        float oi;
+        if constexpr (sizeof(R) == 8) oi = sr.oinv[a]; else oi = float(o[a]) * inv;
+        const float t0 = __builtin_fmaf(float(bx.mn[a]), inv, -oi), t1 = __builtin_fmaf(float(bx.mx[a]), inv, -oi);
+        const bool neg = inv < 0.f;
+        ng[a] = neg;
+        nr[a] = neg ? t1 : t0;
+        fr[a] = neg ? t0 : t1;
+        S += rt_fabs(oi);
+    }
+    const float tn = rt_max(rt_max(nr[0], nr[1]), nr[2]), tf = rt_min(rt_min(fr[0], fr[1]), fr[2]);
+    const float n2 = rt_med3(nr[0], nr[1], nr[2]), f2 = rt_med3(fr[0], fr[1], fr[2]);
+    const float g = (S + rt_fabs(tn) + rt_fabs(tf)) * RT_BOX_FAST_MARGIN;
+    const float lo = float(t_min), hi = float(t_max);
+    if (tn - tf >= g || lo - tf >= g || tn - hi >= g) return 0;
+    if (!(tf - tn >= g)) return 2;
+    if (tn - lo >= g) { // the entry face, or nothing
+        if (!(tn - n2 >= g)) return 2;
+        axis = nr[0] >= nr[1] ? (nr[0] >= nr[2] ? 0 : 2) : (nr[1] >= nr[2] ? 1 : 2);
+        use_mx = axis == 0 ? ng[0] : (axis == 1 ? ng[1] : ng[2]);
+        return 1;
+    }
+    if (lo - tn >= g && f2 - tf >= g) { // the exit face, or nothing
+        axis = fr[0] <= fr[1] ? (fr[0] <= fr[2] ? 0 : 2) : (fr[1] <= fr[2] ? 1 : 2);
+        use_mx = !(axis == 0 ? ng[0] : (axis == 1 ? ng[1] : ng[2]));
+        return 1;
+    }
+    return 2;
+}
+// (`bx`: the record WHERE IT LIES — LDS or global memory: the classification reads its six bounds once and keeps them as floats, the exact quotient
+// reads the one bound it needs by index, the rare undecided ray leaves the whole record to box_t: no copy of it is held in registers)
+template <typename R>
+RT_HD bool box_t_fast(const BoxRec<R>& bx, const Ray<R>& ray, const SlabRay<R>& sr, R t_min, R t_max, R& t_out, int& face) {
+    int axis = 0;
+    bool use_mx = false;
+    const int verdict = box_classify(bx, ray, sr, t_min, t_max, axis, use_mx);
+    if (verdict == 2) { const BoxRec<R> whole = bx; return box_t(whole, ray, t_min, t_max, t_out, face); }
+    if (verdict == 0) return false;
+    // (components copied into scalars first: a conditional on member lvalues is a pointer select into the ray — see rect_t)
+    const R ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+    const R ok = axis == 0 ? ox : (axis == 1 ? oy : oz);
+    const R dk = axis == 0 ? dx : (axis == 1 ? dy : dz);
+    static_assert(offsetof(BoxRec<R>, mx) == 3 * sizeof(R), "mn[3] then mx[3]");
+    const R k = (&bx.mn[0])[axis + (use_mx ? 3 : 0)]; // (a load by index from the record in memory, not a register select)
+    R t, unused;
+    rt_div2(k - ok, k - ok, dk, t, unused); // (the quotient box_t makes for this face: Rectangle::hit's t, hittable.rs:504)
+    const bool hit = !(t < t_min) & !(t > t_max);
+    if (hit) {
+        t_out = t;
+        face = 2 * (2 - axis) + (use_mx ? 1 : 0); // box_t's numbering: xy@min.z, xy@max.z, xz@min.y, xz@max.y, yz@min.x, yz@max.x
+    }
+    return hit;
+}
+
 template <typename R> RT_HD const InstanceHead<R>& head_of(const InstanceRec<R>& in) { return reinterpret_cast<const InstanceHead<R>&>(in); }
 
 // Ray -> object space through the ops of an instance (Translate::hit :600-604, YRotate::hit :687-697): a chain of up to
@@ -815,12 +913,16 @@ template <typename R> RT_HD void rect_ab(int plane, const Ray<R>& ray, R t, R& a
 }
 
 // One primitive, t only (+ `aux`: the winning face of a box).  `ray` is in the primitive's space.
-template <bool NO_TIME = false, typename R>
-RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray<R>& ray, R t_min, R t_max, R& t, int& aux) {
+// (HAVE_SR: `sr` holds the walk's slab constants and `ray` is the ray they were made from — the fast cube test reads its plane distances off them)
+template <bool NO_TIME, bool HAVE_SR, typename R>
+RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray<R>& ray, R t_min, R t_max, R& t, int& aux, const SlabRay<R>& sr) {
     if (kind == PRIM_SPHERE) {
         SphereRec<R> s = sc.spheres[idx];
         return sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, ray, t_min, t_max, t);
     } else if (kind == PRIM_BOX) {
+#if RT_BOX_FAST
+        if constexpr (HAVE_SR) return box_t_fast(sc.boxes[idx], ray, sr, t_min, t_max, t, aux);
+#endif
         const BoxRec<R> bx = sc.boxes[idx];
         return box_t(bx, ray, t_min, t_max, t, aux);
     } else if (kind == PRIM_RECT) {
@@ -832,6 +934,10 @@ RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray
         return sphere_t(moving_center(m, ray.time), m.r, ray, t_min, t_max, t);
     }
     return false;
+}
+template <bool NO_TIME = false, typename R>
+RT_HD bool prim_t(const SceneView<R>& sc, uint32_t kind, uint32_t idx, const Ray<R>& ray, R t_min, R t_max, R& t, int& aux) {
+    return prim_t<NO_TIME, false>(sc, kind, idx, ray, t_min, t_max, t, aux, SlabRay<R>());
 }
 
 // Sequence number of a primitive record (tie-break only; see rt_types.hpp).
@@ -1100,7 +1206,8 @@ template <bool G, typename R> RT_HD bool sphere_wc_t(const SceneView<R>& sc, uin
     const Ray<R> obj = to_object<G>(in, wray);
     return sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, obj, t_min, t_max, t);
 }
-template <bool G = false, bool NO_TIME = false, typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
+// FRAME_RAY: `ray` is the ray of the walk's current frame — the one tr.sr was made from
+template <bool G = false, bool NO_TIME = false, bool FRAME_RAY = false, typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
     R t;
     int aux = 0;
     bool hit;
@@ -1110,7 +1217,7 @@ template <bool G = false, bool NO_TIME = false, typename R> RT_HD void trav_test
         kind = PRIM_SPHERE; // the hit reference names the copy's record: make_record finds the object-space one from it
     } else
 #endif
-    hit = prim_t<NO_TIME>(sc, kind, idx, ray, t_min, tr.closest, t, aux);
+    hit = prim_t<NO_TIME, FRAME_RAY>(sc, kind, idx, ray, t_min, tr.closest, t, aux, tr.sr);
     if (hit) {
         // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
         const bool loses_tie = tr.found && t == tr.closest &&
@@ -1156,12 +1263,12 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     if constexpr (WHOLE_LEAF) {
         for (uint32_t k = 0; k < count; ++k) {
             cnt.prim();
-            trav_test_record<Cnt::GENERAL, Cnt::NO_TIME>(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+            trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, true>(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         }
         trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
-        trav_test_record<Cnt::GENERAL, Cnt::NO_TIME>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+        trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, true>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }
 }

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -515,6 +516,80 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
     }
 }
 
+// The fast cube test (rt_core.hpp box_t_fast: one exact quotient where the ray is clear of the box's edges) against the six-rectangle test it
+// replaces (box_t), on n generated cases in the host build's arithmetic (IEEE, nothing contracted = the reference's): random boxes from 1e-3 to 1e4,
+// origins far, near, ON a face plane (the ray that has just scattered off the cube) and inside; directions at the box, at its corners / edges /
+// face points displaced by 0 .. 1e-3 of the box, random, axis-parallel; ranges open, or ending / starting at, one ulp off, or 1e-9 off the exact t of
+// a face.  out = {mismatches, verdict 0, verdict 1, verdict 2, hits, index of the first mismatch}.
+template <typename R> static void box_fast_check_t(uint64_t n, uint64_t seed, uint64_t* out) {
+    uint64_t st = (seed ^ 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull; // (streams of different seeds must not be shifts of one another)
+    st = (st ^ (st >> 29)) * 0x94D049BB133111EBull + seed;
+    auto next = [&]() { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    auto uni = [&]() { return double(next() >> 11) * (1.0 / 9007199254740992.0); };
+    auto sym = [&]() { return 2.0 * uni() - 1.0; };
+    const double eps_set[8] = {0.0, 1e-16, 1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-3};
+    out[0] = out[1] = out[2] = out[3] = out[4] = 0; out[5] = ~0ull;
+    for (uint64_t i = 0; i < n; ++i) {
+        const double scale = std::pow(10.0, std::floor(uni() * 7.0) - 3.0);
+        BoxRec<R> bx{};
+        double c[3], h[3];
+        for (int a = 0; a < 3; ++a) {
+            c[a] = sym() * 10.0 * scale;
+            h[a] = scale * std::pow(10.0, uni() * 4.0 - 3.0);
+            bx.mn[a] = R(c[a] - h[a]); bx.mx[a] = R(c[a] + h[a]);
+            if (!(bx.mn[a] < bx.mx[a])) bx.mx[a] = std::nextafter(bx.mn[a], R(1e30));
+        }
+        double o[3], d[3];
+        const uint32_t mode = uint32_t(next() % 10);
+        for (int a = 0; a < 3; ++a) o[a] = c[a] + sym() * scale * std::pow(10.0, uni() * 3.0);
+        if (mode == 6 || mode == 7) { // the origin ON a face plane (exactly, or a few ulps off), the other two coordinates inside or just outside the face
+            const int k = int(next() % 3);
+            for (int a = 0; a < 3; ++a) o[a] = double(bx.mn[a]) + uni() * (double(bx.mx[a]) - double(bx.mn[a])) * (uni() < 0.8 ? 1.0 : 1.3);
+            o[k] = (next() & 1) ? double(bx.mx[k]) : double(bx.mn[k]);
+            if (uni() < 0.3) o[k] += sym() * 1e-15 * std::fabs(o[k]);
+        } else if (mode == 8) { // inside
+            for (int a = 0; a < 3; ++a) o[a] = double(bx.mn[a]) + uni() * (double(bx.mx[a]) - double(bx.mn[a]));
+        }
+        // a target point: per axis at mn, at mx, between, or beside the box; displaced by eps x extent
+        double tg[3];
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t pick = uint32_t(next() % 5);
+            const double lo = double(bx.mn[a]), hi = double(bx.mx[a]);
+            tg[a] = pick == 0 ? lo : pick == 1 ? hi : pick == 4 ? lo + (uni() * 1.6 - 0.3) * (hi - lo) : lo + uni() * (hi - lo);
+            tg[a] += sym() * eps_set[next() % 8] * (hi - lo);
+        }
+        const double len = std::pow(10.0, uni() * 3.0 - 2.0);
+        for (int a = 0; a < 3; ++a) d[a] = (tg[a] - o[a]) * len;
+        if (mode == 6 || mode == 7 || mode == 8) { if (uni() < 0.7) for (int a = 0; a < 3; ++a) d[a] = sym(); }
+        if (mode == 9) { // axis-parallel and nearly axis-parallel rays
+            for (int a = 0; a < 3; ++a) if (uni() < 0.5) d[a] = uni() < 0.5 ? 0.0 : d[a] * 1e-12;
+        }
+        if (d[0] == 0 && d[1] == 0 && d[2] == 0) d[2] = 1.0;
+        Ray<R> ray;
+        ray.o = V3<R>(R(o[0]), R(o[1]), R(o[2])); ray.d = V3<R>(R(d[0]), R(d[1]), R(d[2])); ray.time = R(0);
+        R t_min = uni() < 0.8 ? R(0.001) : R(0), t_max = Lim<R>::max();
+        const uint32_t rsel = uint32_t(next() % 8);
+        if (rsel < 5) { // a range that ends (or starts) at, beside, or near the exact t of one face
+            const int f = int(next() % 6), k = f >> 1;
+            const R oo[3] = {ray.o.x, ray.o.y, ray.o.z}, dd[3] = {ray.d.x, ray.d.y, ray.d.z};
+            R tf = ((f & 1) ? bx.mx[k] : bx.mn[k]) - oo[k];
+            tf = tf / dd[k];
+            const uint32_t v = uint32_t(next() % 6);
+            R lim = v == 0 ? tf : v == 1 ? std::nextafter(tf, R(-1e30)) : v == 2 ? std::nextafter(tf, R(1e30)) : v == 3 ? tf * R(1 + 1e-6) : v == 4 ? tf * R(1 - 1e-6) : tf * R(uni() * 2.0);
+            if (rsel < 4) t_max = lim; else t_min = lim;
+        } else if (rsel == 5) t_max = R(std::pow(10.0, uni() * 6.0 - 3.0) * scale);
+        const SlabRay<R> sr = slab_ray<(sizeof(R) == 8 ? -1 : int(SLAB_EXACT))>(ray.o, ray.d);
+        R t1 = R(-1), t2 = R(-1);
+        int f1 = -1, f2 = -1, axis = 0;
+        bool use_mx = false;
+        const bool h1 = box_t(bx, ray, t_min, t_max, t1, f1);
+        const bool h2 = box_t_fast(bx, ray, sr, t_min, t_max, t2, f2);
+        out[1 + box_classify(bx, ray, sr, t_min, t_max, axis, use_mx)] += 1;
+        out[4] += h1 ? 1 : 0;
+        const bool same = h1 == h2 && (!h1 || (std::memcmp(&t1, &t2, sizeof(R)) == 0 && f1 == f2));
+        if (!same) { out[0] += 1; if (out[5] == ~0ull) out[5] = i; }
+    }
+}
 extern "C" {
 void hostsim_walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, int node_steps, uint64_t* hist,
                             uint64_t* out2) {
@@ -592,6 +667,10 @@ int hostsim_ball(uint32_t n, const uint64_t* keys, uint32_t bounce, double* out6
         out64[3 * i] = a.x; out64[3 * i + 1] = a.y; out64[3 * i + 2] = a.z;
         out32[3 * i] = b.x; out32[3 * i + 1] = b.y; out32[3 * i + 2] = b.z;
     }
+    return 0;
+}
+int hostsim_box_fast_check(uint64_t n, uint64_t seed, int f32, uint64_t* out) {
+    if (f32) box_fast_check_t<float>(n, seed, out); else box_fast_check_t<double>(n, seed, out);
     return 0;
 }
 // Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).

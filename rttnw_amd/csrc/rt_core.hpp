@@ -1234,6 +1234,9 @@ template <bool G = false, bool NO_TIME = false, bool FRAME_RAY = false, typename
 template <bool WHOLE_LEAF = false, typename R, typename Stack, typename Cnt>
 RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
     constexpr bool NI = Cnt::NO_INST;
+    // (the fast cube test where the walk's plane distances are to hand and cubes are what a leaf step meets: not in the decoupled kernel — big trees of
+    // spheres, whose LEAN flavour is held to 128 registers: spheres_1m strict 484 -> 479 with the code aboard)
+    constexpr bool FAST_CUBES = Stack::WIDE != NODES_Q8X4;
     if (tr.node == CHILD_EMPTY) { trav_pop<NI>(tr, wray, stack); return; }
     const uint32_t kind = leaf_kind(tr.node), count = leaf_count(tr.node), first = leaf_first(tr.node);
     if (!Cnt::NO_INST_LEAF && kind == PRIM_INSTANCE) { // Translate / YRotate wrappers: continue in object space (hittable.rs:599-606,686-699)
@@ -1263,12 +1266,12 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
     if constexpr (WHOLE_LEAF) {
         for (uint32_t k = 0; k < count; ++k) {
             cnt.prim();
-            trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, true>(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+            trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, FAST_CUBES>(tr, sc, kind, first + k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         }
         trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
-        trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, true>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+        trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, FAST_CUBES>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }
 }

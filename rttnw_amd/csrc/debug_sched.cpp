@@ -17,7 +17,7 @@ void debug_print_sched(const DeviceCounters& hc, bool plain, uint32_t profile, u
                 double(hc.dbg[4]) / hc.dbg[9], double(hc.dbg[7]) / hc.dbg[9], double(hc.dbg[8]) / hc.dbg[9],
                 double(hc.dbg[5] + hc.dbg[6]) / hc.dbg[4]);
         fprintf(stderr, "[plain] walk clock: node steps %.1f%%, leaf steps %.1f%% of the walk\n", 100.0 * hc.dbg[13] / hc.dbg[2], 100.0 * hc.dbg[14] / hc.dbg[2]);
-        for (uint32_t m = 1; m < 64; ++m)
+        for (uint32_t m = 1; m < 64 && profile == 2u; ++m) // (collect_counters = 2 only: level 3 keeps its histograms in the same words)
             if (hc.dbg[80 + m] * 200 > hc.dbg[8])
                 fprintf(stderr, "[plain]   leaf iterations serving {%s%s%s%s%s%s}: %.1f%% of them, %.1f%% of the leaf clock, %.0f clocks each\n", m & 1 ? "sphere " : "",
                         m & 2 ? "moving " : "", m & 4 ? "rect " : "", m & 8 ? "box " : "", m & 16 ? "instance " : "", m & 32 ? "empty " : "",

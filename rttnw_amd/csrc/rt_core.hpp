@@ -723,7 +723,15 @@ template <typename R> RT_HD float slab_inv32(const SlabRay<R>& sr, int a) {
     else return a == 0 ? sr.inv.x : (a == 1 ? sr.inv.y : sr.inv.z);
 }
 // returns 0: certainly no face hits; 1: the only face that can is (axis, use_mx), and its extents test is true; 2: not certain (box_t decides)
-template <typename R>
+// FORM: the same verdicts written two ways — 0: comparison by comparison, 1: one comparison of a min3 / max3 per verdict (fewer instructions).
+// The kernels take whichever their build runs faster with (final_scene f64 1664 -> 1677 with form 1, RTTNW_F64_STRICT 1399 -> 1386: that build
+// keeps form 0); tests/hostsim holds BOTH to box_t.
+#if defined(RT_STRICT_F64)
+constexpr int BOX_CLASSIFY_FORM = 0;
+#else
+constexpr int BOX_CLASSIFY_FORM = 1;
+#endif
+template <int FORM = BOX_CLASSIFY_FORM, typename R>
 RT_HD int box_classify(const BoxRec<R>& bx, const Ray<R>& ray, const SlabRay<R>& sr, R t_min, R t_max, int& axis, bool& use_mx) {
     const R o[3] = {ray.o.x, ray.o.y, ray.o.z};
     float nr[3], fr[3], S = 0.f;
@@ -744,28 +752,42 @@ RT_HD int box_classify(const BoxRec<R>& bx, const Ray<R>& ray, const SlabRay<R>&
     const float n2 = rt_med3(nr[0], nr[1], nr[2]), f2 = rt_med3(fr[0], fr[1], fr[2]);
     const float g = (S + rt_fabs(tn) + rt_fabs(tf)) * RT_BOX_FAST_MARGIN;
     const float lo = float(t_min), hi = float(t_max);
-    if (tn - tf >= g || lo - tf >= g || tn - hi >= g) return 0;
-    if (!(tf - tn >= g)) return 2;
-    if (tn - lo >= g) { // the entry face, or nothing
-        if (!(tn - n2 >= g)) return 2;
-        axis = nr[0] >= nr[1] ? (nr[0] >= nr[2] ? 0 : 2) : (nr[1] >= nr[2] ? 1 : 2);
-        use_mx = axis == 0 ? ng[0] : (axis == 1 ? ng[1] : ng[2]);
-        return 1;
+    if constexpr (FORM == 0) {
+        if (tn - tf >= g || lo - tf >= g || tn - hi >= g) return 0;
+        if (!(tf - tn >= g)) return 2;
+        if (tn - lo >= g) { // the entry face, or nothing
+            if (!(tn - n2 >= g)) return 2;
+            axis = nr[0] >= nr[1] ? (nr[0] >= nr[2] ? 0 : 2) : (nr[1] >= nr[2] ? 1 : 2);
+            use_mx = axis == 0 ? ng[0] : (axis == 1 ? ng[1] : ng[2]);
+            return 1;
+        }
+        if (lo - tn >= g && f2 - tf >= g) { // the exit face, or nothing
+            axis = fr[0] <= fr[1] ? (fr[0] <= fr[2] ? 0 : 2) : (fr[1] <= fr[2] ? 1 : 2);
+            use_mx = !(axis == 0 ? ng[0] : (axis == 1 ? ng[1] : ng[2]));
+            return 1;
+        }
+        return 2;
     }
-    if (lo - tn >= g && f2 - tf >= g) { // the exit face, or nothing
-        axis = fr[0] <= fr[1] ? (fr[0] <= fr[2] ? 0 : 2) : (fr[1] <= fr[2] ? 1 : 2);
-        use_mx = !(axis == 0 ? ng[0] : (axis == 1 ? ng[1] : ng[2]));
-        return 1;
-    }
-    return 2;
+    // (each verdict is ONE comparison of a min3 / max3 against the gap — a NaN anywhere makes the comparison false; the minNum / maxNum of the
+    // instructions would drop a NaN operand, but g itself is NaN then: S sums the |o / d| every distance is made from)
+    const float inside = tf - tn, before = lo - tn;
+    if (rt_max(rt_max(-inside, lo - tf), tn - hi) >= g) return 0;
+    const bool entry = rt_min(rt_min(-before, tn - n2), inside) >= g;   // the entry face, or nothing
+    const bool exit_ = rt_min(rt_min(before, f2 - tf), inside) >= g;    // the exit face, or nothing (never both: -before and before)
+    if (!(entry | exit_)) return 2;
+    // the face's axis: the one whose distance IS the extreme (unique by the gap)
+    const float c0 = entry ? nr[0] : fr[0], c1 = entry ? nr[1] : fr[1], ce = entry ? tn : tf;
+    axis = c0 == ce ? 0 : (c1 == ce ? 1 : 2);
+    use_mx = (axis == 0 ? ng[0] : (axis == 1 ? ng[1] : ng[2])) == entry;
+    return 1;
 }
 // (`bx`: the record WHERE IT LIES — LDS or global memory: the classification reads its six bounds once and keeps them as floats, the exact quotient
 // reads the one bound it needs by index, the rare undecided ray leaves the whole record to box_t: no copy of it is held in registers)
-template <typename R>
+template <int FORM = BOX_CLASSIFY_FORM, typename R>
 RT_HD bool box_t_fast(const BoxRec<R>& bx, const Ray<R>& ray, const SlabRay<R>& sr, R t_min, R t_max, R& t_out, int& face) {
     int axis = 0;
     bool use_mx = false;
-    const int verdict = box_classify(bx, ray, sr, t_min, t_max, axis, use_mx);
+    const int verdict = box_classify<FORM>(bx, ray, sr, t_min, t_max, axis, use_mx);
     if (verdict == 2) { const BoxRec<R> whole = bx; return box_t(whole, ray, t_min, t_max, t_out, face); }
     if (verdict == 0) return false;
     // (components copied into scalars first: a conditional on member lvalues is a pointer select into the ray — see rect_t)

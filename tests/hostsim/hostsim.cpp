@@ -521,7 +521,7 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
 // origins far, near, ON a face plane (the ray that has just scattered off the cube) and inside; directions at the box, at its corners / edges /
 // face points displaced by 0 .. 1e-3 of the box, random, axis-parallel; ranges open, or ending / starting at, one ulp off, or 1e-9 off the exact t of
 // a face.  out = {mismatches, verdict 0, verdict 1, verdict 2, hits, index of the first mismatch}.
-template <typename R> static void box_fast_check_t(uint64_t n, uint64_t seed, uint64_t* out) {
+template <typename R, int FORM> static void box_fast_check_t(uint64_t n, uint64_t seed, uint64_t* out) {
     uint64_t st = (seed ^ 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull; // (streams of different seeds must not be shifts of one another)
     st = (st ^ (st >> 29)) * 0x94D049BB133111EBull + seed;
     auto next = [&]() { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
@@ -583,8 +583,8 @@ template <typename R> static void box_fast_check_t(uint64_t n, uint64_t seed, ui
         int f1 = -1, f2 = -1, axis = 0;
         bool use_mx = false;
         const bool h1 = box_t(bx, ray, t_min, t_max, t1, f1);
-        const bool h2 = box_t_fast(bx, ray, sr, t_min, t_max, t2, f2);
-        out[1 + box_classify(bx, ray, sr, t_min, t_max, axis, use_mx)] += 1;
+        const bool h2 = box_t_fast<FORM>(bx, ray, sr, t_min, t_max, t2, f2);
+        out[1 + box_classify<FORM>(bx, ray, sr, t_min, t_max, axis, use_mx)] += 1;
         out[4] += h1 ? 1 : 0;
         const bool same = h1 == h2 && (!h1 || (std::memcmp(&t1, &t2, sizeof(R)) == 0 && f1 == f2));
         if (!same) { out[0] += 1; if (out[5] == ~0ull) out[5] = i; }
@@ -669,8 +669,9 @@ int hostsim_ball(uint32_t n, const uint64_t* keys, uint32_t bounce, double* out6
     }
     return 0;
 }
-int hostsim_box_fast_check(uint64_t n, uint64_t seed, int f32, uint64_t* out) {
-    if (f32) box_fast_check_t<float>(n, seed, out); else box_fast_check_t<double>(n, seed, out);
+int hostsim_box_fast_check(uint64_t n, uint64_t seed, int f32, int form, uint64_t* out) { // form: rt_core.hpp box_classify's two ways of writing the verdicts
+    if (f32) { if (form) box_fast_check_t<float, 1>(n, seed, out); else box_fast_check_t<float, 0>(n, seed, out); }
+    else { if (form) box_fast_check_t<double, 1>(n, seed, out); else box_fast_check_t<double, 0>(n, seed, out); }
     return 0;
 }
 // Entries the traversal stacks have needed since the last call (the device sizes its LDS stacks by FlatScene::stack_depth).

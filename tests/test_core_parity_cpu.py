@@ -317,21 +317,23 @@ def test_f64_box_tests_only_cull(hostsim, scenes_lib, earth, name, w, h, spp, mo
     assert sta.prims_tested < stb.prims_tested
 
 
+@pytest.mark.parametrize("form", [0, 1], ids=["comparisons", "min3max3"])
 @pytest.mark.parametrize("f32", [0, 1], ids=["f64", "f32"])
-def test_fast_cube_test_is_the_six_rectangle_test(hostsim, f32):
+def test_fast_cube_test_is_the_six_rectangle_test(hostsim, f32, form):
     """rt_core.hpp box_t_fast — ONE exact quotient for the face the walk's f32 plane distances single out, where the ray is clear of the box's edges,
     of t_min and of the incumbent by a margin — against Cube::hit's six rectangle tests (box_t, hittable.rs:560-569,503-513) in the host build's
     arithmetic (IEEE, nothing contracted): the same (hit, t bit for bit, face) on 6 million generated cases per precision — origins far, near, ON a
     face plane (the ray that has just scattered off the cube), inside; rays aimed at corners, edges and face points displaced by 0 .. 1e-3 of the
     box; axis-parallel rays; ranges that end or start at, one ulp beside, or 1e-6 beside the exact t of a face (tests/hostsim box_fast_check_t).
-    With the margin set to 0 the same cases give ~6 % mismatches: the test sees what it is for."""
+    With the margin set to 0 the same cases give ~6 % mismatches: the test sees what it is for.  Both ways box_classify writes its verdicts
+    (the strict build compiles one, the contracted builds the other) are held."""
     import ctypes as C
     lib = hostsim.lib
-    lib.hostsim_box_fast_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+    lib.hostsim_box_fast_check.argtypes = [C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
     decided = hits = total = 0
     for seed in (1, 2, 3):
         out = np.zeros(6, dtype=np.uint64)
-        assert lib.hostsim_box_fast_check(2_000_000, seed, f32, out.ctypes.data) == 0
+        assert lib.hostsim_box_fast_check(2_000_000, seed, f32, form, out.ctypes.data) == 0
         assert out[0] == 0, "first mismatch at case %d of seed %d" % (int(out[5]), seed)
         decided += int(out[1] + out[2]); hits += int(out[4]); total += int(out[1] + out[2] + out[3])
     assert total == 6_000_000 and decided > 0.5 * total and hits > 0.3 * total   # (the generator is hostile: the fast path still decides most cases)

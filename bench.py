@@ -21,7 +21,11 @@ is BASELINE configs[3]'s frame, final_scene 1600x1600, at spp = 1250 x N: per-GP
 3200 Msamples per GPU and step) and the N = 8 point IS configs[3] (1600x1600 spp=10000 tile-sharded across 8).
 value = samples of all ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line of at most 6 KB on stdout: the contract's top-level fields, a FLAT `roofline`, `cpu_baseline`, the
+headline workload through the other two builds as flat scalars (`strict_value` / `strict_ms_per_step`: RTTNW_F64_STRICT, the build whose
+pixels ARE the reference's; `f32_value` / `f32_ms_per_step`) and, under `sub`, one flat record per sub-workload and build.  Everything
+else (notes, instruction classes, per-sample counts, the other readings of the byte accounting) goes to `gpurun_out/bench_detail.json`
+(RTTNW_BENCH_DETAIL=<path> to move it) and, as one line, to stderr.
 
 `roofline` says what bounds the dominant (trace) kernel:
   * scenes whose node records live in LDS (final_scene, cornell_box): "bound": "valu" — achieved = full-wave VALU
@@ -106,6 +110,27 @@ def committed_pmc(scene_name, precision_name):
         return None
     vals["source"] = "profiles/%s/%s" % (PROFILE_ROUND, os.path.basename(pmc))
     return vals
+
+
+FLAT_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "hbm_alg_frac", "hbm_alg_gbps", "alg_bytes_per_sample", "traffic",
+                      "traffic_over_algorithmic", "lane_utilisation", "issue_utilisation", "valu_insts_per_sample", "kernel", "kernel_ms", "pmc")
+LINE_LIMIT = 6000   # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout; round 5's 25.9 KB line could not be parsed)
+
+
+def flat_roofline(detail):
+    """The scalars of a roofline record, no nesting and no prose (the full record goes to bench_detail.json)."""
+    return {k: detail.get(k) for k in FLAT_ROOFLINE_KEYS}
+
+
+def flat_sub(rec, cpu=None):
+    """One flat record per sub-workload and build."""
+    r = rec["roofline"]
+    out = {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"], "kernel_ms": r["kernel_ms"],
+           "hbm_alg_frac": r["hbm_alg_frac"], "traffic_over_algorithmic": r["traffic_over_algorithmic"],
+           "lane_utilisation": r["lane_utilisation"], "bound": r["bound"], "frac": r["frac"]}
+    if cpu is not None:
+        out["cpu_value"] = cpu["value"]
+    return out
 
 
 def main():
@@ -341,6 +366,10 @@ def main():
             common["issue_utilisation"] = valu["issue_utilisation"] if valu else None
             common["valu_insts_per_sample"] = valu["wave_instructions_per_sample"] if valu else None
             common["traffic_over_algorithmic"] = round(traffic / hbm_alg["alg_bytes_per_launch"], 4) if traffic is not None and hbm_alg["alg_bytes_per_launch"] else None
+            common["alg_bytes_per_sample"] = hbm_alg["alg_bytes_per_sample"]
+            # where the counter-derived fields (traffic, lane / issue utilisation) come from: PMC counters exist only under rocprofv3, so they are
+            # the COMMITTED summary of this kernel source (hash-gated, collected on the builder's lease) combined with THIS run's kernel_ms
+            common["pmc"] = "committed" if pmc is not None else None
             # what bounds the kernel: memory when the node records are walked in HBM / Infinity Cache (the decoupled kernel:
             # counter traffic ~ algorithmic bytes), vector-instruction issue when they are LDS-resident (counter traffic ~1 % of peak)
             if lds_resident and valu is not None:
@@ -441,21 +470,15 @@ def main():
     # ---- the other single-GPU configs of BASELINE.json, timed in the same run (default N = 1 run only).  spheres_1m reports the
     # IEEE-strict f64 build first: on that scene (rounding grows ~100x per bounce) it is the build whose pixels equal the CPU
     # reference's (tests/test_gpu_parity.py::test_config5_spheres_1m_at_its_size_vs_oracle); the contracted build rides along.
-    subs = {}
+    subs, subs_detail = {}, {}
     if world == 1 and share is None and args.workload is None and not args.no_sub and not args.spp and not args.size:
         for name in ("cornell_box", "spheres_1m"):
             w2 = Workload(name)
-            first = abi.F64_STRICT if name == "spheres_1m" else abi.F64
-            rec = w2.record(first, args.sub_steps, 1)
-            rec["config"] = w2.config()
-            if first == abi.F64_STRICT:
-                rec["f64_kernels"] = w2.record(abi.F64, args.sub_steps, 1)
-            else:
-                rec["f64strict_kernels"] = w2.record(abi.F64_STRICT, args.sub_steps, 1)
-            rec["f32_kernels"] = w2.record(abi.F32, args.sub_steps, 1)
-            if rank == 0 and args.cpu_seconds > 0:
-                rec["cpu_baseline"] = cpu_sample(w2, min(args.cpu_seconds, 6.0), name)
-            subs[name] = rec
+            recs = {pn: w2.record(pr, args.sub_steps, 1) for pn, pr in (("f64strict", abi.F64_STRICT), ("f64", abi.F64), ("f32", abi.F32))}
+            cpu2 = cpu_sample(w2, min(args.cpu_seconds, 6.0), name) if rank == 0 and args.cpu_seconds > 0 else None
+            subs[name] = {"workload": recs["f64"]["workload"]}
+            subs[name].update({pn: flat_sub(rec, cpu2 if pn == "f64" else None) for pn, rec in recs.items()})
+            subs_detail[name] = dict(recs, config=w2.config(), cpu_baseline=cpu2)
             del w2
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle on the host cores, bounded sample
@@ -475,21 +498,43 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if precision == abi.F32 else "f64", "precision": args.precision, "data": "synthetic",
             "config": cfg,
-            "roofline": roof,
+            "roofline": flat_roofline(roof),
             "cpu_baseline": cpu,
-            ("f64_kernels" if precision == abi.F32 else "f32_kernels"): other,
         }
+        detail = dict(out, roofline=roof)
+        # the headline workload through the other builds, flat: the IEEE-strict build first — its pixels ARE the CPU reference's (tier bar 1)
         if strict is not None:
-            out["f64strict_kernels"] = strict
+            out.update(strict_value=strict["value"], strict_ms_per_step=strict["ms_per_step"], strict_kernel_ms=strict["roofline"]["kernel_ms"],
+                       strict_steps=strict["steps"], strict_hbm_alg_frac=strict["roofline"]["hbm_alg_frac"],
+                       strict_lane_utilisation=strict["roofline"]["lane_utilisation"])
+            detail["f64strict_kernels"] = strict
+        if other is not None:
+            on = "f64" if precision == abi.F32 else "f32"
+            out.update({on + "_value": other["value"], on + "_ms_per_step": other["ms_per_step"], on + "_kernel_ms": other["roofline"]["kernel_ms"],
+                        on + "_steps": other["steps"]})
+            detail[on + "_kernels"] = other
         if use_dist:
             out["distributed"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks_expected": args.gpus,
                                   "rank_kernel_ms": rank_kernel_ms}
+            detail["distributed"] = out["distributed"]
         if per_gpu_reference is not None:
             # (the driver computes its own efficiency from the N = 1, 2, 4, 8 lines; this one is against the SAME frame on one GPU of this run)
             per_gpu_reference["scaling_efficiency"] = round(value / (world * per_gpu_reference["value"]), 4)
-            out["per_gpu_reference"] = per_gpu_reference
-        out.update(subs)
-        print(json.dumps(out), flush=True)
+            out["per_gpu_reference"] = detail["per_gpu_reference"] = per_gpu_reference
+        if subs:
+            out["sub"] = subs
+            detail["sub"] = subs_detail
+        line = json.dumps(out, separators=(",", ":"))
+        assert len(line) <= LINE_LIMIT, "bench: the stdout line is %d bytes (limit %d): move fields to the detail file" % (len(line), LINE_LIMIT)
+        dpath = os.environ.get("RTTNW_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(dpath), exist_ok=True)
+            with open(dpath, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as e:
+            log("bench: detail file not written (%s)" % e)
+        log("bench detail: " + json.dumps(detail))
+        print(line, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

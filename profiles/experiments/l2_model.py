@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""L2-miss lines per sample of the decoupled kernel on spheres_1m, by stream, for candidate layouts of the node and sphere records — the host
+model of tests/hostsim/cache_model.hpp (test infrastructure; nothing here is product code).  Usage:
+    python3 profiles/experiments/l2_model.py [--spheres N] [--waves W] [--cache-mb M] [--layouts current,bfs,...]
+The tree is the HOST builder's (binned SAH + collapse4: the device SAH tree renders within 0.5 % of it)."""
+import argparse
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from rttnw_amd import abi, library           # noqa: E402
+from rttnw_amd import scene as S             # noqa: E402
+
+RAYS_PER_SAMPLE = 7.03
+STREAMS = ["nodes", "spheres", "sphere_mat", "materials", "pool_hot", "pool_cold", "job_sums"]
+
+
+def hostsim_binding():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "hostsim"), "-s"], check=True)
+    lib = C.CDLL(os.path.join(ROOT, "tests", "hostsim", "libhostsim.so"))
+    b = abi.Binding(lib, "rttnw_", abi.BUILDER_FUNCS)
+    b.add([("builder", C.c_void_p, [])])
+    return b
+
+
+def tree_arrays(hs, sc):
+    dims = (C.c_uint32 * 8)()
+    hs.lib.hostsim_scene_dims(sc.handle, dims)
+    n = dims[0]
+    child = np.zeros((n, 4), dtype=np.int32)
+    area = np.zeros((n, 4), dtype=np.float32)
+    root = C.c_int32()
+    hs.lib.hostsim_nodes(sc.handle, child.ctypes.data_as(C.c_void_p), area.ctypes.data_as(C.c_void_p), C.byref(root))
+    return child, area, root.value, dims[1]
+
+
+# ---- layouts: perm[i] = where record i lies -----------------------------------------------------------------------------------------
+def order_to_perm(order, n):
+    perm = np.full(n, -1, dtype=np.int64)
+    perm[np.asarray(order, dtype=np.int64)] = np.arange(len(order))
+    rest = np.flatnonzero(perm < 0)
+    perm[rest] = np.arange(len(order), len(order) + len(rest))   # records no walk reaches (instance trees of other scenes)
+    return perm.astype(np.uint32)
+
+
+def layout_bfs(child, area, root, by_area=False):
+    order, frontier = [], [root]
+    while frontier:
+        order.extend(frontier)
+        nxt = []
+        for i in frontier:
+            cs = [(c, child[i, c]) for c in range(4) if child[i, c] >= 0]
+            if by_area:
+                cs.sort(key=lambda t: -area[i, t[0]])
+            nxt.extend(ch for _, ch in cs)
+        frontier = nxt
+    return order
+
+
+def layout_dfs(child, area, root, by_area=False):
+    order, stack = [], [root]
+    while stack:
+        i = stack.pop()
+        order.append(i)
+        cs = [(c, child[i, c]) for c in range(4) if child[i, c] >= 0]
+        if by_area:
+            cs.sort(key=lambda t: -area[i, t[0]])
+        stack.extend(ch for _, ch in reversed(cs))
+    return order
+
+
+def subtree_sizes(child, root):
+    n = child.shape[0]
+    size = np.ones(n, dtype=np.int64)
+    order = layout_bfs(child, None, root)
+    for i in reversed(order):
+        for c in range(4):
+            if child[i, c] >= 0:
+                size[i] += size[child[i, c]]
+    return size
+
+
+def layout_treelets(child, area, root, treelet, by_area=True):
+    """Treelets of up to `treelet` records: a treelet grows from its root by taking, again and again, the frontier record whose box has the
+    largest surface area (the one a ray that reached the treelet most probably visits next); its records lie contiguously in the order taken;
+    the records left on the frontier root the next treelets, laid out depth-first (a treelet next to its first child treelet)."""
+    import heapq
+    order, stack = [], [root]
+    while stack:
+        r = stack.pop()
+        taken, heap = [], [(-1e30, r)]
+        while heap and len(taken) < treelet:
+            _, i = heapq.heappop(heap)
+            taken.append(i)
+            for c in range(4):
+                if child[i, c] >= 0:
+                    heapq.heappush(heap, (-float(area[i, c]) if by_area else len(taken), child[i, c]))
+        order.extend(taken)
+        rest = sorted(heap)                       # largest area first
+        stack.extend(i for _, i in reversed(rest))
+    return order
+
+
+def layout_pairs(child, area, root):
+    """Lines of two: depth-first, but a record's inner children are emitted as adjacent PAIRS (largest-area two together) right after it when it
+    is line-aligned — so that the two most probable next visits share ONE line."""
+    order, stack = [], [("n", root)]
+    placed = set()
+    while stack:
+        kind, i = stack.pop()
+        if kind == "n":
+            if i not in placed:
+                order.append(i); placed.add(i)
+            cs = sorted([(-area[i, c], child[i, c]) for c in range(4) if child[i, c] >= 0])
+            kids = [ch for _, ch in cs]
+            # emit the children now, as a block of siblings (pairs of siblings share lines when the block starts on a line)
+            if len(order) % 2 == 1 and kids:
+                pass
+            for ch in kids:
+                order.append(ch); placed.add(ch)
+            stack.extend(("n", ch) for ch in reversed(kids))
+    return order
+
+
+def sphere_order_from_tree(child, order_nodes, n_spheres):
+    """Sphere records in the order the node layout meets their leaves (a leaf = up to four consecutive same-kind records)."""
+    seen = np.zeros(n_spheres, dtype=bool)
+    out = []
+    for i in order_nodes:
+        for c in range(4):
+            ch = int(child[i, c])
+            if ch < 0 and ch != -2 ** 31:
+                bits = (~ch) & 0xFFFFFFFF
+                kind, count, first = bits >> 28, ((bits >> 26) & 3) + 1, bits & 0x3FFFFFF
+                if kind == 0:
+                    for k in range(first, first + count):
+                        if not seen[k]:
+                            seen[k] = True
+                            out.append(k)
+    rest = np.flatnonzero(~seen)
+    return np.concatenate([np.asarray(out, dtype=np.int64), rest])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--spheres", type=int, default=1000000)
+    ap.add_argument("--waves", type=int, default=416, help="waves sharing the cache: 32 CUs x 13 waves per XCD on the f64 LEAN flavour")
+    ap.add_argument("--cache-mb", type=float, default=4.0)
+    ap.add_argument("--ways", type=int, default=16)
+    ap.add_argument("--warm", type=int, default=3)
+    ap.add_argument("--measure", type=int, default=4)
+    ap.add_argument("--layouts", default="current,dfs_area,bfs,bfs_area,treelet8,treelet16,treelet32")
+    ap.add_argument("--variants", default="base", help="comma list of: base, spheres_tree (sphere records in node-layout order), "
+                    "mat_by_sphere (material beside the sphere's index, 64 B), precull (one-sphere leaves pre-tested, 5 %% inflated)")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--batch-stride", type=int, default=0, help="0: job batches strided over the whole render; k: every k-th batch from --batch-offset (the kernel's order: k = 8 XCDs)")
+    ap.add_argument("--batch-offset", type=int, default=0)
+    args = ap.parse_args()
+
+    hs = hostsim_binding()
+    scenes = library.scenes()
+    t0 = time.time()
+    sc, setup = S.build(hs, scenes, "spheres_1m", None, args.spheres)   # (the host build has only the host builder)
+    child, area, root, n_spheres = tree_arrays(hs, sc)
+    n = child.shape[0]
+    print("scene: %d spheres, %d four-wide records, built in %.1f s" % (n_spheres, n, time.time() - t0), flush=True)
+    cam, p = S.params_for(setup, args.size, args.size, 256, precision=abi.F64, seed=1)
+
+    def layout(name):
+        if name == "current":
+            return list(range(n)), None
+        if name == "dfs_area":
+            o = layout_dfs(child, area, root, True)
+        elif name == "dfs":
+            o = layout_dfs(child, area, root, False)
+        elif name == "bfs":
+            o = layout_bfs(child, area, root, False)
+        elif name == "bfs_area":
+            o = layout_bfs(child, area, root, True)
+        elif name.startswith("treelet"):
+            o = layout_treelets(child, area, root, int(name[7:]))
+        elif name == "pairs":
+            o = layout_pairs(child, area, root)
+        else:
+            raise SystemExit("unknown layout " + name)
+        return o, order_to_perm(o, n)
+
+    print("%-12s %-14s | %s | total rd-miss  wr-back | per ray: nodes sph-tests skipped" % ("layout", "variant", " ".join("%10s" % s for s in STREAMS)))
+    for lname in args.layouts.split(","):
+        order, perm = layout(lname)
+        for variant in args.variants.split(","):
+            vs = set(variant.split("+"))
+            sperm = None
+            if "spheres_tree" in vs:
+                so = sphere_order_from_tree(child, order, n_spheres)
+                sperm = order_to_perm(so, n_spheres)
+            prm = np.zeros(17, dtype=np.uint32)
+            cache_bytes = int(args.cache_mb * (1 << 20))
+            prm[:] = [args.waves, args.ways, 5, 8, args.warm, args.measure, cache_bytes & 0xFFFFFFFF, cache_bytes >> 32,
+                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset]
+            out = np.zeros(160, dtype=np.uint64)
+            t0 = time.time()
+            hs.lib.hostsim_cache_model(sc.handle, C.byref(cam), C.byref(p), prm.ctypes.data_as(C.c_void_p),
+                                       perm.ctypes.data_as(C.c_void_p) if perm is not None else None,
+                                       sperm.ctypes.data_as(C.c_void_p) if sperm is not None else None, out.ctypes.data_as(C.c_void_p))
+            # normalised per RAY and quoted per sample at the measured rays per sample (profiles/r05: 7.03 on spheres_1m): a model run is short against
+            # the ~53 000 paths in flight, so the samples it COMPLETES are biased to the short ones (sky) while the lines per ray are not
+            ns = float(out[1]) / RAYS_PER_SAMPLE
+            miss = [out[9 + 4 * s] / ns for s in range(len(STREAMS))]
+            wb = sum(out[10 + 4 * s] for s in range(len(STREAMS))) / ns
+            print("%-12s %-14s | %s | %8.1f %8.1f | %6.1f %6.2f %6.2f   (%.0f s, %d samples)" %
+                  (lname, variant, " ".join("%10.2f" % m for m in miss), sum(miss), wb, out[2] / max(1.0, float(out[1])), out[3] / max(1.0, float(out[1])),
+                   out[4] / max(1.0, float(out[1])), time.time() - t0, int(out[1])), flush=True)
+            if lname == "current" and variant == "base":
+                print("    node accesses / misses per sample by depth: " +
+                      " ".join("%d:%.1f/%.1f" % (d, out[64 + d] / ns, out[96 + d] / ns) for d in range(32) if out[64 + d]), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -590,7 +590,35 @@ template <typename R, int FORM> static void box_fast_check_t(uint64_t n, uint64_
         if (!same) { out[0] += 1; if (out[5] == ~0ull) out[5] = i; }
     }
 }
+#include "cache_model.hpp"
+
 extern "C" {
+// L2 model of the decoupled kernel on a tree in HBM (cache_model.hpp).  prm: the Params fields in order (cache_bytes as prm[6] | prm[7] << 32
+// after the six leading words), node_perm / sphere_perm: where a record lies (null: where it lies today), nodes_out: optional dump
+// [n][4] of the 4-wide records' child slots for whoever computes a layout.
+void hostsim_cache_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, const uint32_t* prm, const uint32_t* node_perm,
+                         const uint32_t* sphere_perm, uint64_t* out) {
+    cache_model::Params P{};
+    P.n_waves = prm[0]; P.ways = prm[1]; P.node_steps = prm[2]; P.retire = prm[3]; P.warm_samples_per_slot = prm[4]; P.measure_samples_per_slot = prm[5];
+    P.cache_bytes = uint64_t(prm[6]) | (uint64_t(prm[7]) << 32);
+    P.sphere_bytes = prm[8]; P.mat_bytes = prm[9]; P.mat_by_sphere = prm[10]; P.real_bytes = prm[11]; P.precull = prm[12]; P.precull_pct = prm[13];
+    P.xcds = prm[14]; P.node_bytes = prm[15]; P.batch_offset = prm[16];
+    if (p->precision == RTTNW_F32) cache_model::run<float>(s, cam, p, P, node_perm, sphere_perm, out);
+    else cache_model::run<double>(s, cam, p, P, node_perm, sphere_perm, out);
+}
+// The 4-wide records of the committed scene, for layout experiments: child[n][4], and the surface area of every child box area[n][4].
+int hostsim_nodes(rttnw_scene* s, int32_t* child, float* area, int32_t* top_root) {
+    if (!s || !s->committed) return RTTNW_ERR_INVALID;
+    const auto& n4 = s->flat.nodes4;
+    for (size_t i = 0; i < n4.size(); ++i)
+        for (int c = 0; c < 4; ++c) {
+            child[i * 4 + c] = n4[i].child[c];
+            const float dx = n4[i].hi[0][c] - n4[i].lo[0][c], dy = n4[i].hi[1][c] - n4[i].lo[1][c], dz = n4[i].hi[2][c] - n4[i].lo[2][c];
+            area[i * 4 + c] = n4[i].child[c] == CHILD_EMPTY ? 0.f : 2.f * (dx * dy + dy * dz + dz * dx);
+        }
+    *top_root = s->flat.top_root;
+    return RTTNW_OK;
+}
 void hostsim_walk_histogram(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, int node_steps, uint64_t* hist,
                             uint64_t* out2) {
     walk_histogram(s, cam, p, node_steps, hist, out2);

@@ -817,6 +817,42 @@ def test_bench_line_through_torch_distributed_with_one_rank(gpu):
     assert d["config"]["workload"].startswith("final_scene 800x800 spp=16") and d["roofline"]["kernel_ms"] > 0
 
 
+def test_bench_default_line_fits_the_drivers_window(gpu, tmp_path):
+    """The default bench run — headline + strict + f32 + both sub-workloads + CPU legs, as the driver starts it (fewer steps, shorter CPU
+    samples) — prints ONE line that a reader holding only the last 8 KB of stdout can parse (round 5's 25.9 KB line could not be: BENCH_r05.json
+    `parsed: null`): under 6000 bytes, flat `roofline` with `frac`, `cpu_baseline.value`, the strict build's figures at the top level, one flat
+    record per sub-workload and build; the long form lands in the detail file."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    detail = str(tmp_path / "bench_detail.json")
+    env = dict(os.environ, RTTNW_BENCH_DETAIL=detail)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--sub-steps", "1", "--cpu-seconds", "1.5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = r.stdout[-8000:].splitlines()[-1]
+    assert len(line) < 6000 and len(r.stdout.strip().splitlines()) == 1, (len(line), r.stdout[:300])
+    d = json.loads(line)
+    assert d["metric"].startswith("Msamples/sec on final_scene 800x800 spp=1000") and d["config"]["workload"] == "final_scene 800x800 spp=1000"
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] == pytest.approx(800 * 800 * 1000 / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-4)
+    roof = d["roofline"]
+    assert all(not isinstance(v, (dict, list)) for v in roof.values()), roof
+    assert 0 < roof["frac"] < 1 and 0 < roof["hbm_alg_frac"] < 1 and roof["kernel_ms"] > 0 and roof["bound"] in ("hbm", "valu")
+    assert roof["pmc"] in ("committed", None) and (roof["traffic"] is None) == (roof["pmc"] is None)
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["strict_value"] > 0 and d["strict_ms_per_step"] > 0 and d["f32_value"] > 0
+    for name in ("cornell_box", "spheres_1m"):
+        for build in ("f64", "f64strict", "f32"):
+            rec = d["sub"][name][build]
+            assert all(not isinstance(v, (dict, list)) for v in rec.values()) and rec["value"] > 0 and rec["kernel_ms"] > 0
+        assert d["sub"][name]["f64"]["cpu_value"] > 0
+    full = json.load(open(detail))
+    assert "note" in full["roofline"] and full["sub"]["spheres_1m"]["f64strict"]["roofline"]["per_sample"]["nodes"] > 0
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_bench_n_ranks_rehearsed_on_one_gpu(gpu, scenes_lib, earth, tmp_path, world):
     """`bench.py --gpus N` (N = 2, and N = 8: configs[3]'s partition) exactly as the driver launches it — `python -m torch.distributed.run --nproc-per-node N ...` — on a

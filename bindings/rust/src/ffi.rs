@@ -162,6 +162,7 @@ extern "C" {
     pub fn rttnw_translate(s: *mut rttnw_scene, item: rttnw_id, offset: *const f64) -> rttnw_id;
     pub fn rttnw_rotate_y(s: *mut rttnw_scene, item: rttnw_id, angle_degrees: f64) -> rttnw_id;
     pub fn rttnw_constant_medium(s: *mut rttnw_scene, boundary: rttnw_id, density: f64, tex: rttnw_id) -> rttnw_id;
+    pub fn rttnw_hittable_bounds(s: *const rttnw_scene, hittable: rttnw_id, initial_time: f64, final_time: f64, out_min_max: *mut f64) -> c_int;
     pub fn rttnw_scene_set_world(s: *mut rttnw_scene, world_list: rttnw_id) -> c_int;
     pub fn rttnw_scene_set_bvh_builder(s: *mut rttnw_scene, builder: u32) -> c_int;
     pub fn rttnw_scene_commit(s: *mut rttnw_scene) -> c_int;

@@ -91,6 +91,14 @@ impl SceneBuilder {
     pub fn translate(&mut self, item: Hit, offset: [f64; 3]) -> Result<Hit> { id(unsafe { ffi::rttnw_translate(self.raw, item.0, offset.as_ptr()) }).map(Hit) }
     pub fn rotate_y(&mut self, item: Hit, angle_degrees: f64) -> Result<Hit> { id(unsafe { ffi::rttnw_rotate_y(self.raw, item.0, angle_degrees) }).map(Hit) }
     pub fn constant_medium(&mut self, boundary: Hit, density: f64, phase: Tex) -> Result<Hit> { id(unsafe { ffi::rttnw_constant_medium(self.raw, boundary.0, density, phase.0) }).map(Hit) }
+    /// `Hittable::bounding_box(initial_time, final_time) -> Option<Bound>` (hittable.rs:50) of any hittable built so far: `Some((min, max))`, or `None`
+    /// where the reference returns `None` (an empty `List`).  `YRotate`'s box is the correct rotation of the item's corners (not quirk Q2's).
+    pub fn bounding_box(&self, item: Hit, time: std::ops::Range<f64>) -> Result<Option<([f64; 3], [f64; 3])>> {
+        let mut b = [0f64; 6];
+        let rc = unsafe { ffi::rttnw_hittable_bounds(self.raw, item.0, time.start, time.end, b.as_mut_ptr()) };
+        if rc < 0 { return ok(rc).map(|_| None); }
+        Ok(if rc == 1 { Some(([b[0], b[1], b[2]], [b[3], b[4], b[5]])) } else { None })
+    }
     /// Force where the BVHs are built; before `commit`.  Without this call the library decides per tree (`RTTNW_BVH_AUTO`: host below
     /// 100 000 leaves, the device's binned-SAH build above).
     pub fn device_bvh(&mut self, on: bool) -> Result<()> {

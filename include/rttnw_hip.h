@@ -139,6 +139,16 @@ rttnw_id rttnw_rotate_y(rttnw_scene* s, rttnw_id item, double angle_degrees);
 /* `ConstantMedium::new(boundary, density, phase_texture)` — hittable.rs:724-801 */
 rttnw_id rttnw_constant_medium(rttnw_scene* s, rttnw_id boundary, double density, rttnw_id tex);
 
+/* `Hittable::bounding_box(initial_time, final_time) -> Option<Bound>` — hittable.rs:50, the trait's second method, for any hittable id of the
+ * scene's graph (before or after commit): Sphere :125-130, List :165-176, MovingSphere :233-244, BvhTree :370-372 (the bound stored by
+ * `BvhTree::from` = over times 0..1, whatever is asked), Rectangle :532-546 (k -+ 0.0001), Cube :585-591, Translate :619-628, YRotate :719-721
+ * (the item's box over 0..1, turned about y), ConstantMedium :798-800.  Returns 1 and writes min.xyz, max.xyz to out_min_max — 0 for `None`
+ * (an empty List, a List with a member that has none) — or a negative rttnw_status.  One deliberate difference: YRotate's box is the CORRECT
+ * rotation of the item's eight corners; the reference's (:661-662) rotates z with the x it has just overwritten (latent there:
+ * no scene puts a YRotate into a BvhTree) and can fail to contain the object.  Nothing on the render path reads these boxes: the lowering builds
+ * its own f32 boxes, rounded outward (scene_lower.cpp). */
+int rttnw_hittable_bounds(const rttnw_scene* s, rttnw_id hittable, double initial_time, double final_time, double out_min_max[6]);
+
 /* The `world: List` handed to `color()` — main.rs:47-55,216. */
 int rttnw_scene_set_world(rttnw_scene* s, rttnw_id world_list);
 /* Which builder `rttnw_scene_commit` uses for the flat BVHs (before commit; default RTTNW_BVH_AUTO).  Replaces the

@@ -147,6 +147,36 @@ def sphere_order_from_tree(child, order_nodes, n_spheres):
     return np.concatenate([np.asarray(out, dtype=np.int64), rest])
 
 
+def unified_layout(child, order_nodes, n_spheres, align_parent=False):
+    """Node and sphere records in ONE buffer, positions in 32-byte units: every node record (64 B, on a 64-byte boundary) is followed by the sphere
+    records of its sphere leaves.  align_parent: a record that has sphere leaves starts on a 128-byte line (its first two spheres share its line)."""
+    n = child.shape[0]
+    npos = np.zeros(n, dtype=np.uint32)
+    spos = np.full(n_spheres, 0xFFFFFFFF, dtype=np.uint32)
+    at = 0
+    for i in order_nodes:
+        leaves = []
+        for c in range(4):
+            ch = int(child[i, c])
+            if ch < 0 and ch != -2 ** 31:
+                bits = (~ch) & 0xFFFFFFFF
+                if bits >> 28 == 0:
+                    leaves.append((bits & 0x3FFFFFF, ((bits >> 26) & 3) + 1))
+        at += at & 1
+        if align_parent and leaves and (at & 3):
+            at += 4 - (at & 3)
+        npos[i] = at
+        at += 2
+        for first, count in leaves:
+            for k in range(first, first + count):
+                spos[k] = at
+                at += 1
+    rest = np.flatnonzero(spos == 0xFFFFFFFF)
+    spos[rest] = at + np.arange(len(rest), dtype=np.uint32)
+    print("    unified buffer: %.1f MB" % ((at + len(rest)) * 32 / 1e6))
+    return npos, spos
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--spheres", type=int, default=1000000)
@@ -197,17 +227,21 @@ def main():
         for variant in args.variants.split(","):
             vs = set(variant.split("+"))
             sperm = None
-            if "spheres_tree" in vs:
+            unified = "unified" in vs
+            nperm = perm
+            if unified:
+                nperm, sperm = unified_layout(child, order, n_spheres, align_parent="aligned" in vs)
+            elif "spheres_tree" in vs:
                 so = sphere_order_from_tree(child, order, n_spheres)
                 sperm = order_to_perm(so, n_spheres)
-            prm = np.zeros(17, dtype=np.uint32)
+            prm = np.zeros(18, dtype=np.uint32)
             cache_bytes = int(args.cache_mb * (1 << 20))
             prm[:] = [args.waves, args.ways, 5, 8, args.warm, args.measure, cache_bytes & 0xFFFFFFFF, cache_bytes >> 32,
-                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset]
+                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset, 1 if unified else 0]
             out = np.zeros(160, dtype=np.uint64)
             t0 = time.time()
             hs.lib.hostsim_cache_model(sc.handle, C.byref(cam), C.byref(p), prm.ctypes.data_as(C.c_void_p),
-                                       perm.ctypes.data_as(C.c_void_p) if perm is not None else None,
+                                       nperm.ctypes.data_as(C.c_void_p) if nperm is not None else None,
                                        sperm.ctypes.data_as(C.c_void_p) if sperm is not None else None, out.ctypes.data_as(C.c_void_p))
             # normalised per RAY and quoted per sample at the measured rays per sample (profiles/r05: 7.03 on spheres_1m): a model run is short against
             # the ~53 000 paths in flight, so the samples it COMPLETES are biased to the short ones (sky) while the lines per ray are not

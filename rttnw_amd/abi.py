@@ -108,6 +108,7 @@ PRODUCT_FUNCS = [
     ("scene_info", C.c_int, [scene_p, C.POINTER(Stats)]),
     ("scene_set_bvh_builder", C.c_int, [scene_p, C.c_uint32]),
     ("scene_build_info", C.c_int, [scene_p, C.POINTER(BuildInfo)]),
+    ("hittable_bounds", C.c_int, [scene_p, c_id, C.c_double, C.c_double, _dp]),
     ("debug_scene_nodes", C.c_int, [scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
     ("debug_scene_nodes4", C.c_int, [scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
     ("builder", C.c_void_p, []),

@@ -529,17 +529,33 @@ __device__ __forceinline__ int expand4(const BvhNode* __restrict__ nodes, int b,
     return n;
 }
 // One 4-wide level: every head of the frontier marks the inner children of its record as heads of the next level.
-__global__ void collapse_mark_kernel(const BvhNode* __restrict__ nodes, const int* __restrict__ frontier, int n_front, int* __restrict__ next,
-                                     int* __restrict__ next_count, uint32_t* __restrict__ is_head) {
+// (two passes and a scan instead of an atomic counter: the frontier's ORDER numbers the records in level order, and a build must repeat bit for bit)
+__global__ void collapse_count_kernel(const BvhNode* __restrict__ nodes, const int* __restrict__ frontier, int n_front, uint32_t* __restrict__ n_inner_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_front) return;
     Slot slots[5];
     const int n = expand4(nodes, frontier[i], slots);
+    uint32_t n_inner = 0;
+    for (int c = 0; c < n; ++c) n_inner += slots[c].child >= 0;
+    n_inner_out[i] = n_inner;
+}
+__global__ void collapse_mark_kernel(const BvhNode* __restrict__ nodes, const int* __restrict__ frontier, int n_front, int* __restrict__ next,
+                                     const uint32_t* __restrict__ offset, uint32_t* __restrict__ is_head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_front) return;
+    Slot slots[5];
+    const int n = expand4(nodes, frontier[i], slots);
+    uint32_t at = offset[i]; // the record's inner children side by side in the next frontier, in slot order
     for (int c = 0; c < n; ++c)
         if (slots[c].child >= 0) {
             is_head[slots[c].child] = 1u;
-            next[atomicAdd(next_count, 1)] = slots[c].child;
+            next[at++] = slots[c].child;
         }
+}
+// Level order: record number = position of its head in the frontier arrays (root first, the inner children of a record side by side).
+__global__ void rank_by_position_kernel(const int* __restrict__ heads, int n_heads, uint32_t* __restrict__ rank) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_heads) rank[heads[i]] = uint32_t(i);
 }
 __global__ void collapse_write_kernel(const BvhNode* __restrict__ nodes, const int* __restrict__ heads, int n_heads, const uint32_t* __restrict__ rank,
                                       Bvh4Node* __restrict__ out) {
@@ -646,7 +662,7 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
     const size_t max_large = n / size_t(SAH_SMALL + 1) + 2;
     // collapse
     int *d_heads = nullptr, *d_count = nullptr;
-    uint32_t *d_is_head = nullptr, *d_rank = nullptr, *d_need = nullptr;
+    uint32_t *d_is_head = nullptr, *d_rank = nullptr, *d_need = nullptr, *d_fcount = nullptr, *d_foff = nullptr;
     Bvh4Node* d_out4 = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const uint32_t nb = uint32_t((n + 255) / 256);
@@ -664,6 +680,8 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
         LBVH_TRY(hipMalloc((void**)&d_count, 4));
         LBVH_TRY(hipMalloc((void**)&d_is_head, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_rank, (n - 1) * 4));
+        LBVH_TRY(hipMalloc((void**)&d_fcount, (n - 1) * 4));
+        LBVH_TRY(hipMalloc((void**)&d_foff, (n - 1) * 4));
         LBVH_TRY(rocprim::exclusive_scan(nullptr, temp2_bytes, d_is_head, d_rank, 0u, size_t(n_inner), rocprim::plus<uint32_t>(), hipStream_t(0)));
         LBVH_TRY(hipMalloc(&d_temp2, std::max<size_t>(temp2_bytes, 16)));
         if (!sah) {
@@ -775,17 +793,28 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
         level_off.push_back(1);
         for (;;) {
             const int lo = level_off[level_off.size() - 2], hi = level_off.back(), n_front = hi - lo;
-            LBVH_TRY(hipMemsetAsync(d_count, 0, 4, 0));
-            hipLaunchKernelGGL(collapse_mark_kernel, dim3((n_front + 255) / 256), dim3(256), 0, 0, d_out2, d_heads + lo, n_front, d_heads + hi, d_count,
+            hipLaunchKernelGGL(collapse_count_kernel, dim3((n_front + 255) / 256), dim3(256), 0, 0, d_out2, d_heads + lo, n_front, d_fcount);
+            LBVH_TRY(rocprim::exclusive_scan(d_temp2, temp2_bytes, d_fcount, d_foff, 0u, size_t(n_front), rocprim::plus<uint32_t>(), hipStream_t(0)));
+            hipLaunchKernelGGL(collapse_mark_kernel, dim3((n_front + 255) / 256), dim3(256), 0, 0, d_out2, d_heads + lo, n_front, d_heads + hi, d_foff,
                                d_is_head);
-            int added = 0;
-            LBVH_TRY(hipMemcpy(&added, d_count, 4, hipMemcpyDeviceToHost));
+            uint32_t last[2] = {0, 0};
+            LBVH_TRY(hipMemcpy(&last[0], d_fcount + (n_front - 1), 4, hipMemcpyDeviceToHost));
+            LBVH_TRY(hipMemcpy(&last[1], d_foff + (n_front - 1), 4, hipMemcpyDeviceToHost));
+            const int added = int(last[0] + last[1]);
             if (added == 0) break;
             if (hi + added > n_inner || level_off.size() > 4096) { err = "lbvh_build: collapse did not converge"; rc = -4; goto done; }
             level_off.push_back(hi + added);
         }
         n_heads = uint32_t(level_off.back());
-        LBVH_TRY(rocprim::exclusive_scan(d_temp2, temp2_bytes, d_is_head, d_rank, 0u, size_t(n_inner), rocprim::plus<uint32_t>(), hipStream_t(0)));
+        // Numbering of the records.  Level order (default since round 6): a record's number is its head's position in the frontier arrays, so the
+        // inner children of a record lie side by side — two 64-byte quantised records to a 128-byte line, and a walk that visits a record visits
+        // 1.6 of its children on average (tests/hostsim/cache_model.hpp: 50.1 -> 45.1 node-record miss lines per sample on spheres_1m against
+        // the binary tree's pre-order; treelets of 4 .. 64 records: 47 - 48).  RTTNW_NODE_ORDER=pre: the binary pre-order of rounds 1-5.
+        const char* order_env = getenv("RTTNW_NODE_ORDER");
+        if (order_env && std::string(order_env) == "pre")
+            LBVH_TRY(rocprim::exclusive_scan(d_temp2, temp2_bytes, d_is_head, d_rank, 0u, size_t(n_inner), rocprim::plus<uint32_t>(), hipStream_t(0)));
+        else
+            hipLaunchKernelGGL(rank_by_position_kernel, dim3((n_heads + 255) / 256), dim3(256), 0, 0, d_heads, int(n_heads), d_rank);
         LBVH_TRY(hipMalloc((void**)&d_out4, size_t(n_heads) * sizeof(Bvh4Node)));
         LBVH_TRY(hipMalloc((void**)&d_need, size_t(n_heads) * 4));
         hipLaunchKernelGGL(collapse_write_kernel, dim3((n_heads + 255) / 256), dim3(256), 0, 0, d_out2, d_heads, int(n_heads), d_rank, d_out4);
@@ -819,7 +848,7 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
 done:
     for (void* p : {(void*)d_prims, (void*)d_keys, (void*)d_keys2, (void*)d_order, (void*)d_order2, (void*)d_children, (void*)d_node_parent,
                     (void*)d_done, (void*)d_levels, (void*)d_box, (void*)d_out, (void*)d_out2, (void*)d_pos, d_temp, d_temp2, (void*)d_heads,
-                    (void*)d_count, (void*)d_is_head, (void*)d_rank, (void*)d_need, (void*)d_out4, d_temp3, (void*)d_pa, (void*)d_pb, (void*)d_sa, (void*)d_sb,
+                    (void*)d_count, (void*)d_is_head, (void*)d_rank, (void*)d_fcount, (void*)d_foff, (void*)d_need, (void*)d_out4, d_temp3, (void*)d_pa, (void*)d_pb, (void*)d_sa, (void*)d_sb,
                     (void*)d_slot, (void*)d_list[0], (void*)d_list[1], (void*)d_list[2], (void*)d_list[3], (void*)d_segs, (void*)d_split, (void*)d_bins,
                     (void*)d_next, (void*)d_flag, (void*)d_scan})
         if (p) (void)hipFree(p);

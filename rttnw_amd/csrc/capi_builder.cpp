@@ -185,6 +185,99 @@ rttnw_id rttnw_constant_medium(rttnw_scene* s, rttnw_id boundary, double density
     GraphObj o; o.kind = GraphObj::MEDIUM_K; o.a = boundary; o.b = iso; o.v[0] = density; o.c = int32_t(s->n_media++);
     return push(s, std::move(o));
 }
+// ---- Hittable::bounding_box (hittable.rs:50) of any hittable of the graph, before or after commit.  The trait's second method: nothing on the
+// render path asks for it (the lowering computes its own f32-outward boxes, scene_lower.cpp), so this is the boundary's introspection of the graph.
+namespace {
+struct Bound6 { double mn[3], mx[3]; };
+void surround(Bound6& a, const Bound6& b) { // Bound::surrounding — bound.rs:34-46
+    for (int k = 0; k < 3; ++k) { a.mn[k] = std::min(a.mn[k], b.mn[k]); a.mx[k] = std::max(a.mx[k], b.mx[k]); }
+}
+// true = Some(bound).  `depth`: a list that (transitively) holds itself cannot be built through this API (ids only refer backwards), the guard is belt and braces
+bool graph_bounds(const rt::SceneGraph& g, int32_t id, double t0, double t1, Bound6& out, int depth) {
+    if (depth > 64) return false;
+    const GraphObj& o = g.objs[size_t(id)];
+    switch (o.kind) {
+    case GraphObj::SPHERE_K: // hittable.rs:125-130: centre -+ radius, literally (a negative radius gives min > max there too)
+        for (int k = 0; k < 3; ++k) { out.mn[k] = o.v[k] - o.v[3]; out.mx[k] = o.v[k] + o.v[3]; }
+        return true;
+    case GraphObj::MOVING_K: { // hittable.rs:233-244 with center(time) of :187-191
+        Bound6 b[2];
+        const double tt[2] = {t0, t1};
+        for (int e = 0; e < 2; ++e) {
+            const double f = (tt[e] - o.v[6]) / (o.v[7] - o.v[6]);
+            for (int k = 0; k < 3; ++k) {
+                const double c = o.v[k] + f * (o.v[3 + k] - o.v[k]);
+                b[e].mn[k] = c - o.v[8]; b[e].mx[k] = c + o.v[8];
+            }
+        }
+        out = b[0];
+        surround(out, b[1]);
+        return true;
+    }
+    case GraphObj::RECT_K: { // hittable.rs:532-546: the two ranges as given, k -+ 0.0001
+        const int a0 = o.c == 2 ? 1 : 0, a1 = o.c == 0 ? 1 : 2, ka = o.c == 0 ? 2 : (o.c == 1 ? 1 : 0);
+        out.mn[a0] = o.v[0]; out.mx[a0] = o.v[1];
+        out.mn[a1] = o.v[2]; out.mx[a1] = o.v[3];
+        out.mn[ka] = o.v[4] - 0.0001; out.mx[ka] = o.v[4] + 0.0001;
+        return true;
+    }
+    case GraphObj::CUBE_K: // hittable.rs:585-591: the two corners as given
+        for (int k = 0; k < 3; ++k) { out.mn[k] = o.v[k]; out.mx[k] = o.v[3 + k]; }
+        return true;
+    case GraphObj::LIST_K: { // hittable.rs:165-176: None for an empty list or when any member has none
+        if (o.items.empty()) return false;
+        if (!graph_bounds(g, o.items[0], t0, t1, out, depth + 1)) return false;
+        for (size_t i = 1; i < o.items.size(); ++i) {
+            Bound6 b;
+            if (!graph_bounds(g, o.items[i], t0, t1, b, depth + 1)) return false;
+            surround(out, b);
+        }
+        return true;
+    }
+    case GraphObj::BVH_K: { // hittable.rs:370-372: the bound stored at construction — BvhTree::from = from_time(list, 0., 1.) (:255-257), whatever is asked;
+        // the surrounding of the members' boxes, a member without one counted as Bound::default() like :306-317
+        bool first = true;
+        for (int32_t it : o.items) {
+            Bound6 b;
+            if (!graph_bounds(g, it, 0.0, 1.0, b, depth + 1)) b = Bound6{{0, 0, 0}, {0, 0, 0}};
+            if (first) { out = b; first = false; } else surround(out, b);
+        }
+        return !first;
+    }
+    case GraphObj::TRANSLATE_K: { // hittable.rs:619-628
+        if (!graph_bounds(g, o.a, t0, t1, out, depth + 1)) return false;
+        for (int k = 0; k < 3; ++k) { out.mn[k] += o.v[k]; out.mx[k] += o.v[k]; }
+        return true;
+    }
+    case GraphObj::ROTATE_K: { // hittable.rs:645-676,719-721: the item's box over (0., 1.), its eight corners turned about y, stored at construction and
+        // returned whatever is asked.  The CORRECT rotation: the reference's z line reads the x it has just overwritten (:661-662, SURVEY quirk Q2 —
+        // latent there, no YRotate is ever put into a BvhTree); a box that does not contain its object is not something to reproduce
+        Bound6 b;
+        if (!graph_bounds(g, o.a, 0.0, 1.0, b, depth + 1)) b = Bound6{{0, 0, 0}, {0, 0, 0}}; // (has_bound = false: Default::default(), :647-649)
+        const double rad = o.v[0] * (3.14159265358979323846 / 180.0), sn = std::sin(rad), cs = std::cos(rad);
+        for (int k = 0; k < 3; ++k) { out.mn[k] = INFINITY; out.mx[k] = -INFINITY; }
+        for (int c = 0; c < 8; ++c) {
+            const double x = (c & 1) ? b.mx[0] : b.mn[0], y = (c & 2) ? b.mx[1] : b.mn[1], z = (c & 4) ? b.mx[2] : b.mn[2];
+            const double p[3] = {cs * x + sn * z, y, -sn * x + cs * z};
+            for (int k = 0; k < 3; ++k) { out.mn[k] = std::min(out.mn[k], p[k]); out.mx[k] = std::max(out.mx[k], p[k]); }
+        }
+        return true;
+    }
+    case GraphObj::MEDIUM_K: // hittable.rs:798-800: the boundary's
+        return graph_bounds(g, o.a, t0, t1, out, depth + 1);
+    default:
+        return false;
+    }
+}
+} // namespace
+int rttnw_hittable_bounds(const rttnw_scene* s, rttnw_id hittable, double initial_time, double final_time, double out_min_max[6]) {
+    if (!s || !out_min_max) return fail(RTTNW_ERR_INVALID, "hittable_bounds: NULL argument");
+    if (!s->graph.is_hittable(hittable)) return fail(RTTNW_ERR_INVALID, "hittable_bounds: bad hittable id");
+    Bound6 b;
+    if (!graph_bounds(s->graph, hittable, initial_time, final_time, b, 0)) return 0; // None
+    for (int k = 0; k < 3; ++k) { out_min_max[k] = b.mn[k]; out_min_max[3 + k] = b.mx[k]; }
+    return 1;
+}
 int rttnw_scene_set_world(rttnw_scene* s, rttnw_id world) {
     if (int rc = check_open(s)) return rc;
     auto& g = s->graph;

@@ -121,9 +121,13 @@ int reference_frame_scene(::rttnw_scene* s, const FlatScene*& flat) {
     if (!s->flat_ref) {
         std::string err;
         DeviceBvhApi device_builder;
-        const bool on_device = s->bvh_builder != RTTNW_BVH_HOST_SAH;
+        bool on_device = s->bvh_builder != RTTNW_BVH_HOST_SAH;
         if (on_device)
-            if (int brc = device_bvh_builder(s, device_builder, err)) { set_last_error(err); return brc; }
+            if (int brc = device_bvh_builder(s, device_builder, err)) {
+                // (as rttnw_scene_commit, capi_builder.cpp: RTTNW_BVH_AUTO falls back to the host builder; an explicitly requested device builder fails)
+                if (s->bvh_builder != RTTNW_BVH_AUTO) { set_last_error(err); return brc; }
+                on_device = false;
+            }
         std::unique_ptr<FlatScene> ref(new FlatScene());
         // RTTNW_STRICT_GROUP_TREES=1 (experiments / tests): the round-4 form — the copies stay in their groups' trees and the walk enters them
         const char* gt = getenv("RTTNW_STRICT_GROUP_TREES");

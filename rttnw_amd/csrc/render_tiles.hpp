@@ -212,7 +212,8 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             const bool lean_kernel = !count && !gen && no_inst && no_time;
             const uint32_t wave_bytes = wave_lds_bytes<R>(rc.stack_depth, lean_kernel);
             int wblock = lean_kernel ? int(wave_block_waves(wave_bytes)) * 64 : TRACE_BLOCK;
-            if (const char* e = getenv("RTTNW_WAVE_BLOCK")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0 && v <= (lean_kernel ? 1024 : TRACE_BLOCK)) wblock = v; }
+            // (clamped to what a CU's LDS holds: 16 f64 waves would ask for 198 KB and fail the whole render instead of running with 13)
+            if (const char* e = getenv("RTTNW_WAVE_BLOCK")) { const int v = atoi(e); if (v >= 64 && v % 64 == 0 && v <= (lean_kernel ? 1024 : TRACE_BLOCK)) wblock = lean_kernel ? std::min(v, wblock) : v; }
             const size_t lds_bytes = size_t(wave_bytes) * size_t(wblock / 64);
             size_t grid = 1;
             if (int g = persistent_grid((const void*)kernel, lds_bytes, (n_jobs + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE, grid, wblock)) return g;

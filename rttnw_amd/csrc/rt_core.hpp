@@ -736,12 +736,17 @@ RT_HD int box_classify(const BoxRec<R>& bx, const Ray<R>& ray, const SlabRay<R>&
     const R o[3] = {ray.o.x, ray.o.y, ray.o.z};
     float nr[3], fr[3], S = 0.f;
     bool ng[3]; // (no array is indexed by a run-time axis below: that would put it — and the walk's state around it — in scratch)
+    bool inverted = false; // a cube built from corners with mn > mx on an axis (rttnw_cube stores what it is given, like Cube::new hittable.rs:551-558):
+                           // the reference's six half-open rectangles still hit the two faces across that axis, while near / far below — chosen by the
+                           // direction's sign alone — would swap and the verdicts with them: such a record is box_t's (round-5 advisor)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float inv = slab_inv32(sr, a);
         float oi;
         if constexpr (sizeof(R) == 8) oi = sr.oinv[a]; else oi = float(o[a]) * inv;
-        const float t0 = __builtin_fmaf(float(bx.mn[a]), inv, -oi), t1 = __builtin_fmaf(float(bx.mx[a]), inv, -oi);
+        const float mn32 = float(bx.mn[a]), mx32 = float(bx.mx[a]);
+        inverted |= mn32 > mx32;
+        const float t0 = __builtin_fmaf(mn32, inv, -oi), t1 = __builtin_fmaf(mx32, inv, -oi);
         const bool neg = inv < 0.f;
         ng[a] = neg;
         nr[a] = neg ? t1 : t0;
@@ -752,6 +757,7 @@ RT_HD int box_classify(const BoxRec<R>& bx, const Ray<R>& ray, const SlabRay<R>&
     const float n2 = rt_med3(nr[0], nr[1], nr[2]), f2 = rt_med3(fr[0], fr[1], fr[2]);
     const float g = (S + rt_fabs(tn) + rt_fabs(tf)) * RT_BOX_FAST_MARGIN;
     const float lo = float(t_min), hi = float(t_max);
+    if (inverted) return 2;
     if constexpr (FORM == 0) {
         if (tn - tf >= g || lo - tf >= g || tn - hi >= g) return 0;
         if (!(tf - tn >= g)) return 2;

@@ -935,7 +935,9 @@ struct Lowering {
         const auto t_mats = now();
         if (const char* e = getenv("RTTNW_SAH_LEAF_COST")) { const double v = std::atof(e); if (v > 0) leaf_cost = v; }
         if (world_spheres_arg >= 0) { move_spheres = world_spheres_arg != 0; test_in_group_frame = world_spheres_arg == 2; }
-        else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) { move_spheres = std::atoi(e) != 0; test_in_group_frame = std::atoi(e) == 2; }
+        // (the environment chooses between 0 and 1 only: leaves of kind PRIM_SPHERE_WC — 2 — exist for the relowering RTTNW_F64_STRICT renders, asked for
+        // by argument; the contracted kernels are compiled without that kind, and a default lowering that emitted it would lose those spheres)
+        else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
         ItemVec top;
         top_items = &top;
         collect(g.world, top, Chain{});
@@ -1025,6 +1027,7 @@ int lower_scene(const SceneGraph& g, FlatScene& out, std::string& err, const Dev
         lw.world_spheres_arg = world_spheres;
         const int rc = lw.run();
         out.n_world_copies = uint32_t(lw.world_spheres.size());
+        out.decide_lean();
         if (rc != 0 || max_leaf == 4 || fits_lds_form(out)) return rc;
     }
     return 0;

@@ -95,11 +95,12 @@ struct FlatScene {
     uint32_t n_world_copies = 0;      // spheres of transformed groups that the walk tests as world-space copies in the top tree (scene_lower.cpp collect)
     // A LEAN scene: no MovingSphere, no ConstantMedium, every material a solid colour (lowered into its record: tex < 0) — the kernels have
     // instantiations without the code of any of them (rt_core.hpp SHAPES_NONE_NT / SHAPES_SINGLE_NT).
-    bool lean() const {
-        if (!moving.empty() || !media.empty()) return false;
-        for (const auto& m : mats)
-            if (m.tex >= 0) return false;
-        return true;
+    // (decided ONCE, at the end of lower_scene: spheres_1m has 10^6 materials, and the render path asks this before every launch)
+    bool is_lean = false;
+    bool lean() const { return is_lean; }
+    void decide_lean() {
+        is_lean = moving.empty() && media.empty();
+        for (size_t i = 0; is_lean && i < mats.size(); ++i) is_lean = mats[i].tex < 0;
     }
 };
 

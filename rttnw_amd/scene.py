@@ -115,6 +115,13 @@ class Scene:
         tex = tex_or_rgb if isinstance(tex_or_rgb, int) else self.solid(tex_or_rgb)
         return self._id(self.b.constant_medium(self.handle, boundary, density, tex), "constant_medium")
 
+    def bounding_box(self, hittable, initial_time=0.0, final_time=1.0):
+        """`Hittable::bounding_box(initial_time, final_time)` (hittable.rs:50): (min, max) as two arrays of 3, or None (an empty List)."""
+        out = np.zeros(6)
+        rc = check(self.b.hittable_bounds(self.handle, hittable, initial_time, final_time, out.ctypes.data_as(C.POINTER(C.c_double))), self.b,
+                   "hittable_bounds")
+        return (out[:3].copy(), out[3:].copy()) if rc == 1 else None
+
     def set_world(self, lst):
         check(self.b.scene_set_world(self.handle, lst), self.b, "scene_set_world")
 

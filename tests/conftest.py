@@ -44,7 +44,8 @@ def hostsim():
     b = abi.Binding(lib, "rttnw_", abi.BUILDER_FUNCS)
     b.add([("builder", C.c_void_p, []),
            ("debug_scene_nodes", C.c_int, [abi.scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
-           ("debug_scene_nodes4", C.c_int, [abi.scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)])])
+           ("debug_scene_nodes4", C.c_int, [abi.scene_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]),
+           ("hittable_bounds", C.c_int, [abi.scene_p, abi.c_id, C.c_double, C.c_double, C.POINTER(C.c_double)])])
     lib.hostsim_render.restype = C.c_int
     lib.hostsim_render.argtypes = [C.c_void_p, C.POINTER(abi.CameraDesc), C.POINTER(abi.Params), C.c_void_p,
                                    C.POINTER(abi.Stats), C.c_int]

@@ -69,6 +69,7 @@ struct Params {
     uint32_t precull_pct;
     uint32_t xcds;           // 0: batches strided over the whole render; k > 0: this cache's waves take every k-th batch starting at batch_offset
     uint32_t batch_offset;
+    uint32_t unified;        // 1: node and sphere records share ONE buffer — node_perm / sphere_perm are positions in 32-byte units of it
     uint32_t node_bytes;     // 64 (quantised records) / 128
 };
 
@@ -141,13 +142,14 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
     };
     auto node_access = [&](int32_t idx) {
         const uint64_t at = node_perm ? node_perm[idx] : uint32_t(idx);
-        const bool hit = l2.touch(S_NODE, at * P.node_bytes >> 7, false);
+        const bool hit = l2.touch(S_NODE, P.unified ? at * 32u >> 7 : at * P.node_bytes >> 7, false);
         ++node_visits;
         const uint32_t d = depth[size_t(idx)];
         ++dacc[d];
         if (!hit) ++dmiss[d];
     };
-    auto sphere_line = [&](uint32_t idx) { return (uint64_t(sphere_perm ? sphere_perm[idx] : idx) * P.sphere_bytes) >> 7; };
+    auto sphere_line = [&](uint32_t idx) { return (uint64_t(sphere_perm ? sphere_perm[idx] : idx) * (P.unified ? 32u : P.sphere_bytes)) >> 7; };
+    const uint32_t S_SPH = P.unified ? uint32_t(S_NODE) : uint32_t(S_SPHERE);
 
     uint32_t live = P.n_waves;
     while (live != 0 && samples_done < total) {
@@ -173,7 +175,7 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
                             for (uint32_t a = 3; a < 6; ++a) pool(S_POOL_HOT, a, 4, g, false);
                             if (sl.found && ref_kind(sl.best.prim) == PRIM_SPHERE) {
                                 const uint32_t idx = ref_index(sl.best.prim);
-                                l2.touch(S_SPHERE, sphere_line(idx), false); // make_record reads the centre again
+                                l2.touch(S_SPH, sphere_line(idx), false); // make_record reads the centre again
                                 uint64_t mat_at;
                                 if (P.mat_by_sphere) mat_at = uint64_t(sphere_perm ? sphere_perm[idx] : idx);
                                 else {
@@ -265,7 +267,7 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
                         fetch = sphere_t(V3<R>(sp.cx, sp.cy, sp.cz), sp.r * R(1.0 + 0.01 * P.precull_pct), ray, t_min, l.tr.closest, tt);
                     }
                     ++sphere_tests;
-                    if (fetch) l2.touch(S_SPHERE, sphere_line(idx), false); else ++skipped;
+                    if (fetch) l2.touch(S_SPH, sphere_line(idx), false); else ++skipped;
                 }
                 trav_leaf_step(l.tr, hs.view, ray, t_min, l.stack, cnt);
             }

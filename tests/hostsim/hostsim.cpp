@@ -520,7 +520,7 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
 // replaces (box_t), on n generated cases in the host build's arithmetic (IEEE, nothing contracted = the reference's): random boxes from 1e-3 to 1e4,
 // origins far, near, ON a face plane (the ray that has just scattered off the cube) and inside; directions at the box, at its corners / edges /
 // face points displaced by 0 .. 1e-3 of the box, random, axis-parallel; ranges open, or ending / starting at, one ulp off, or 1e-9 off the exact t of
-// a face.  out = {mismatches, verdict 0, verdict 1, verdict 2, hits, index of the first mismatch}.
+// a face.  out = {mismatches, verdict 0, verdict 1, verdict 2, hits, index of the first mismatch, inverted / flat boxes among the cases}.
 template <typename R, int FORM> static void box_fast_check_t(uint64_t n, uint64_t seed, uint64_t* out) {
     uint64_t st = (seed ^ 0xD1B54A32D192ED03ull) * 0xBF58476D1CE4E5B9ull; // (streams of different seeds must not be shifts of one another)
     st = (st ^ (st >> 29)) * 0x94D049BB133111EBull + seed;
@@ -528,7 +528,7 @@ template <typename R, int FORM> static void box_fast_check_t(uint64_t n, uint64_
     auto uni = [&]() { return double(next() >> 11) * (1.0 / 9007199254740992.0); };
     auto sym = [&]() { return 2.0 * uni() - 1.0; };
     const double eps_set[8] = {0.0, 1e-16, 1e-14, 1e-12, 1e-9, 1e-6, 1e-4, 1e-3};
-    out[0] = out[1] = out[2] = out[3] = out[4] = 0; out[5] = ~0ull;
+    out[0] = out[1] = out[2] = out[3] = out[4] = out[6] = 0; out[5] = ~0ull;
     for (uint64_t i = 0; i < n; ++i) {
         const double scale = std::pow(10.0, std::floor(uni() * 7.0) - 3.0);
         BoxRec<R> bx{};
@@ -538,6 +538,15 @@ template <typename R, int FORM> static void box_fast_check_t(uint64_t n, uint64_
             h[a] = scale * std::pow(10.0, uni() * 4.0 - 3.0);
             bx.mn[a] = R(c[a] - h[a]); bx.mx[a] = R(c[a] + h[a]);
             if (!(bx.mn[a] < bx.mx[a])) bx.mx[a] = std::nextafter(bx.mn[a], R(1e30));
+        }
+        // one case in eight: a cube from corners that are not min / max on one or two axes (Cube::new takes any two points, hittable.rs:551-558:
+        // its rectangles' half-open ranges are then empty on that axis) or that coincide on an axis (zero thickness) — out[6] counts them
+        if ((next() & 7u) == 0u) {
+            const uint32_t what = uint32_t(next() % 3), k1 = uint32_t(next() % 3), k2 = uint32_t(next() % 3);
+            if (what == 0) std::swap(bx.mn[k1], bx.mx[k1]);
+            else if (what == 1) { std::swap(bx.mn[k1], bx.mx[k1]); if (k2 != k1) std::swap(bx.mn[k2], bx.mx[k2]); }
+            else bx.mx[k1] = bx.mn[k1];
+            out[6] += 1;
         }
         double o[3], d[3];
         const uint32_t mode = uint32_t(next() % 10);
@@ -602,7 +611,7 @@ void hostsim_cache_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rtt
     P.n_waves = prm[0]; P.ways = prm[1]; P.node_steps = prm[2]; P.retire = prm[3]; P.warm_samples_per_slot = prm[4]; P.measure_samples_per_slot = prm[5];
     P.cache_bytes = uint64_t(prm[6]) | (uint64_t(prm[7]) << 32);
     P.sphere_bytes = prm[8]; P.mat_bytes = prm[9]; P.mat_by_sphere = prm[10]; P.real_bytes = prm[11]; P.precull = prm[12]; P.precull_pct = prm[13];
-    P.xcds = prm[14]; P.node_bytes = prm[15]; P.batch_offset = prm[16];
+    P.xcds = prm[14]; P.node_bytes = prm[15]; P.batch_offset = prm[16]; P.unified = prm[17];
     if (p->precision == RTTNW_F32) cache_model::run<float>(s, cam, p, P, node_perm, sphere_perm, out);
     else cache_model::run<double>(s, cam, p, P, node_perm, sphere_perm, out);
 }

@@ -405,6 +405,14 @@ def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib, precision):
     else:
         differ = (np.abs(lin - lin2).max(axis=2) > 0).mean()
         assert differ <= 0.25 and abs(lin.mean() - lin2.mean()) <= 0.01 * lin.mean(), (differ, lin.mean(), lin2.mean())
+        # what the docstring promises, asserted: a pixel all of whose samples missed everything is the background EXACTLY (a mean of equal values) in both
+        # forms — the same pixels, and a good part of this frame (the cloud does not fill it); and where the forms differ they differ like two
+        # estimates of one pixel, not like a broken one: within the spread of a 4-sample mean on this scene (light 7 behind the cloud, albedo < 1)
+        bg = lin[0, 0]   # (the frame's corner sees only sky: the value every all-sky pixel has — the same chain of additions on the same constant)
+        assert np.allclose(bg, np.asarray(p.background[:3]), rtol=1e-6)
+        sky, sky2 = (lin == bg).all(axis=2), (lin2 == bg).all(axis=2)
+        assert np.array_equal(sky, sky2) and 0.02 <= sky.mean() <= 0.98, sky.mean()
+        assert np.abs(lin - lin2).max() <= 6.0 * 1.0 / np.sqrt(4) + 1.0 / 256, np.abs(lin - lin2).max()
 
 
 @pytest.mark.parametrize("precision", [abi.F64_STRICT, abi.F64, abi.F32], ids=["f64strict", "f64", "f32"])

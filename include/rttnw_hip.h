@@ -225,7 +225,7 @@ typedef struct rttnw_stats {
     uint32_t n_nodes;        /* flat scene size: 4-wide node records */
     uint32_t n_prims;
     uint32_t scene_bytes;    /* bytes of node+primitive arrays resident on the device */
-    uint32_t reserved;       /* render: kernel form that ran — bit 0: decoupled (else lane-owns-path), bit 1: node records resident in LDS, bit 2: three node steps per walk trip (tiny top trees), bit 3: the instantiation whose walk never changes frames (no Translate / YRotate group with a tree of its own), bit 4: ... but tests single wrapped records in place, bit 5: ... in the LEAN flavour (the scene has no MovingSphere, no ConstantMedium and only solid colours: their code is compiled out); scene_info: stack depth */
+    uint32_t reserved;       /* render: kernel form that ran — bit 0: decoupled (else lane-owns-path), bit 1: node records resident in LDS, bit 2: three node steps per walk trip (tiny top trees), bit 3: the instantiation whose walk never changes frames (no Translate / YRotate group with a tree of its own), bit 4: ... but tests single wrapped records in place, bit 5: ... in the LEAN flavour (the scene has no MovingSphere, no ConstantMedium and only solid colours: their code is compiled out); rttnw_render_multi, rank 0 only — bit 8: the gather went through peer copies (RTTNW_MULTI_GATHER=peer), bit 9: ... because the RCCL set-up failed; scene_info: stack depth */
 } rttnw_stats;
 
 /* Framebuffer partition: 8x8-pixel tiles, tile t owned by rank
@@ -253,7 +253,10 @@ int rttnw_render(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_param
  * device-to-device copy for ranks that share rank 0's device — and un-tiled there.  A device may appear more than once
  * (logical ranks; they run one after the other on it), so any partition can be exercised on a single GPU.  The image is
  * bit-identical to rttnw_render's for every ngpu.  Outputs as rttnw_render; `p->tile_rank` / `p->tile_world` are ignored;
- * `stats` (optional) points to ngpu records: samples and device time (trace + resolve) of each rank.  Blocking. */
+ * `stats` (optional) points to ngpu records: samples and device time (trace + resolve) of each rank.  Blocking.
+ * Environment: RTTNW_MULTI_GATHER=rccl (default) | peer — `peer` gathers with hipMemcpyPeerAsync on each rank's stream (an event orders
+ * the root's un-tile behind it) instead of RCCL; the call falls through to it by itself, with one line on stderr, when RCCL cannot be loaded
+ * or ncclCommInitAll fails (stats[0].reserved bits 8 / 9). */
 int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t ngpu,
                        const int32_t* device_ids, double* out_linear_rgb, uint8_t* out_rgba8, rttnw_stats* stats);
 

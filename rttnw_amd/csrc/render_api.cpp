@@ -431,47 +431,104 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
         HIP_TRY(hipEventRecord(ev[2 * r + 1], d->stream));
     }
 
-    // ---- gather to the root: a device-to-device copy for ranks on the root's device, RCCL send/recv over xGMI for the others.
-    // RTTNW_MULTI_FORCE_RCCL=1 (tests): the ranks on the root's device travel through RCCL too — a grouped ncclSend / ncclRecv
-    // of the root to itself — so that the dlopen'ed entry points, the communicator set-up, the stream ordering and the
-    // error paths run on a box with ONE GPU as well.
+    // ---- gather to the root: a device-to-device copy for ranks on the root's device; for the others one of TWO transports over xGMI
+    // (RTTNW_MULTI_GATHER=rccl|peer, default rccl):
+    //   rccl  a grouped ncclSend / ncclRecv per rank buffer (north_star's "RCCL gather over xGMI"; communicators cached per device list);
+    //   peer  hipMemcpyPeerAsync of each rank's packed tiles into the root's gather buffer on the RANK's stream, an event behind it that the
+    //         root's stream waits for — 5 MB per rank, no library, no communicator.  Also what the call FALLS THROUGH to when RCCL cannot be
+    //         loaded or ncclCommInitAll fails (one stderr line; rttnw_stats.reserved bit 9 of rank 0), so that a node whose RCCL is broken
+    //         still renders.  Bit 8 of stats[0].reserved: the gather went through peer copies.
+    // RTTNW_MULTI_FORCE_TRANSPORT=1 (tests; RTTNW_MULTI_FORCE_RCCL=1 is the older name): the ranks on the root's device travel through the
+    // transport too — the root sending to itself — so that the dlopen'ed entry points, the communicator set-up, the peer copies, the stream
+    // ordering and the error paths run on a box with ONE GPU as well.  RTTNW_MULTI_FAIL_RCCL=1 (tests): the RCCL set-up reports failure.
     const char* force_env = getenv("RTTNW_MULTI_FORCE_RCCL");
-    const bool force_rccl = force_env && force_env[0] == '1';
-    if (distinct.size() > 1 || force_rccl) {
+    const char* force_env2 = getenv("RTTNW_MULTI_FORCE_TRANSPORT");
+    const bool force_rccl = (force_env && force_env[0] == '1') || (force_env2 && force_env2[0] == '1'); // (every rank through the transport)
+    const char* gather_env = getenv("RTTNW_MULTI_GATHER");
+    bool use_peer = gather_env && std::string(gather_env) == "peer";
+    if (gather_env && !use_peer && std::string(gather_env) != "rccl") { set_last_error("render_multi: RTTNW_MULTI_GATHER must be rccl or peer"); return RTTNW_ERR_INVALID; }
+    bool fell_back = false;
+    const bool debug_multi = getenv("RTTNW_DEBUG_MULTI") != nullptr;
+    if ((distinct.size() > 1 || force_rccl) && !use_peer) {
         std::unique_lock<std::mutex> comms_lock(g_comms_mutex);
-        if (!g_rccl.load(err)) { set_last_error("render_multi: " + err); return RTTNW_ERR_HIP; }
         MultiComms* mc = nullptr;
-        for (MultiComms* c : g_comms)
-            if (c->devices == distinct) mc = c;
-        if (!mc) {
-            mc = new MultiComms();
-            mc->devices = distinct;
-            mc->comms.resize(distinct.size());
-            ncclResult_t nr = g_rccl.CommInitAll(mc->comms.data(), int(distinct.size()), distinct.data());
-            if (nr != ncclSuccess) { set_last_error(std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr)); delete mc; return RTTNW_ERR_HIP; }
-            g_comms.push_back(mc); // kept: communicator set-up costs ~100 ms; destroyed by rttnw_shutdown() or at exit
-            if (!g_comms_atexit) { g_comms_atexit = true; std::atexit(destroy_comms); }
-            if (getenv("RTTNW_DEBUG_MULTI")) fprintf(stderr, "[render_multi] RCCL communicators over %zu device(s)\n", distinct.size());
+        std::string why;
+        const char* fail_env = getenv("RTTNW_MULTI_FAIL_RCCL");
+        if (fail_env && fail_env[0] == '1') why = "RTTNW_MULTI_FAIL_RCCL=1";
+        else if (!g_rccl.load(err)) why = err;
+        if (why.empty()) {
+            for (MultiComms* c : g_comms)
+                if (c->devices == distinct) mc = c;
+            if (!mc) {
+                mc = new MultiComms();
+                mc->devices = distinct;
+                mc->comms.resize(distinct.size());
+                ncclResult_t nr = g_rccl.CommInitAll(mc->comms.data(), int(distinct.size()), distinct.data());
+                if (nr != ncclSuccess) {
+                    why = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(nr);
+                    delete mc;
+                    mc = nullptr;
+                } else {
+                    g_comms.push_back(mc); // kept: communicator set-up costs ~100 ms; destroyed by rttnw_shutdown() or at exit
+                    if (!g_comms_atexit) { g_comms_atexit = true; std::atexit(destroy_comms); }
+                    if (debug_multi) fprintf(stderr, "[render_multi] RCCL communicators over %zu device(s)\n", distinct.size());
+                }
+            }
         }
-        // (the list's lock is released, the set's own is taken: two host threads rendering over the SAME devices take turns on
-        // its communicators; threads over different device lists do not wait for each other)
-        std::unique_lock<std::mutex> use(mc->in_use);
-        comms_lock.unlock();
-        ncclResult_t nr = g_rccl.GroupStart();
+        if (!mc) {
+            // nothing has been sent yet: the peer transport does the same job
+            fprintf(stderr, "[render_multi] RCCL gather unavailable (%s): gathering through peer copies\n", why.c_str());
+            use_peer = fell_back = true;
+        } else {
+            // (the list's lock is released, the set's own is taken: two host threads rendering over the SAME devices take turns on
+            // its communicators; threads over different device lists do not wait for each other)
+            std::unique_lock<std::mutex> use(mc->in_use);
+            comms_lock.unlock();
+            ncclResult_t nr = g_rccl.GroupStart();
+            uint32_t n_sent = 0;
+            for (uint32_t r = 0; r < ngpu && nr == ncclSuccess; ++r) {
+                size_t k = 0;
+                while (distinct[k] != device_ids[r]) ++k;
+                if (k == 0 && !force_rccl) continue; // on the root's device: copied below
+                const void* src = (const char*)st[r]->multi_packed + chunk * slot[r];
+                nr = g_rccl.Send(src, chunk, ncclChar, 0, mc->comms[k], st[r]->stream);
+                if (nr == ncclSuccess) nr = g_rccl.Recv((char*)root->gathered + chunk * r, chunk, ncclChar, int(k), mc->comms[0], root->stream);
+                ++n_sent;
+            }
+            ncclResult_t ne = g_rccl.GroupEnd();
+            if (nr == ncclSuccess) nr = ne;
+            if (nr != ncclSuccess) { set_last_error(std::string("RCCL gather: ") + g_rccl.GetErrorString(nr)); return RTTNW_ERR_HIP; }
+            if (debug_multi) fprintf(stderr, "[render_multi] %u rank buffer(s) of %zu bytes through ncclSend / ncclRecv\n", n_sent, chunk);
+        }
+    }
+    if ((distinct.size() > 1 || force_rccl) && use_peer) {
+        // direct access root <- rank device where the fabric allows it (xGMI: every pair of a node); without it the copy is staged by the runtime
+        for (size_t k = 1; k < distinct.size(); ++k) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, distinct[k], root->device) == hipSuccess && can) {
+                HIP_TRY(hipSetDevice(distinct[k]));
+                const hipError_t e = hipDeviceEnablePeerAccess(root->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+                (void)hipGetLastError();
+            }
+        }
+        std::vector<hipEvent_t> sent(ngpu, nullptr);
+        struct SentFree { std::vector<hipEvent_t>& v; ~SentFree() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); } } sent_free{sent};
         uint32_t n_sent = 0;
-        for (uint32_t r = 0; r < ngpu && nr == ncclSuccess; ++r) {
-            size_t k = 0;
-            while (distinct[k] != device_ids[r]) ++k;
-            if (k == 0 && !force_rccl) continue; // on the root's device: copied below
+        for (uint32_t r = 0; r < ngpu; ++r) {
+            if (device_ids[r] == root->device && !force_rccl) continue; // on the root's device: copied below
+            HIP_TRY(hipSetDevice(st[r]->device));
             const void* src = (const char*)st[r]->multi_packed + chunk * slot[r];
-            nr = g_rccl.Send(src, chunk, ncclChar, 0, mc->comms[k], st[r]->stream);
-            if (nr == ncclSuccess) nr = g_rccl.Recv((char*)root->gathered + chunk * r, chunk, ncclChar, int(k), mc->comms[0], root->stream);
+            HIP_TRY(hipMemcpyPeerAsync((char*)root->gathered + chunk * r, root->device, src, st[r]->device, chunk, st[r]->stream));
+            HIP_TRY(hipEventCreateWithFlags(&sent[r], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(sent[r], st[r]->stream));
             ++n_sent;
         }
-        ncclResult_t ne = g_rccl.GroupEnd();
-        if (nr == ncclSuccess) nr = ne;
-        if (nr != ncclSuccess) { set_last_error(std::string("RCCL gather: ") + g_rccl.GetErrorString(nr)); return RTTNW_ERR_HIP; }
-        if (getenv("RTTNW_DEBUG_MULTI")) fprintf(stderr, "[render_multi] %u rank buffer(s) of %zu bytes through ncclSend / ncclRecv\n", n_sent, chunk);
+        HIP_TRY(hipSetDevice(root->device));
+        for (uint32_t r = 0; r < ngpu; ++r)
+            if (sent[r]) HIP_TRY(hipStreamWaitEvent(root->stream, sent[r], 0)); // the un-tile below reads what the ranks' streams have written
+        if (debug_multi) fprintf(stderr, "[render_multi] %u rank buffer(s) of %zu bytes through hipMemcpyPeerAsync\n", n_sent, chunk);
+        // (the events are destroyed when this block ends: a recorded event may be destroyed while work waits on it — the wait was enqueued)
     }
     HIP_TRY(hipSetDevice(root->device));
     if (!force_rccl)
@@ -493,6 +550,7 @@ extern "C" int rttnw_render_multi(rttnw_scene* s, const rttnw_camera_desc* cam, 
             HIP_TRY(hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]));
             stats[r].kernel_ms = ms; // trace + resolve of this rank
         }
+    if (stats && use_peer && (distinct.size() > 1 || force_rccl)) stats[0].reserved |= 0x100u | (fell_back ? 0x200u : 0u);
     HIP_TRY(hipSetDevice(root->device));
     if (out_rgba8) HIP_TRY(hipMemcpy(out_rgba8, root->rgba, npx * 4, hipMemcpyDeviceToHost));
     if (out_linear_rgb) {

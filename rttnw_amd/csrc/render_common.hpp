@@ -161,13 +161,13 @@ template <typename R> struct DeviceScene {
         for (double v : f.perlin_vec) pv.push_back(R(v));
 
         int rc;
-        if ((rc = upload_nodes(f)) || (rc = spheres.upload(sp)) || (rc = sphere_mat.upload(f.sphere_mat)) ||
+        if ((rc = upload_nodes(f)) || (rc = spheres.upload(sp)) || (!f.sphere_mat_is_index && (rc = sphere_mat.upload(f.sphere_mat))) ||
             (rc = sphere_seq.upload(f.sphere_seq)) || (rc = moving.upload(mv)) || (rc = rects.upload(rc_)) ||
             (rc = boxes.upload(bx)) || (rc = insts.upload(in)) || (rc = media.upload(md)) || (rc = medium_refs.upload(f.medium_refs)) || (rc = mats.upload(mt)) ||
             (rc = texs.upload(tx)) || (rc = images.upload(f.images)) || (rc = texels.upload(f.texels)) ||
             (rc = perlin_vec.upload(pv)) || (rc = perlin_perm.upload(f.perlin_perm)))
             return rc;
-        view.nodes = nodes.p; view.nodes4q = nullptr; view.spheres = spheres.p; view.sphere_mat = sphere_mat.p; view.sphere_seq = sphere_seq.p;
+        view.nodes = nodes.p; view.nodes4q = nullptr; view.spheres = spheres.p; view.sphere_mat = f.sphere_mat_is_index ? nullptr : sphere_mat.p; view.sphere_seq = sphere_seq.p;
         view.moving = moving.p; view.rects = rects.p; view.boxes = boxes.p; view.insts = insts.p; view.media = media.p; view.medium_refs = medium_refs.p;
         view.mats = mats.p; view.texs = texs.p; view.images = images.p; view.texels = texels.p;
         view.perlin_vec = perlin_vec.p; view.perlin_perm = perlin_perm.p;

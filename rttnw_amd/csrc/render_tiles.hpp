@@ -152,7 +152,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
                 }
                 {
                     const size_t bytes = lds_pad32(flat.sphere_mat.size() * 4);
-                    if (!flat.sphere_mat.empty() && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes + bytes <= 160 * 1024) {
+                    if (!flat.sphere_mat.empty() && !flat.sphere_mat_is_index && lds_form_bytes(n4, rc.stack_depth, LDS_BLOCK) + perlin_bytes + bytes <= 160 * 1024) {
                         rc.lds_recs[4] = uint32_t(flat.sphere_mat.size());
                         perlin_bytes += bytes;
                     }

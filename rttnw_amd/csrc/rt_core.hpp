@@ -1234,6 +1234,18 @@ template <bool G, typename R> RT_HD bool sphere_wc_t(const SceneView<R>& sc, uin
     const Ray<R> obj = to_object<G>(in, wray);
     return sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, obj, t_min, t_max, t);
 }
+// A record passed its test at t: it becomes the incumbent — unless it TIES the incumbent exactly and comes earlier in list order (hittable.rs:157-159)
+template <typename R> RT_HD void trav_accept(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t, int aux, int32_t inst) {
+    const bool loses_tie = tr.found && t == tr.closest &&
+                           prim_seq(sc, kind, idx) < prim_seq(sc, ref_kind(tr.best.prim), ref_index(tr.best.prim));
+    if (!loses_tie) {
+        tr.closest = t;
+        tr.best.prim = make_ref(kind, idx);
+        tr.best.inst = inst;
+        tr.best.aux = aux;
+        tr.found = true;
+    }
+}
 // FRAME_RAY: `ray` is the ray of the walk's current frame — the one tr.sr was made from
 template <bool G = false, bool NO_TIME = false, bool FRAME_RAY = false, typename R> RT_HD void trav_test_record(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
     R t;
@@ -1246,18 +1258,48 @@ template <bool G = false, bool NO_TIME = false, bool FRAME_RAY = false, typename
     } else
 #endif
     hit = prim_t<NO_TIME, FRAME_RAY>(sc, kind, idx, ray, t_min, tr.closest, t, aux, tr.sr);
-    if (hit) {
-        // exact tie with the incumbent: the later object in list order wins (hittable.rs:157-159)
-        const bool loses_tie = tr.found && t == tr.closest &&
-                               prim_seq(sc, kind, idx) < prim_seq(sc, ref_kind(tr.best.prim), ref_index(tr.best.prim));
-        if (!loses_tie) {
-            tr.closest = t;
-            tr.best.prim = make_ref(kind, idx);
-            tr.best.inst = inst;
-            tr.best.aux = aux;
-            tr.found = true;
+    if (hit) trav_accept(tr, sc, kind, idx, t, aux, inst);
+}
+#ifndef RT_LEAF_PREFETCH
+#define RT_LEAF_PREFETCH 0 // experiment (round 6): the lane-owns-path kernels read a leaf's sphere OR cube record before either kind's code runs (see trav_test_record_pre)
+#endif
+// The leaf step of the lane-owns-path kernels with the record READ FIRST: a wave's leaf step is the union of the kinds its lanes stand at — on
+// final_scene a third of them serve spheres AND cubes and take half the leaf clock (profiles/r05/phases_final_scene_f64.txt: 40.5 k clocks against
+// 18.1 k for spheres alone) — and each kind's branch began with its own record read, so such a step waited for memory twice in a row.  Here both
+// reads are issued under their lanes' masks before any test: one wait.  (The cube's face plane is then selected from registers instead of re-read
+// by index.)  Same tests on the same operands: bit-identical.
+template <bool G, bool NO_TIME, typename R> RT_HD void trav_test_record_pre(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
+    SphereRec<R> s{};
+    BoxRec<R> bx{};
+    if (kind == PRIM_SPHERE) s = sc.spheres[idx];
+    if (kind == PRIM_BOX) bx = sc.boxes[idx];
+    R t;
+    int aux = 0;
+    bool hit = false;
+    if (kind == PRIM_SPHERE) {
+        hit = sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, ray, t_min, tr.closest, t);
+    } else if (kind == PRIM_BOX) {
+        int axis = 0;
+        bool use_mx = false;
+        const int verdict = box_classify(bx, ray, tr.sr, t_min, tr.closest, axis, use_mx);
+        if (verdict == 2) {
+            hit = box_t(bx, ray, t_min, tr.closest, t, aux);
+        } else if (verdict == 1) {
+            const R ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
+            const R ok = axis == 0 ? ox : (axis == 1 ? oy : oz);
+            const R dk = axis == 0 ? dx : (axis == 1 ? dy : dz);
+            const R kmn = axis == 0 ? bx.mn[0] : (axis == 1 ? bx.mn[1] : bx.mn[2]), kmx = axis == 0 ? bx.mx[0] : (axis == 1 ? bx.mx[1] : bx.mx[2]);
+            const R k = use_mx ? kmx : kmn;
+            R unused;
+            rt_div2(k - ok, k - ok, dk, t, unused);
+            hit = !(t < t_min) & !(t > tr.closest);
+            aux = 2 * (2 - axis) + (use_mx ? 1 : 0);
         }
+    } else { // the rarer kinds (rectangle, moving sphere, a strict build's world-space copy): as before
+        trav_test_record<G, NO_TIME, true>(tr, sc, kind, idx, t_min, ray, inst);
+        return;
     }
+    if (hit) trav_accept(tr, sc, kind, idx, t, aux, inst);
 }
 template <bool WHOLE_LEAF = false, typename R, typename Stack, typename Cnt>
 RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
@@ -1299,6 +1341,10 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
         trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
+#if RT_LEAF_PREFETCH && RT_BOX_FAST
+        if constexpr (FAST_CUBES) trav_test_record_pre<Cnt::GENERAL, Cnt::NO_TIME>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
+        else
+#endif
         trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, FAST_CUBES>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }
@@ -1357,7 +1403,8 @@ template <bool G, bool NO_TIME = false, typename R> // (NO_TIME = a LEAN scene, 
 RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R t, uint32_t quirks, HitRecord<R>& rec) {
     const uint32_t kind = ref_kind(ref.prim);
     uint32_t idx = ref_index(ref.prim);
-    if (kind == PRIM_SPHERE && ref.inst < 0) { // the world-space copy of a transformed group's sphere: its record is made in
+    // (sc.sphere_mat == nullptr: sphere i's material slot holds i — FlatScene::sphere_mat_is_index, big clouds only: no slot is read, and none is a copy's)
+    if (kind == PRIM_SPHERE && ref.inst < 0 && sc.sphere_mat) { // the world-space copy of a transformed group's sphere: its record is made in
         const int32_t home = sc.sphere_mat[idx]; // object space through the group's chain, like the reference's (scene_lower.cpp)
         if (home & MAT_HOME_FLAG) { idx = uint32_t(home) & MAT_HOME_SPHERE_MASK; ref.inst = (home >> MAT_HOME_INST_SHIFT) & MAT_HOME_INST_MAX; }
     }
@@ -1370,7 +1417,7 @@ RT_HD void make_record(const SceneView<R>& sc, const Ray<R>& wray, HitRef ref, R
         V3<R> c(s.cx, s.cy, s.cz);
         rec.p = ray.at(t);
         outward = (rec.p - c) / s.r;
-        const int32_t mref = sc.sphere_mat[idx];
+        const int32_t mref = sc.sphere_mat ? sc.sphere_mat[idx] : int32_t(idx);
         rec.mat = mref & MAT_INDEX_MASK;
         rec.u = R(0); rec.v = R(0);
         // (f64: deferring these ~250 instructions to the image texture's texel choice, made in f32 wherever f32 is certain of the

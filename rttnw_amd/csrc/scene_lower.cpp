@@ -937,7 +937,13 @@ struct Lowering {
         if (world_spheres_arg >= 0) { move_spheres = world_spheres_arg != 0; test_in_group_frame = world_spheres_arg == 2; }
         // (the environment chooses between 0 and 1 only: leaves of kind PRIM_SPHERE_WC — 2 — exist for the relowering RTTNW_F64_STRICT renders, asked for
         // by argument; the contracted kernels are compiled without that kind, and a default lowering that emitted it would lose those spheres)
-        else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) move_spheres = std::atoi(e) != 0;
+        // (the host test build of the core — tests/hostsim, RT_HOST_TEST_BUILD — knows the kind in every precision and takes 2 from the environment)
+        else if (const char* e = getenv("RTTNW_WORLD_SPHERES")) {
+            move_spheres = std::atoi(e) != 0;
+#if defined(RT_HOST_TEST_BUILD)
+            test_in_group_frame = std::atoi(e) == 2;
+#endif
+        }
         ItemVec top;
         top_items = &top;
         collect(g.world, top, Chain{});

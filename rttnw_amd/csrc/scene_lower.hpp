@@ -101,7 +101,14 @@ struct FlatScene {
     void decide_lean() {
         is_lean = moving.empty() && media.empty();
         for (size_t i = 0; is_lean && i < mats.size(); ++i) is_lean = mats[i].tex < 0;
+        // A big cloud whose spheres were created material-then-sphere, in order (spheres_1m: 10^6 of each), keeps that order through the lowering
+        // when its tree is built on the device (one record per leaf, records in creation order): sphere i's material slot holds i.  The kernels
+        // then take the index itself (SceneView::sphere_mat == nullptr, rt_core.hpp make_record) — on a tree that lives in HBM the slot is an
+        // L2-miss line per hit of its own (tests/hostsim/cache_model.hpp: 4.4 of 92 per sample).  Small scenes keep their slots (LDS-staged).
+        sphere_mat_is_index = spheres.size() >= 65536;
+        for (size_t i = 0; sphere_mat_is_index && i < sphere_mat.size(); ++i) sphere_mat_is_index = sphere_mat[i] == int32_t(i);
     }
+    bool sphere_mat_is_index = false;
 };
 
 // Lower `g` into `out`.  Returns 0 or a negative rttnw_status; `err` receives a message.  `device` (optional)

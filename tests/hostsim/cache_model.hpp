@@ -179,8 +179,8 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
                                 uint64_t mat_at;
                                 if (P.mat_by_sphere) mat_at = uint64_t(sphere_perm ? sphere_perm[idx] : idx);
                                 else {
-                                    l2.touch(S_SPHMAT, uint64_t(idx) * 4u >> 7, false);
-                                    mat_at = uint64_t(uint32_t(hs.view.sphere_mat[idx]) & uint32_t(MAT_INDEX_MASK));
+                                    if (hs.view.sphere_mat) l2.touch(S_SPHMAT, uint64_t(idx) * 4u >> 7, false);
+                                    mat_at = hs.view.sphere_mat ? uint64_t(uint32_t(hs.view.sphere_mat[idx]) & uint32_t(MAT_INDEX_MASK)) : uint64_t(idx);
                                 }
                                 const uint64_t b0 = mat_at * P.mat_bytes, b1 = b0 + P.mat_bytes - 1;
                                 l2.touch(S_MAT, b0 >> 7, false);

@@ -122,7 +122,7 @@ template <typename R> struct HostScene {
         for (double v : f.perlin_vec) perlin_vec.push_back(R(v));
         view.nodes = f.nodes4.data();
         view.nodes4q = nullptr;
-        view.spheres = spheres.data(); view.sphere_mat = f.sphere_mat.data(); view.sphere_seq = f.sphere_seq.data();
+        view.spheres = spheres.data(); view.sphere_mat = f.sphere_mat_is_index ? nullptr : f.sphere_mat.data(); view.sphere_seq = f.sphere_seq.data();
         view.moving = moving.data(); view.rects = rects.data(); view.boxes = boxes.data();
         view.insts = insts.data(); view.media = media.data(); view.medium_refs = f.medium_refs.data(); view.mats = mats.data(); view.texs = texs.data();
         view.images = f.images.data(); view.texels = f.texels.data();

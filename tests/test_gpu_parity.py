@@ -768,38 +768,58 @@ def test_config3_final_scene_1600_at_spp_10000_across_eight_ranks(gpu, oracle, h
 
 
 _RCCL_SCRIPT = r"""
-import sys
+import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
 import numpy as np
 from rttnw_amd import abi, library, render, scene as S
 gpu, scenes = library.product(), library.scenes()
 sc, setup = S.build(gpu, scenes, "final_scene", S.load_earth())
-for prec in (abi.F64, abi.F32):
+bits = set()
+for prec in ((abi.F64, abi.F32) if os.environ.get("RTTNW_MULTI_GATHER") != "peer" and not os.environ.get("RTTNW_MULTI_FAIL_RCCL") else (abi.F64,)):
     cam, p = S.params_for(setup, 104, 72, 6, precision=prec, spp_chunk=3, seed=8)
     one, rgba, _ = render.render_host(sc, cam, p)
     for n in (1, 3, 8):
         lin, rg, st = render.render_multi(sc, cam, p, [0] * n)
         assert np.array_equal(lin, one) and np.array_equal(rg, rgba), (prec, n)
-print("RCCL_LEG_OK")
+        bits.add(int(st[0].reserved) & 0x300)
+print("GATHER_LEG_OK bits=%%s" %% sorted(bits))
 """
 
 
-def test_render_multi_gather_through_rccl_on_one_gpu(gpu, tmp_path):
-    """The RCCL leg of rttnw_render_multi on a box with ONE GPU: RTTNW_MULTI_FORCE_RCCL=1 sends the packed tiles of the ranks
-    that live on the root's device through a grouped ncclSend / ncclRecv of the root to itself instead of a device-to-device
-    copy, so the dlopen'ed entry points, ncclCommInitAll, the grouped calls on the ranks' streams and the un-tile behind them
-    run for real; the image must still equal rttnw_render's bit for bit.  In a child process with a time limit: a
-    communicator that hangs must fail the test, not the box."""
+@pytest.mark.parametrize("transport", ["rccl", "peer", "rccl_fails"])
+def test_render_multi_gather_transports_on_one_gpu(gpu, tmp_path, transport):
+    """Both gather transports of rttnw_render_multi on a box with ONE GPU.  RTTNW_MULTI_FORCE_TRANSPORT=1 sends the packed tiles of the ranks that
+    live on the root's device through the transport — the root to itself — instead of a plain device-to-device copy:
+      rccl        a grouped ncclSend / ncclRecv: the dlopen'ed entry points, ncclCommInitAll, the grouped calls on the ranks' streams and the
+                  un-tile behind them run for real;
+      peer        RTTNW_MULTI_GATHER=peer: hipMemcpyPeerAsync on the rank's stream, an event the root's stream waits for (stats[0].reserved bit 8);
+      rccl_fails  RTTNW_MULTI_FAIL_RCCL=1: the RCCL set-up reports failure — one line on stderr, the call falls through to the peer copies
+                  (bits 8 and 9) and still returns the image.
+    1, 3 and 8 logical ranks each; the image must equal rttnw_render's bit for bit.  In a child process with a time limit: a communicator that hangs
+    must fail the test, not the box.  (The branch over SEVERAL devices — communicators over 8 GPUs, peer access over xGMI — has never run: no such
+    node has been available.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "rccl_leg.py"
+    script = tmp_path / "gather_leg.py"
     script.write_text(_RCCL_SCRIPT % {"root": root})
-    env = dict(os.environ, RTTNW_MULTI_FORCE_RCCL="1", RTTNW_DEBUG_MULTI="1", NCCL_DEBUG="VERSION")
+    env = dict(os.environ, RTTNW_MULTI_FORCE_TRANSPORT="1", RTTNW_DEBUG_MULTI="1", NCCL_DEBUG="VERSION")
+    if transport == "peer":
+        env["RTTNW_MULTI_GATHER"] = "peer"
+    if transport == "rccl_fails":
+        env["RTTNW_MULTI_FAIL_RCCL"] = "1"
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "RCCL_LEG_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
-    assert "RCCL communicators over 1 device(s)" in r.stderr and "through ncclSend / ncclRecv" in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0 and "GATHER_LEG_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    if transport == "rccl":
+        assert "RCCL communicators over 1 device(s)" in r.stderr and "through ncclSend / ncclRecv" in r.stderr, r.stderr[-4000:]
+        assert "bits=[0]" in r.stdout, r.stdout[-500:]
+    elif transport == "peer":
+        assert "through hipMemcpyPeerAsync" in r.stderr and "ncclSend" not in r.stderr, r.stderr[-4000:]
+        assert "bits=[256]" in r.stdout, r.stdout[-500:]
+    else:
+        assert "RCCL gather unavailable (RTTNW_MULTI_FAIL_RCCL=1): gathering through peer copies" in r.stderr and "through hipMemcpyPeerAsync" in r.stderr
+        assert "bits=[768]" in r.stdout, r.stdout[-500:]
 
 
 def test_bench_line_through_torch_distributed_with_one_rank(gpu):

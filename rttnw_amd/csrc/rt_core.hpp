@@ -1260,47 +1260,6 @@ template <bool G = false, bool NO_TIME = false, bool FRAME_RAY = false, typename
     hit = prim_t<NO_TIME, FRAME_RAY>(sc, kind, idx, ray, t_min, tr.closest, t, aux, tr.sr);
     if (hit) trav_accept(tr, sc, kind, idx, t, aux, inst);
 }
-#ifndef RT_LEAF_PREFETCH
-#define RT_LEAF_PREFETCH 0 // experiment (round 6): the lane-owns-path kernels read a leaf's sphere OR cube record before either kind's code runs (see trav_test_record_pre)
-#endif
-// The leaf step of the lane-owns-path kernels with the record READ FIRST: a wave's leaf step is the union of the kinds its lanes stand at — on
-// final_scene a third of them serve spheres AND cubes and take half the leaf clock (profiles/r05/phases_final_scene_f64.txt: 40.5 k clocks against
-// 18.1 k for spheres alone) — and each kind's branch began with its own record read, so such a step waited for memory twice in a row.  Here both
-// reads are issued under their lanes' masks before any test: one wait.  (The cube's face plane is then selected from registers instead of re-read
-// by index.)  Same tests on the same operands: bit-identical.
-template <bool G, bool NO_TIME, typename R> RT_HD void trav_test_record_pre(Trav<R>& tr, const SceneView<R>& sc, uint32_t kind, uint32_t idx, R t_min, const Ray<R>& ray, int32_t inst) {
-    SphereRec<R> s{};
-    BoxRec<R> bx{};
-    if (kind == PRIM_SPHERE) s = sc.spheres[idx];
-    if (kind == PRIM_BOX) bx = sc.boxes[idx];
-    R t;
-    int aux = 0;
-    bool hit = false;
-    if (kind == PRIM_SPHERE) {
-        hit = sphere_t(V3<R>(s.cx, s.cy, s.cz), s.r, ray, t_min, tr.closest, t);
-    } else if (kind == PRIM_BOX) {
-        int axis = 0;
-        bool use_mx = false;
-        const int verdict = box_classify(bx, ray, tr.sr, t_min, tr.closest, axis, use_mx);
-        if (verdict == 2) {
-            hit = box_t(bx, ray, t_min, tr.closest, t, aux);
-        } else if (verdict == 1) {
-            const R ox = ray.o.x, oy = ray.o.y, oz = ray.o.z, dx = ray.d.x, dy = ray.d.y, dz = ray.d.z;
-            const R ok = axis == 0 ? ox : (axis == 1 ? oy : oz);
-            const R dk = axis == 0 ? dx : (axis == 1 ? dy : dz);
-            const R kmn = axis == 0 ? bx.mn[0] : (axis == 1 ? bx.mn[1] : bx.mn[2]), kmx = axis == 0 ? bx.mx[0] : (axis == 1 ? bx.mx[1] : bx.mx[2]);
-            const R k = use_mx ? kmx : kmn;
-            R unused;
-            rt_div2(k - ok, k - ok, dk, t, unused);
-            hit = !(t < t_min) & !(t > tr.closest);
-            aux = 2 * (2 - axis) + (use_mx ? 1 : 0);
-        }
-    } else { // the rarer kinds (rectangle, moving sphere, a strict build's world-space copy): as before
-        trav_test_record<G, NO_TIME, true>(tr, sc, kind, idx, t_min, ray, inst);
-        return;
-    }
-    if (hit) trav_accept(tr, sc, kind, idx, t, aux, inst);
-}
 template <bool WHOLE_LEAF = false, typename R, typename Stack, typename Cnt>
 RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wray, R t_min, Stack& stack, Cnt& cnt) {
     constexpr bool NI = Cnt::NO_INST;
@@ -1341,10 +1300,6 @@ RT_HD void trav_leaf_step(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& wra
         trav_pop<NI>(tr, wray, stack);
     } else {
         cnt.prim();
-#if RT_LEAF_PREFETCH && RT_BOX_FAST
-        if constexpr (FAST_CUBES) trav_test_record_pre<Cnt::GENERAL, Cnt::NO_TIME>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
-        else
-#endif
         trav_test_record<Cnt::GENERAL, Cnt::NO_TIME, FAST_CUBES>(tr, sc, kind, first + tr.leaf_k, t_min, NI ? wray : tr.ray, NI ? -1 : tr.cur_inst);
         if (++tr.leaf_k >= count) trav_pop<NI>(tr, wray, stack);
     }

@@ -1174,7 +1174,10 @@ RT_HD void trav_node_step4q(Trav<R>& tr, const SceneView<R>& sc, const Ray<R>& w
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float inv = slab_inv_of(tr.sr, a);
-        if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
+        // (an axis the ray is parallel to must not cull: NaN, not infinity.  The f64 walk's constants are made that way once per walk — slab_ray —;
+        // the f32 walk's are the bare reciprocals)
+        if constexpr (sizeof(R) == 4)
+            if (!(rt_fabs(inv) < __builtin_huge_valf())) inv = __builtin_nanf("");
         const bool neg = inv < 0.f;
         const float D = float(R(bits_float(w[a])) - oo[a]);
         A[a] = D * inv;

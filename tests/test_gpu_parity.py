@@ -563,11 +563,12 @@ def test_config3_frame_across_eight_ranks(gpu, oracle, scenes_lib, earth):
                 assert (rgba[y0:y0 + 64, x0:x0 + 64] == ro).all(axis=2).mean() >= 0.999
 
 
-@pytest.mark.parametrize("name,crops,lsb_each,lsb_all", [("final_scene", [(40, 440), (180, 540), (330, 330), (520, 300)], 0.93, 0.955),
-                                                        ("cornell_box", [(100, 100), (370, 420), (600, 300)], 0.98, 0.99)])
+@pytest.mark.parametrize("name,crops,lsb_each,lsb_all", [("final_scene", ["t2_final_0", "t2_final_1", "t2_final_2", "t2_final_3"], 0.93, 0.955),
+                                                        ("cornell_box", ["t2_cornell_0", "t2_cornell_1", "t2_cornell_2"], 0.98, 0.99)])
 def test_T2_at_baseline_size(gpu, oracle, scenes_lib, earth, name, crops, lsb_each, lsb_all):
     """SURVEY section 8(c) T2 at the BASELINE size: 800x800 at spp 1000 on the GPU against the f64 oracle on 64x64 crops
-    (earth + blue sphere, glass sphere, noise sphere, sphere cluster / the Cornell walls and blocks; oracle window render).
+    (earth + blue sphere, glass sphere, noise sphere, sphere cluster / the Cornell walls and blocks; the oracle's window renders are committed
+    fixtures — tests/golden/golden_windows.npz — of which a few pixels are re-rendered live every run).
     F64 kernels (the reference's arithmetic): RGBA8 IDENTICAL on >= 99.9 % of the crop pixels, linear within 1e-9 on >= 99 %.
     F32 kernels (throughput mode; equal seeds share the top 24 bits of every uniform):
       per pixel and channel  |delta| <= 6 sigma_hat / sqrt(spp) + 1/256  on >= 99.8 % of the pixels (sigma_hat: the oracle's per-
@@ -588,8 +589,8 @@ def test_T2_at_baseline_size(gpu, oracle, scenes_lib, earth, name, crops, lsb_ea
     p64 = util.params_for(setup, 800, 800, spp)[1]
     lin64, rgba64, _ = gpu_render(gpu, sg, cam, p64)
     n_px = n_bound = n_lsb = n_same64 = n_close64 = 0
-    for (x0, y0) in crops:
-        lo, ro, var, _ = rto.render_window(so, cam, p64, x0, y0, x0 + 64, y0 + 64, want_var=True)
+    for key in crops:
+        lo, ro, var, (x0, y0, _, _) = oracle_window(key, so, cam, p64)   # (committed oracle windows, spot-checked live: golden_cases.py WINDOWS)
         g = lin[y0:y0 + 64, x0:x0 + 64]
         bound = 6.0 * np.sqrt(np.maximum(var, 0.0) / spp) + 1.0 / 256
         n_bound += int((np.abs(g - lo) <= bound).all(axis=2).sum())
@@ -680,6 +681,33 @@ def _plan(hostsim, spp, w, h, rsz, world=1):
     return {"spp_chunk": out[0], "n_main": out[1], "n_chunks": out[2], "per_launch": out[3], "launches": out[4], "n_jobs": out[5]}
 
 
+_WINDOWS = None
+
+
+def oracle_window(key, so, cam, p, n_live=6):
+    """The oracle's render of window `key` of tests/golden_cases.py WINDOWS — the COMMITTED one (tests/golden/golden_windows.npz, made by
+    make_golden_windows.py: minutes of 256 host threads per window at these sample counts) — after re-rendering `n_live` of its pixels live with
+    the oracle built in this process (`so`, `cam`, `p`: the frame's parameters): the fixture must be what the oracle computes today, bit for bit.
+    Returns (linear, rgba8, variance or None, (x0, y0, w, h))."""
+    global _WINDOWS
+    from golden_cases import WINDOWS, load_windows
+    if _WINDOWS is None:
+        _WINDOWS = load_windows()
+    case = [c for c in WINDOWS if c[0] == key][0]
+    _, _, w, h, spp, x0, y0, cw, ch, want_var = case
+    assert (p.width, p.height, p.spp) == (w, h, spp), (key, p.width, p.height, p.spp)
+    lin, rgba = _WINDOWS[key + "_linear"], _WINDOWS[key + "_rgba8"]
+    var = _WINDOWS[key + "_var"] if want_var else None
+    assert lin.shape == (ch, cw, 3) and rgba.shape == (ch, cw, 4)
+    rng = np.random.default_rng(sum(map(ord, key)))   # (a fixed choice per window)
+    xs, ys = rng.integers(0, cw, n_live), rng.integers(0, ch, n_live)
+    live_lin, live_rgba, live_var = rto.render_pixel_list(so, cam, p, xs + x0, ys + y0, want_var=want_var)[:3]
+    assert np.array_equal(live_lin, lin[ys, xs]) and np.array_equal(live_rgba, rgba[ys, xs]), key
+    if want_var:
+        assert np.array_equal(live_var, var[ys, xs]), key
+    return lin, rgba, var, (x0, y0, cw, ch)
+
+
 def test_config2_final_scene_800_at_spp_5000(gpu, oracle, hostsim, scenes_lib, earth):
     """BASELINE configs[2] at its STATED spp: final_scene 800x800 spp=5000 in the F64 kernels: 1367 chunks = 19.6 GiB of chunk sums, ONE
     launch within an MI355X's 24 GiB chunk-sum budget (round 3: the budget follows the device's memory because every launch boundary
@@ -714,8 +742,8 @@ def test_config2_final_scene_800_at_spp_5000(gpu, oracle, hostsim, scenes_lib, e
     # reference tests them): no remainder
     _, ps = util.params_for(setup, w, h, spp, precision=abi.F64_STRICT)
     lin_s, rgba_s, _ = gpu_render(gpu, sc, cam, ps)
-    for (x0, y0) in [(250, 560), (510, 290)]:
-        lo, ro, _, _ = rto.render_window(so, cam, p, x0, y0, x0 + 48, y0 + 32)
+    for key in ("cfg2_glass", "cfg2_cluster"):
+        lo, ro, _, (x0, y0, _, _) = oracle_window(key, so, cam, p)   # (the windows at (250, 560) and (510, 290): committed, spot-checked live)
         d = np.abs(lin[y0:y0 + 32, x0:x0 + 48] - lo).max(axis=2)
         d_s = np.abs(lin_s[y0:y0 + 32, x0:x0 + 48] - lo).max(axis=2)
         # the flipped pixels are LISTED (this line is the list: count and largest difference per crop and build)
@@ -756,8 +784,8 @@ def test_config3_final_scene_1600_at_spp_10000_across_eight_ranks(gpu, oracle, h
     # ... and the frame through RTTNW_F64_STRICT (the reference's operations in the reference's frames): no remainder at spp 10 000 either
     _, ps = util.params_for(setup, w, h, spp, precision=abi.F64_STRICT)
     strict, rgba_s, _ = gpu_render(gpu, sc, cam, ps)
-    for (x0, y0) in [(500, 1100), (1020, 580)]:
-        lo, ro, _, _ = rto.render_window(so, cam, p, x0, y0, x0 + 32, y0 + 24)
+    for key in ("cfg3_glass", "cfg3_cluster"):
+        lo, ro, _, (x0, y0, _, _) = oracle_window(key, so, cam, p)   # (the windows at (500, 1100) and (1020, 580): committed, spot-checked live)
         d = np.abs(one[y0:y0 + 24, x0:x0 + 32] - lo).max(axis=2)
         d_s = np.abs(strict[y0:y0 + 24, x0:x0 + 32] - lo).max(axis=2)
         print("final_scene 1600x1600 spp 10000 crop (%d, %d): RTTNW_F64 %d of 768 pixels beyond 1e-9, max |delta| %.3g; RTTNW_F64_STRICT max |delta| %.3g"

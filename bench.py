@@ -71,9 +71,11 @@ VALU_COST_CYCLES = {"SQ_INSTS_VALU_FMA_F32": 2.36, "SQ_INSTS_VALU_MUL_F32": 2.36
                     "SQ_INSTS_VALU_INT32": 3.3, "SQ_INSTS_VALU_INT64": 4.4, "SQ_INSTS_VALU_CVT": 4.3}
 VALU_COST_OTHER_CYCLES = 3.3
 NODE_VISIT_BYTES = 32.0  # ONE 32-B accounting record per node visit, whatever a record physically holds
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
+# (what a launch's counters depend on: the kernels, their launch code and flags — and, since round 6, what lays the records out for them: the device
+# collapse's numbering and the upload)
 KERNEL_SOURCES = ["rttnw_amd/csrc/trace_kernels.hpp", "rttnw_amd/csrc/render_tiles.hpp", "rttnw_amd/csrc/rt_core.hpp", "rttnw_amd/csrc/rt_types.hpp",
-                  "rttnw_amd/csrc/bvh_quant.hpp", "rttnw_amd/csrc/Makefile"]
+                  "rttnw_amd/csrc/bvh_quant.hpp", "rttnw_amd/csrc/Makefile", "rttnw_amd/csrc/bvh_build.hip", "rttnw_amd/csrc/render_common.hpp"]
 
 
 def log(*a):

@@ -191,6 +191,9 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--batch-stride", type=int, default=0, help="0: job batches strided over the whole render; k: every k-th batch from --batch-offset (the kernel's order: k = 8 XCDs)")
     ap.add_argument("--batch-offset", type=int, default=0)
+    ap.add_argument("--node-steps", type=int, default=5, help="node steps per trip (RT_WAVE_STEPS)")
+    ap.add_argument("--retire", type=int, default=8, help="finished rays that end a burst while rays are queued (RT_WAVE_RETIRE)")
+    ap.add_argument("--leaf-threshold", type=int, default=0, help="dynamic leaf steps inside a trip once this many lanes wait at a leaf (0: the kernel's fixed trips)")
     args = ap.parse_args()
 
     hs = hostsim_binding()
@@ -234,11 +237,11 @@ def main():
             elif "spheres_tree" in vs:
                 so = sphere_order_from_tree(child, order, n_spheres)
                 sperm = order_to_perm(so, n_spheres)
-            prm = np.zeros(18, dtype=np.uint32)
+            prm = np.zeros(19, dtype=np.uint32)
             cache_bytes = int(args.cache_mb * (1 << 20))
-            prm[:] = [args.waves, args.ways, 5, 8, args.warm, args.measure, cache_bytes & 0xFFFFFFFF, cache_bytes >> 32,
-                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset, 1 if unified else 0]
-            out = np.zeros(160, dtype=np.uint64)
+            prm[:] = [args.waves, args.ways, args.node_steps, args.retire, args.warm, args.measure, cache_bytes & 0xFFFFFFFF, cache_bytes >> 32,
+                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset, 1 if unified else 0, args.leaf_threshold]
+            out = np.zeros(192, dtype=np.uint64)
             t0 = time.time()
             hs.lib.hostsim_cache_model(sc.handle, C.byref(cam), C.byref(p), prm.ctypes.data_as(C.c_void_p),
                                        nperm.ctypes.data_as(C.c_void_p) if nperm is not None else None,
@@ -251,6 +254,10 @@ def main():
             print("%-12s %-14s | %s | %8.1f %8.1f | %6.1f %6.2f %6.2f   (%.0f s, %d samples)" %
                   (lname, variant, " ".join("%10.2f" % m for m in miss), sum(miss), wb, out[2] / max(1.0, float(out[1])), out[3] / max(1.0, float(out[1])),
                    out[4] / max(1.0, float(out[1])), time.time() - t0, int(out[1])), flush=True)
+            ne, nl, le, ll, se, sl = [float(out[128 + k]) for k in range(6)]
+            # wave-level cost of the schedule in vector instructions per sample (quantised node step ~170, sphere leaf step ~120, a shade pass ~1500)
+            print("    steps per sample: node %.2f executions x %.1f lanes, leaf %.2f x %.1f, shade %.3f x %.1f  -> ~%.0f instructions per sample"
+                  % (ne / ns, nl / max(1.0, ne), le / ns, ll / max(1.0, le), se / ns, sl / max(1.0, se), (ne * 170 + le * 120 + se * 1500) / ns), flush=True)
             if lname == "current" and variant == "base":
                 print("    node accesses / misses per sample by depth: " +
                       " ".join("%d:%.1f/%.1f" % (d, out[64 + d] / ns, out[96 + d] / ns) for d in range(32) if out[64 + d]), flush=True)

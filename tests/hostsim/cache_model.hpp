@@ -11,7 +11,8 @@
 //   the path-state pool (hot: throughput, key, bounce — every shade; cold: pixel, sample range, job, running sum — when a path ends), job sums.
 // Writes allocate without a fetch and count as a write-back when the dirty line leaves the cache.
 // out: [0] samples measured, [1] rays, [2] node visits, [3] sphere tests, [4] sphere tests the pre-cull skipped;
-//      [8 + 4 s ...]: accesses, read misses, write-backs, (spare) of stream s; [64 + d] / [96 + d]: node accesses / misses at tree depth d (< 32).
+//      [8 + 4 s ...]: accesses, read misses, write-backs, (spare) of stream s; [64 + d] / [96 + d]: node accesses / misses at tree depth d (< 32);
+//      [128 ..]: wave-level executions of the node step and the lanes they served, likewise the leaf step and the shade pass.
 #pragma once
 
 namespace cache_model {
@@ -69,6 +70,7 @@ struct Params {
     uint32_t precull_pct;
     uint32_t xcds;           // 0: batches strided over the whole render; k > 0: this cache's waves take every k-th batch starting at batch_offset
     uint32_t batch_offset;
+    uint32_t leaf_threshold; // 0: a leaf step ends every trip (the kernel's); T: also inside the trip, after any node step that leaves >= T lanes at a leaf
     uint32_t unified;        // 1: node and sphere records share ONE buffer — node_perm / sphere_perm are positions in 32-byte units of it
     uint32_t node_bytes;     // 64 (quantised records) / 128
 };
@@ -133,6 +135,7 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
     const uint64_t n_batches = std::max<uint64_t>(1, rc.n_jobs / 256u);
     const uint64_t n_slots_total = uint64_t(P.n_waves) * 128u;
     uint64_t samples_done = 0, rays = 0, node_visits = 0, sphere_tests = 0, skipped = 0;
+    uint64_t node_execs = 0, node_lanes = 0, leaf_execs = 0, leaf_lanes = 0, shade_execs = 0, shade_lanes = 0; // wave-level executions of a step and the lanes they served
     uint64_t dacc[32] = {}, dmiss[32] = {};
     bool measuring = false;
     const uint64_t warm = uint64_t(P.warm_samples_per_slot) * n_slots_total, total = warm + uint64_t(P.measure_samples_per_slot) * n_slots_total;
@@ -164,6 +167,7 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
                     if (w.hitq.empty()) { w.done = true; --live; continue; }
                     // ---------------- SHADE
                     const uint32_t m = uint32_t(std::min<size_t>(64, w.hitq.size()));
+                    ++shade_execs; shade_lanes += m;
                     for (uint32_t k = 0; k < m; ++k) {
                         const uint32_t hs_ = w.hitq.back();
                         w.hitq.pop_back();
@@ -231,6 +235,7 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
                         measuring = true;
                         l2.reset_counts();
                         rays = node_visits = sphere_tests = skipped = 0;
+                        node_execs = node_lanes = leaf_execs = leaf_lanes = shade_execs = shade_lanes = 0;
                         for (int d = 0; d < 32; ++d) dacc[d] = dmiss[d] = 0;
                         out[0] = samples_done;
                     }
@@ -249,28 +254,43 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
             }
             // ---------------- one trip of the burst
             uint32_t walking = 0, finished = 0;
-            for (uint32_t k = 0; k < P.node_steps; ++k)
+            auto leaf_step = [&]() {
+                uint32_t served = 0;
+                for (auto& l : w.lane) {
+                    if (!l.has_ray || l.tr.node >= 0 || l.tr.node == TRAV_DONE) continue;
+                    const Ray<R>& ray = w.slot[l.slot].ps.ray;
+                    if (l.tr.node != CHILD_EMPTY && leaf_kind(l.tr.node) == PRIM_SPHERE) {
+                        const uint32_t idx = leaf_first(l.tr.node) + l.tr.leaf_k;
+                        bool fetch = true;
+                        if (P.precull && leaf_count(l.tr.node) == 1) {
+                            const SphereRec<R> sp = hs.view.spheres[idx];
+                            R tt;
+                            fetch = sphere_t(V3<R>(sp.cx, sp.cy, sp.cz), sp.r * R(1.0 + 0.01 * P.precull_pct), ray, t_min, l.tr.closest, tt);
+                        }
+                        ++sphere_tests;
+                        if (fetch) l2.touch(S_SPH, sphere_line(idx), false); else ++skipped;
+                    }
+                    trav_leaf_step(l.tr, hs.view, ray, t_min, l.stack, cnt);
+                    ++served;
+                }
+                if (served) { ++leaf_execs; leaf_lanes += served; }
+            };
+            for (uint32_t k = 0; k < P.node_steps; ++k) {
+                uint32_t served = 0, at_leaf = 0;
                 for (auto& l : w.lane)
                     if (l.has_ray && l.tr.node >= 0) {
                         node_access(l.tr.node);
                         trav_node_step(l.tr, hs.view, w.slot[l.slot].ps.ray, t_min, l.stack, cnt);
+                        ++served;
                     }
-            for (auto& l : w.lane) {
-                if (!l.has_ray || l.tr.node >= 0 || l.tr.node == TRAV_DONE) continue;
-                const Ray<R>& ray = w.slot[l.slot].ps.ray;
-                if (l.tr.node != CHILD_EMPTY && leaf_kind(l.tr.node) == PRIM_SPHERE) {
-                    const uint32_t idx = leaf_first(l.tr.node) + l.tr.leaf_k;
-                    bool fetch = true;
-                    if (P.precull && leaf_count(l.tr.node) == 1) {
-                        const SphereRec<R> sp = hs.view.spheres[idx];
-                        R tt;
-                        fetch = sphere_t(V3<R>(sp.cx, sp.cy, sp.cz), sp.r * R(1.0 + 0.01 * P.precull_pct), ray, t_min, l.tr.closest, tt);
-                    }
-                    ++sphere_tests;
-                    if (fetch) l2.touch(S_SPH, sphere_line(idx), false); else ++skipped;
+                if (served) { ++node_execs; node_lanes += served; }
+                // (a dynamic leaf step: taken inside the trip as soon as leaf_threshold lanes wait at a leaf — 0: only at the trip's end, the kernel's)
+                if (P.leaf_threshold && k + 1 < P.node_steps) {
+                    for (auto& l : w.lane) at_leaf += l.has_ray && l.tr.node < 0 && l.tr.node != TRAV_DONE;
+                    if (at_leaf >= P.leaf_threshold) leaf_step();
                 }
-                trav_leaf_step(l.tr, hs.view, ray, t_min, l.stack, cnt);
             }
+            leaf_step();
             for (auto& l : w.lane) {
                 if (!l.has_ray) continue;
                 if (l.tr.node == TRAV_DONE) ++finished; else ++walking;
@@ -291,6 +311,7 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
     }
     out[0] = samples_done - out[0];
     out[1] = rays; out[2] = node_visits; out[3] = sphere_tests; out[4] = skipped;
+    out[128] = node_execs; out[129] = node_lanes; out[130] = leaf_execs; out[131] = leaf_lanes; out[132] = shade_execs; out[133] = shade_lanes;
     for (uint32_t st = 0; st < S_COUNT; ++st) { out[8 + 4 * st] = l2.acc[st]; out[9 + 4 * st] = l2.miss[st]; out[10 + 4 * st] = l2.wb[st]; }
     for (int d = 0; d < 32; ++d) { out[64 + d] = dacc[d]; out[96 + d] = dmiss[d]; }
 }

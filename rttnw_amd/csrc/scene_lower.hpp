@@ -107,6 +107,25 @@ struct FlatScene {
         // L2-miss line per hit of its own (tests/hostsim/cache_model.hpp: 4.4 of 92 per sample).  Small scenes keep their slots (LDS-staged).
         sphere_mat_is_index = spheres.size() >= 65536;
         for (size_t i = 0; sphere_mat_is_index && i < sphere_mat.size(); ++i) sphere_mat_is_index = sphere_mat[i] == int32_t(i);
+        // ... and where a builder has reordered the records (the host SAH build emits them in leaf order), a LEAN cloud gets the order back the
+        // other way round: the materials follow the spheres — material i = sphere i's, the scene's own materials behind them (the other kinds'
+        // references move along).  Nothing but indices changes; 64 B per sphere.
+        if (!sphere_mat_is_index && is_lean && spheres.size() >= 65536 && insts.empty() && mats.size() < (size_t(1) << 28)) {
+            bool plain = true; // (no slot is a world-space copy's way home, none asks for (u, v))
+            for (size_t i = 0; plain && i < sphere_mat.size(); ++i) plain = (sphere_mat[i] & ~MAT_INDEX_MASK) == 0 && (sphere_mat[i] & MAT_HOME_FLAG) == 0;
+            if (plain) {
+                const size_t ns = spheres.size(), nm = mats.size();
+                RecVec<MaterialRec<double>> moved;
+                moved.resize(ns + nm);
+                for (size_t i = 0; i < ns; ++i) moved[i] = mats[size_t(sphere_mat[i])];
+                for (size_t i = 0; i < nm; ++i) moved[ns + i] = mats[i];
+                mats.swap(moved);
+                for (size_t i = 0; i < ns; ++i) sphere_mat[i] = int32_t(i);
+                for (auto& r : rects) r.mat += int32_t(ns);   // (the flag bits above the index stay where they are)
+                for (auto& b : boxes) b.mat += int32_t(ns);
+                sphere_mat_is_index = true;
+            }
+        }
     }
     bool sphere_mat_is_index = false;
 };

@@ -720,6 +720,12 @@ int hostsim_scene_dims(rttnw_scene* s, uint32_t* out /* nodes, spheres, moving, 
     out[6] = uint32_t(s->flat.media.size()); out[7] = s->flat.stack_depth;
     return RTTNW_OK;
 }
+// What the lowering decided about the committed scene: bit 0 LEAN (no moving sphere, no medium, solid colours only), bit 1 sphere material slot i holds i
+// (FlatScene::sphere_mat_is_index: the kernels — and this build's SceneView — take the index itself, SceneView::sphere_mat == nullptr)
+int hostsim_scene_flags(rttnw_scene* s) {
+    if (!s || !s->committed) return RTTNW_ERR_INVALID;
+    return (s->flat.lean() ? 1 : 0) | (s->flat.sphere_mat_is_index ? 2 : 0);
+}
 int hostsim_probe_path(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params* p, uint32_t px, uint32_t row,
                        uint32_t sample, double* out, uint32_t max_out) {
     return p->precision == RTTNW_F32 ? probe_path_t<float>(s, cam, p, px, row, sample, out, max_out)

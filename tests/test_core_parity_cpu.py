@@ -43,6 +43,27 @@ def test_core_f64_equals_golden(hostsim, scenes_lib, earth, case, world_spheres,
         assert d.max() <= 1e-12 * max(1.0, g.max()), (key, d.max())
 
 
+def test_big_cloud_takes_the_sphere_index_as_its_material_slot(hostsim, oracle, scenes_lib):
+    """A LEAN cloud of >= 65 536 spheres (spheres_1m) is lowered so that sphere i's material slot holds i — kept where the records stay in creation
+    order (the device builder: one record per leaf), re-established by moving the materials behind the spheres where a builder reordered them (the
+    host SAH build, which this test runs) —; the scene view then carries NO slot array (FlatScene::sphere_mat_is_index, SceneView::sphere_mat ==
+    nullptr) and make_record takes the index itself: one L2-miss line per hit less on the device.  The host build of the core with that view
+    against the oracle (median-split tree: the reference's builder cannot make this one) on a small frame: every pixel within 1e-12 — the
+    materials included, or the colours would differ."""
+    n = 70000
+    sh, setup = util.build(hostsim, scenes_lib, "spheres_1m", None, n)
+    so, _ = util.build(oracle, scenes_lib, "spheres_1m", None, n, bvh=rto.BVH_MEDIAN_SPLIT)
+    flags = hostsim.lib.hostsim_scene_flags(sh.handle)
+    assert flags & 1, "spheres_1m is a LEAN scene"
+    cam, p = util.params_for(setup, 40, 32, 3, spp_chunk=3, precision=abi.F64)
+    lin, _ = util.hostsim_render(hostsim, sh, cam, p)
+    lo, _, _ = rto.render(so, cam, p, want_rgba8=False)[:3]
+    assert np.abs(lin - lo).max() <= 1e-12 * max(1.0, lo.max()), np.abs(lin - lo).max()
+    assert flags & 2, "the big LEAN cloud must come out with slot i == i"
+    small, _ = util.build(hostsim, scenes_lib, "spheres_1m", None, 3000)
+    assert hostsim.lib.hostsim_scene_flags(small.handle) == 1   # (a small cloud keeps its slots: they are staged in LDS)
+
+
 def test_core_counts_match_oracle_rays(hostsim, oracle, scenes_lib, earth):
     """Same number of world.hit() calls as the oracle; far fewer node visits than the reference's tree."""
     for name in ("cornell_box", "final_scene"):

@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--batch-offset", type=int, default=0)
     ap.add_argument("--node-steps", type=int, default=5, help="node steps per trip (RT_WAVE_STEPS)")
     ap.add_argument("--retire", type=int, default=8, help="finished rays that end a burst while rays are queued (RT_WAVE_RETIRE)")
+    ap.add_argument("--cold-words", type=int, default=5, help="words of slot bookkeeping read at a path's end (5: the kernel's; 2: the job as its index — round 6, measured slower)")
     ap.add_argument("--leaf-threshold", type=int, default=0, help="dynamic leaf steps inside a trip once this many lanes wait at a leaf (0: the kernel's fixed trips)")
     args = ap.parse_args()
 
@@ -237,10 +238,10 @@ def main():
             elif "spheres_tree" in vs:
                 so = sphere_order_from_tree(child, order, n_spheres)
                 sperm = order_to_perm(so, n_spheres)
-            prm = np.zeros(19, dtype=np.uint32)
+            prm = np.zeros(20, dtype=np.uint32)
             cache_bytes = int(args.cache_mb * (1 << 20))
             prm[:] = [args.waves, args.ways, args.node_steps, args.retire, args.warm, args.measure, cache_bytes & 0xFFFFFFFF, cache_bytes >> 32,
-                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset, 1 if unified else 0, args.leaf_threshold]
+                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset, 1 if unified else 0, args.leaf_threshold, args.cold_words]
             out = np.zeros(192, dtype=np.uint64)
             t0 = time.time()
             hs.lib.hostsim_cache_model(sc.handle, C.byref(cam), C.byref(p), prm.ctypes.data_as(C.c_void_p),

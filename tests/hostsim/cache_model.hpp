@@ -70,6 +70,7 @@ struct Params {
     uint32_t precull_pct;
     uint32_t xcds;           // 0: batches strided over the whole render; k > 0: this cache's waves take every k-th batch starting at batch_offset
     uint32_t batch_offset;
+    uint32_t cold_words;     // words of a slot's bookkeeping read when its path ends: 5 (pixel, sample, sample end, 64-bit sum index); 2 = the job as its index (measured: slower)
     uint32_t leaf_threshold; // 0: a leaf step ends every trip (the kernel's); T: also inside the trip, after any node step that leaves >= T lanes at a leaf
     uint32_t unified;        // 1: node and sphere records share ONE buffer — node_perm / sphere_perm are positions in 32-byte units of it
     uint32_t node_bytes;     // 64 (quantised records) / 128
@@ -193,8 +194,8 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
                             if (path_shade(sl.ps, hs.view, rc, background, t_min, sl.found, sl.closest, sl.best, cnt)) {
                                 emit = true;
                             } else {
-                                for (uint32_t a = 0; a < 5; ++a) pool(S_POOL_COLD, a, 4, g, false);
-                                for (uint32_t a = 5; a < 8; ++a) pool(S_POOL_COLD, a, P.real_bytes, g, false);
+                                for (uint32_t a = 0; a < P.cold_words; ++a) pool(S_POOL_COLD, a, 4, g, false);       // pixel, sample, sample end, sum index
+                                for (uint32_t a = 5; a < 8; ++a) pool(S_POOL_COLD, a, P.real_bytes, g, false);          // the job's running sum
                                 ++sl.s;
                                 ++samples_done;
                                 need_sample = true;
@@ -221,7 +222,7 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
                         if (need_sample && !slot_done) {
                             path_begin(sl.ps, camr, rc, sl.px, sl.row, sl.s);
                             for (uint32_t a = 3; a < 5; ++a) pool(S_POOL_HOT, a, 4, g, true);            // key
-                            for (uint32_t a = 0; a < 5; ++a) pool(S_POOL_COLD, a, 4, g, true);
+                            for (uint32_t a = 0; a < P.cold_words; ++a) pool(S_POOL_COLD, a, 4, g, true);
                             for (uint32_t a = 5; a < 8; ++a) pool(S_POOL_COLD, a, P.real_bytes, g, true);
                             emit = true;
                         }

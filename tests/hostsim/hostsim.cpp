@@ -611,7 +611,7 @@ void hostsim_cache_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rtt
     P.n_waves = prm[0]; P.ways = prm[1]; P.node_steps = prm[2]; P.retire = prm[3]; P.warm_samples_per_slot = prm[4]; P.measure_samples_per_slot = prm[5];
     P.cache_bytes = uint64_t(prm[6]) | (uint64_t(prm[7]) << 32);
     P.sphere_bytes = prm[8]; P.mat_bytes = prm[9]; P.mat_by_sphere = prm[10]; P.real_bytes = prm[11]; P.precull = prm[12]; P.precull_pct = prm[13];
-    P.xcds = prm[14]; P.node_bytes = prm[15]; P.batch_offset = prm[16]; P.unified = prm[17]; P.leaf_threshold = prm[18];
+    P.xcds = prm[14]; P.node_bytes = prm[15]; P.batch_offset = prm[16]; P.unified = prm[17]; P.leaf_threshold = prm[18]; P.cold_words = prm[19] ? prm[19] : 5u;
     if (p->precision == RTTNW_F32) cache_model::run<float>(s, cam, p, P, node_perm, sphere_perm, out);
     else cache_model::run<double>(s, cam, p, P, node_perm, sphere_perm, out);
 }

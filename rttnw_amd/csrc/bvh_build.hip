@@ -16,9 +16,11 @@
 //   6. collapse to the 4-WIDE records the trace kernels walk (rt_types.hpp Bvh4Node), on the device, with the rule of the
 //      host's collapse4 (scene_lower.cpp): a record takes a binary node's two children and, while it has fewer than four,
 //      replaces its inner child of largest area by that child's two children.  Which binary nodes become records ("heads")
-//      is decided top-down, one launch per 4-wide level over a frontier (collapse_mark_kernel); an exclusive scan of the head
-//      flags in binary pre-order numbers the records (so records keep the binary tree's pre-order: a record next to its
-//      first child, the top levels together); collapse_write_kernel writes them; collapse_need_kernel, bottom-up over the
+//      is decided top-down, one launch per 4-wide level over a frontier (collapse_count_kernel + a scan + collapse_mark_kernel:
+//      the frontier's order is deterministic); a record's number is its head's position in the frontier arrays — LEVEL order,
+//      the inner children of a record side by side (round 6: the two 64-byte quantised records of a 128-byte line are
+//      siblings; RTTNW_NODE_ORDER=pre: the binary tree's pre-order of rounds 1-5, by a scan of the head flags);
+//      collapse_write_kernel writes them; collapse_need_kernel, bottom-up over the
 //      same frontiers, gives the exact traversal-stack bound.  The tree STAYS on the device: the scene's node array adopts
 //      the buffer (render_common.hpp DeviceScene), nothing is copied back unless someone asks to inspect it.
 // HBM-bound integer/byte work: coalesced SoA arrays, no LDS needed.  The hierarchy has exactly n-1 inner nodes;
@@ -661,7 +663,7 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
     int sah_levels = 0;
     const size_t max_large = n / size_t(SAH_SMALL + 1) + 2;
     // collapse
-    int *d_heads = nullptr, *d_count = nullptr;
+    int* d_heads = nullptr;
     uint32_t *d_is_head = nullptr, *d_rank = nullptr, *d_need = nullptr, *d_fcount = nullptr, *d_foff = nullptr;
     Bvh4Node* d_out4 = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -677,7 +679,6 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
         LBVH_TRY(hipMalloc((void**)&d_levels, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_out2, (n - 1) * sizeof(BvhNode)));
         LBVH_TRY(hipMalloc((void**)&d_heads, (n - 1) * 4));
-        LBVH_TRY(hipMalloc((void**)&d_count, 4));
         LBVH_TRY(hipMalloc((void**)&d_is_head, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_rank, (n - 1) * 4));
         LBVH_TRY(hipMalloc((void**)&d_fcount, (n - 1) * 4));
@@ -848,7 +849,7 @@ int lbvh_build_device_tree(const BuildPrim* prims, size_t n, const float* centro
 done:
     for (void* p : {(void*)d_prims, (void*)d_keys, (void*)d_keys2, (void*)d_order, (void*)d_order2, (void*)d_children, (void*)d_node_parent,
                     (void*)d_done, (void*)d_levels, (void*)d_box, (void*)d_out, (void*)d_out2, (void*)d_pos, d_temp, d_temp2, (void*)d_heads,
-                    (void*)d_count, (void*)d_is_head, (void*)d_rank, (void*)d_fcount, (void*)d_foff, (void*)d_need, (void*)d_out4, d_temp3, (void*)d_pa, (void*)d_pb, (void*)d_sa, (void*)d_sb,
+                    (void*)d_is_head, (void*)d_rank, (void*)d_fcount, (void*)d_foff, (void*)d_need, (void*)d_out4, d_temp3, (void*)d_pa, (void*)d_pb, (void*)d_sa, (void*)d_sb,
                     (void*)d_slot, (void*)d_list[0], (void*)d_list[1], (void*)d_list[2], (void*)d_list[3], (void*)d_segs, (void*)d_split, (void*)d_bins,
                     (void*)d_next, (void*)d_flag, (void*)d_scan})
         if (p) (void)hipFree(p);

@@ -29,7 +29,7 @@ static_assert(sizeof(BuildPrim) == 32, "BuildPrim must be 32 bytes");
 
 // A tree the device builder made and LEFT ON THE DEVICE ("the step before the path" hands its result
 // to the path without a round trip through the host): the 4-wide records the kernels walk (rt_types.hpp Bvh4Node, root =
-// record 0, records in the pre-order of the binary tree they were collapsed from) and, for inspection, the builder's binary
+// record 0, records in LEVEL order — the inner children of a record side by side: bvh_build.hip) and, for inspection, the builder's binary
 // tree (BvhNode, pre-order, root = 0).  Child indices are LOCAL to the tree until `rebase` has added the tree's place in
 // the scene's node array.  The buffers are owned by the shared pointers (freed on the device they live on).
 struct DeviceTree {

@@ -71,6 +71,14 @@ int main(int argc, char** argv) {
         CHECK(rttnw_list_push(s, world, b));
     }
     CHECK(rttnw_scene_set_world(s, world));
+    {   /* world.bounding_box(0., 1.) — hittable.rs:50,165-176: the Cornell box is [0, 555]^3 (its walls 0.0001 thick) */
+        double bb[6];
+        const int has = rttnw_hittable_bounds(s, world, 0.0, 1.0, bb);
+        if (has != 1 || bb[0] > 0.0 || bb[3] < 555.0 || bb[1] > 0.0 || bb[4] < 555.0 || bb[2] > 0.0 || bb[5] < 555.0) {
+            fprintf(stderr, "rttnw_hittable_bounds: unexpected world box (%d)\n", has);
+            return 3;
+        }
+    }
     CHECK(rttnw_scene_commit(s)); /* flatten, build the BVHs, upload: needs a HIP device */
 
     /* main.rs:137-150 (lookfrom, lookat, vfov 40, aperture 0) + Camera::from's shutter 0..1 */

@@ -379,7 +379,26 @@ static void wave_model(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw
                 }
                 for (int k = 0; k < a; ++k) {
                     uint32_t n = 0;
-                    for (uint32_t i = 0; i < 64; ++i) if (!L[i].done && walking[i] && L[i].tr.node >= 0) { trav_node_step(L[i].tr, hs.view, L[i].ps.ray, t_min, L[i].stack, cnt); ++n; }
+                    for (uint32_t i = 0; i < 64; ++i) if (!L[i].done && walking[i] && L[i].tr.node >= 0) {
+                        trav_node_step(L[i].tr, hs.view, L[i].ps.ray, t_min, L[i].stack, cnt); ++n;
+                        // HOSTSIM_SPHERE_PRECULL=<pct> (experiment): the one-sphere leaf a node step has just DESCENDED into is pre-tested against the sphere its
+                        // box implies (modelled: the record's sphere, radius inflated by pct / 1000) and skipped when the ray misses it; out[35] counts the skips.
+                        // (=<pct>,all: leaves taken off the stack are pre-tested too — what a test in the leaf step's place could do with the box at hand)
+                        static const char* pre = getenv("HOSTSIM_SPHERE_PRECULL");
+                        if (pre) {
+                            static const double infl = 1.0 + std::atof(pre) * 1e-3;
+                            static const bool all = std::strstr(pre, "all") != nullptr;
+                            Trav<R>& tr = L[i].tr;
+                            while (tr.node < 0 && tr.node != TRAV_DONE && tr.node != CHILD_EMPTY && leaf_kind(tr.node) == PRIM_SPHERE && leaf_count(tr.node) == 1) {
+                                const SphereRec<R> sp = hs.view.spheres[leaf_first(tr.node)];
+                                R tt;
+                                if (sphere_t(V3<R>(sp.cx, sp.cy, sp.cz), sp.r * R(infl), L[i].ps.ray, t_min, tr.closest, tt)) break;
+                                out[35]++;
+                                trav_pop(tr, L[i].ps.ray, L[i].stack);
+                                if (!all) break;
+                            }
+                        }
+                    }
                     if (n) { out[1]++; out[2] += n; }
                 }
                 // the leaf step.  jobs_per_wave's top bits select a LEAF POLICY (experiments): 0 every lane at a leaf is served (the kernel's); 1 only the

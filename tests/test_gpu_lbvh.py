@@ -208,3 +208,42 @@ def test_full_size_config5_invariants(gpu, scenes_lib, builder):
     want = tiles.pack_rank(a, 5, 8)
     got = r.packed.cpu().numpy().astype(np.float64)
     assert np.array_equal(got[:, :3], want[:, :3])
+
+
+@DEVICE_BUILDERS
+def test_record_numbering_is_level_order_and_result_free(gpu, scenes_lib, builder, monkeypatch):
+    """The device collapse numbers the 4-wide records in LEVEL order (round 6: a record's inner children side by side — the two 64-byte quantised
+    records of a 128-byte line are siblings); RTTNW_NODE_ORDER=pre keeps the binary tree's pre-order of rounds 1-5.  The numbering is layout only:
+    the same records (as a multiset of boxes and leaves), the same image bit for bit, the same node visits and record tests.  Level order itself:
+    every record's inner children are consecutive numbers, and a child's number is larger than its parent's."""
+    n = 120000
+    sc, setup = util.build(gpu, scenes_lib, "spheres_1m", None, n, bvh=builder)
+    monkeypatch.setenv("RTTNW_NODE_ORDER", "pre")
+    sc_pre, _ = util.build(gpu, scenes_lib, "spheres_1m", None, n, bvh=builder)
+    monkeypatch.delenv("RTTNW_NODE_ORDER")
+    n4, root = util.nodes_of(gpu, sc, wide=True)
+    n4p, rootp = util.nodes_of(gpu, sc_pre, wide=True)
+    assert root == rootp == 0 and len(n4) == len(n4p)
+    siblings = 0
+    for i in range(len(n4)):
+        inner = [int(c) for c in n4[i]["child"] if c >= 0]
+        assert all(c > i for c in inner)
+        assert inner == list(range(inner[0], inner[0] + len(inner))) if inner else True
+        siblings += len(inner) >= 2
+    assert siblings > len(n4) // 8
+    # pre-order: a record's FIRST inner child is the next record; level order puts it a level away
+    first_next = sum(1 for i in range(len(n4p)) if any(int(c) == i + 1 for c in n4p[i]["child"][:1] if c >= 0))
+    assert first_next > 0
+
+    def boxes(nodes):   # the records as sets of (boxes, leaf children), whatever their numbers
+        out = []
+        for nd in nodes:
+            leaves = tuple(sorted(int(c) for c in nd["child"] if c < 0))
+            out.append((nd["lo"].tobytes(), nd["hi"].tobytes(), leaves, sum(1 for c in nd["child"] if c >= 0)))
+        return sorted(out)
+    assert boxes(n4) == boxes(n4p)
+    cam, p = util.params_for(setup, 96, 96, 3, precision=abi.F64_STRICT, seed=9, collect_counters=1)
+    a, ra, sa = render.render_host(sc, cam, p)
+    b, rb, sb = render.render_host(sc_pre, cam, p)
+    assert np.array_equal(a, b) and np.array_equal(ra, rb)
+    assert (sa.rays, sa.nodes_visited, sa.prims_tested) == (sb.rays, sb.nodes_visited, sb.prims_tested)

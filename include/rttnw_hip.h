@@ -225,7 +225,7 @@ typedef struct rttnw_stats {
     uint32_t n_nodes;        /* flat scene size: 4-wide node records */
     uint32_t n_prims;
     uint32_t scene_bytes;    /* bytes of node+primitive arrays resident on the device */
-    uint32_t reserved;       /* render: kernel form that ran — bit 0: decoupled (else lane-owns-path), bit 1: node records resident in LDS, bit 2: three node steps per walk trip (tiny top trees), bit 3: the instantiation whose walk never changes frames (no Translate / YRotate group with a tree of its own), bit 4: ... but tests single wrapped records in place, bit 5: ... in the LEAN flavour (the scene has no MovingSphere, no ConstantMedium and only solid colours: their code is compiled out); rttnw_render_multi, rank 0 only — bit 8: the gather went through peer copies (RTTNW_MULTI_GATHER=peer), bit 9: ... because the RCCL set-up failed; scene_info: stack depth */
+    uint32_t reserved;       /* render: kernel form that ran — bit 0: decoupled (else lane-owns-path), bit 1: node records resident in LDS, bit 2: three node steps per walk trip (tiny top trees), bit 3: the instantiation whose walk never changes frames (no Translate / YRotate group with a tree of its own), bit 4: ... but tests single wrapped records in place, bit 5: ... in the LEAN flavour (the scene has no MovingSphere, no ConstantMedium and only solid colours: their code is compiled out); bit 6: the decoupled kernel walked the interleaved node + sphere buffer of a big cloud; rttnw_render_multi, rank 0 only — bit 8: the gather went through peer copies (RTTNW_MULTI_GATHER=peer), bit 9: ... because the RCCL set-up failed; scene_info: stack depth */
 } rttnw_stats;
 
 /* Framebuffer partition: 8x8-pixel tiles, tile t owned by rank

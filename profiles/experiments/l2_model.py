@@ -147,9 +147,11 @@ def sphere_order_from_tree(child, order_nodes, n_spheres):
     return np.concatenate([np.asarray(out, dtype=np.int64), rest])
 
 
-def unified_layout(child, order_nodes, n_spheres, align_parent=False):
-    """Node and sphere records in ONE buffer, positions in 32-byte units: every node record (64 B, on a 64-byte boundary) is followed by the sphere
-    records of its sphere leaves.  align_parent: a record that has sphere leaves starts on a 128-byte line (its first two spheres share its line)."""
+def unified_layout(child, order_nodes, n_spheres, align_parent=False, unit=32):
+    """Node and sphere records in ONE buffer, positions in units of a sphere record (32 B in f64, 16 B in f32): every node record (64 B, on a 64-byte
+    boundary) is followed by the sphere records of its sphere leaves.  align_parent: a record that has sphere leaves starts on a 128-byte line (its
+    first two — f32: all four — spheres share its line)."""
+    nu, lu = 64 // unit, 128 // unit
     n = child.shape[0]
     npos = np.zeros(n, dtype=np.uint32)
     spos = np.full(n_spheres, 0xFFFFFFFF, dtype=np.uint32)
@@ -162,18 +164,18 @@ def unified_layout(child, order_nodes, n_spheres, align_parent=False):
                 bits = (~ch) & 0xFFFFFFFF
                 if bits >> 28 == 0:
                     leaves.append((bits & 0x3FFFFFF, ((bits >> 26) & 3) + 1))
-        at += at & 1
-        if align_parent and leaves and (at & 3):
-            at += 4 - (at & 3)
+        at += (-at) % nu
+        if align_parent and leaves and (at % lu):
+            at += lu - (at % lu)
         npos[i] = at
-        at += 2
+        at += nu
         for first, count in leaves:
             for k in range(first, first + count):
                 spos[k] = at
                 at += 1
     rest = np.flatnonzero(spos == 0xFFFFFFFF)
     spos[rest] = at + np.arange(len(rest), dtype=np.uint32)
-    print("    unified buffer: %.1f MB" % ((at + len(rest)) * 32 / 1e6))
+    print("    unified buffer: %.1f MB" % ((at + len(rest)) * unit / 1e6))
     return npos, spos
 
 
@@ -189,6 +191,7 @@ def main():
     ap.add_argument("--variants", default="base", help="comma list of: base, spheres_tree (sphere records in node-layout order), "
                     "mat_by_sphere (material beside the sphere's index, 64 B), precull (one-sphere leaves pre-tested, 5 %% inflated)")
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"], help="record sizes and the walk's arithmetic (f32: 16-byte spheres, 512 waves per XCD: pass --waves 512)")
     ap.add_argument("--batch-stride", type=int, default=0, help="0: job batches strided over the whole render; k: every k-th batch from --batch-offset (the kernel's order: k = 8 XCDs)")
     ap.add_argument("--batch-offset", type=int, default=0)
     ap.add_argument("--node-steps", type=int, default=5, help="node steps per trip (RT_WAVE_STEPS)")
@@ -204,7 +207,7 @@ def main():
     child, area, root, n_spheres = tree_arrays(hs, sc)
     n = child.shape[0]
     print("scene: %d spheres, %d four-wide records, built in %.1f s" % (n_spheres, n, time.time() - t0), flush=True)
-    cam, p = S.params_for(setup, args.size, args.size, 256, precision=abi.F64, seed=1)
+    cam, p = S.params_for(setup, args.size, args.size, 256, precision=abi.F32 if args.precision == "f32" else abi.F64, seed=1)
 
     def layout(name):
         if name == "current":
@@ -231,17 +234,19 @@ def main():
         for variant in args.variants.split(","):
             vs = set(variant.split("+"))
             sperm = None
+            sph_b = 16 if args.precision == "f32" else 32
             unified = "unified" in vs
             nperm = perm
             if unified:
-                nperm, sperm = unified_layout(child, order, n_spheres, align_parent="aligned" in vs)
+                nperm, sperm = unified_layout(child, order, n_spheres, align_parent="aligned" in vs, unit=sph_b)
             elif "spheres_tree" in vs:
                 so = sphere_order_from_tree(child, order, n_spheres)
                 sperm = order_to_perm(so, n_spheres)
+            f32 = args.precision == "f32"
             prm = np.zeros(20, dtype=np.uint32)
             cache_bytes = int(args.cache_mb * (1 << 20))
             prm[:] = [args.waves, args.ways, args.node_steps, args.retire, args.warm, args.measure, cache_bytes & 0xFFFFFFFF, cache_bytes >> 32,
-                      32, 64 if "mat_by_sphere" in vs else 40, 1 if "mat_by_sphere" in vs else 0, 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset, 1 if unified else 0, args.leaf_threshold, args.cold_words]
+                      sph_b, (32 if f32 else 64) if "mat_by_sphere" in vs else (24 if f32 else 40), 1 if "mat_by_sphere" in vs else 0, 4 if f32 else 8, 1 if "precull" in vs else 0, 5, args.batch_stride, 64, args.batch_offset, 1 if unified else 0, args.leaf_threshold, args.cold_words]
             out = np.zeros(192, dtype=np.uint64)
             t0 = time.time()
             hs.lib.hostsim_cache_model(sc.handle, C.byref(cam), C.byref(p), prm.ctypes.data_as(C.c_void_p),

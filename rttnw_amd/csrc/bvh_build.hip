@@ -912,6 +912,64 @@ __global__ void quant4_make_kernel(const Bvh4Node* __restrict__ nodes4, uint32_t
 }
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The interleaved node + sphere buffer (bvh_build.hpp): one thread per record.
+namespace {
+__global__ void interleave_count_kernel(const Bvh4Node* __restrict__ nodes4, uint32_t n, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int32_t ch = nodes4[i].child[c];
+        if (ch < 0 && ch != CHILD_EMPTY && leaf_kind(ch) == PRIM_SPHERE) k += leaf_count(ch);
+    }
+    out[i] = uint8_t(k);
+}
+__device__ __forceinline__ void copy16(void* dst, const void* src, uint32_t bytes) {
+    for (uint32_t b = 0; b < bytes; b += 16) *reinterpret_cast<uint4*>((char*)dst + b) = *reinterpret_cast<const uint4*>((const char*)src + b);
+}
+__global__ void interleave_scatter_kernel(InterleaveArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n4) return;
+    Bvh4QNode q;
+    quant4_make(a.nodes4, int32_t(i), q);
+    const uint32_t su = a.sphere_bytes / 16u;
+    uint32_t at = a.noff[i] + 4u; // the record's spheres follow it
+    for (int c = 0; c < 4; ++c) {
+        const int32_t ch = a.nodes4[i].child[c];
+        if (ch == CHILD_EMPTY) continue;
+        if (ch >= 0) { q.child[c] = int32_t(a.noff[ch] >> 2); continue; }
+        if (leaf_kind(ch) != PRIM_SPHERE) continue; // other kinds keep their records where they are
+        const uint32_t cnt = leaf_count(ch), first = leaf_first(ch), at_sphere = at / su;
+        q.child[c] = make_leaf(PRIM_SPHERE, cnt, at_sphere);
+        for (uint32_t k = 0; k < cnt; ++k) {
+            copy16((char*)a.buffer + size_t(at + k * su) * 16u, (const char*)a.spheres + size_t(first + k) * a.sphere_bytes, a.sphere_bytes);
+            a.seq_out[at_sphere + k] = a.sphere_seq[first + k];
+            copy16((char*)a.mats_out + size_t(at_sphere + k) * a.mat_bytes, (const char*)a.mats + size_t(first + k) * a.mat_bytes, a.mat_bytes);
+        }
+        at += cnt * su;
+    }
+    *reinterpret_cast<Bvh4QNode*>((char*)a.buffer + size_t(a.noff[i]) * 16u) = q;
+}
+} // namespace
+
+int interleave_count_device(const Bvh4Node* d_nodes4, uint32_t n, uint8_t* d_sphere_count, std::string& err) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(interleave_count_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d_nodes4, n, d_sphere_count);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { err = std::string("interleave_count: ") + hipGetErrorString(e); return -4; }
+    return 0;
+}
+int interleave_build_device(const InterleaveArgs& a, std::string& err) {
+    if (a.n4 == 0) return 0;
+    hipLaunchKernelGGL(interleave_scatter_kernel, dim3((a.n4 + 127) / 128), dim3(128), 0, 0, a);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { err = std::string("interleave_build: ") + hipGetErrorString(e); return -4; }
+    return 0;
+}
+
 int quant4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4QNode* d_out, std::string& err) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(quant4_make_kernel, dim3((n + 127) / 128), dim3(128), 0, 0, d_nodes4, n, d_out);

@@ -64,4 +64,23 @@ int device_tree_rebase(DeviceTree& tree, uint32_t base4, uint32_t base2, std::st
 // Bvh4QNode, bvh_quant.hpp), index for index, into d_out[0, n).  Synchronous.
 int quant4_build_device(const Bvh4Node* d_nodes4, uint32_t n, Bvh4QNode* d_out, std::string& err);
 
+// The INTERLEAVED buffer of the decoupled kernels (round 6, big clouds: FlatScene::sphere_mat_is_index): a quantised node record is followed, in ONE
+// buffer, by the sphere records of its sphere leaves — a record that has any starts on a 128-byte line, so that the walk that has fetched the node
+// finds its first two (f64; all four in f32) spheres in the line it already holds.  Positions are counted in 16-byte UNITS: `noff[i]` = where record
+// i starts (the host lays the records out from the per-record sphere counts of interleave_count_device).  A node is addressed as buffer +
+// (noff / 4) x 64 bytes, a sphere as buffer + index x sphere_bytes: child slots and leaf bits of the records are rewritten to those numbers; the
+// spheres' sequence numbers and materials (slot i holds i: material index = sphere index) move to the same, sparse, indices.  Layout only.
+int interleave_count_device(const Bvh4Node* d_nodes4, uint32_t n, uint8_t* d_sphere_count, std::string& err);
+struct InterleaveArgs {
+    const Bvh4Node* nodes4; uint32_t n4;
+    const uint32_t* noff;                       // [n4], 16-byte units
+    const void* spheres; uint32_t sphere_bytes;  // 16 (f32) / 32 (f64)
+    const int32_t* sphere_seq;
+    const void* mats; uint32_t mat_bytes;        // sizeof(MaterialRec<R>)
+    void* buffer;                                // out: the interleaved node + sphere buffer
+    int32_t* seq_out;                            // out: sequence numbers by the new sphere index
+    void* mats_out;                              // out: materials by the new sphere index
+};
+int interleave_build_device(const InterleaveArgs& a, std::string& err);
+
 } // namespace rt

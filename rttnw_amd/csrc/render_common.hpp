@@ -79,6 +79,16 @@ template <typename R> struct DeviceScene {
     DevBuf<uint8_t> perlin_perm;
     SceneView<R> view{};
     size_t bytes = 0;
+    // The decoupled kernels' own view of a big cloud (round 6, ensure_quant4): node records and the sphere records of their leaves INTERLEAVED in one
+    // buffer (bvh_build.hpp interleave_build_device), the spheres' sequence numbers and materials at the same, sparse, indices; the few other records'
+    // material references moved behind them.  Layout only: what `view` describes, elsewhere.
+    bool interleaved = false;
+    SceneView<R> view_q{};
+    DevBuf<int32_t> seq_q;
+    DevBuf<MaterialRec<R>> mats_q;
+    DevBuf<RectRec<R>> rects_q;
+    DevBuf<BoxRec<R>> boxes_q;
+    const SceneView<R>& decoupled_view() const { return interleaved ? view_q : view; }
 
     // The scene's node array on the current device: the host-built records followed by the device-built trees.  A scene whose
     // nodes are ONE device-built tree on this very device (spheres_1m: 57 MB) simply adopts the builder's buffer; otherwise the
@@ -112,6 +122,10 @@ template <typename R> struct DeviceScene {
     // The decoupled kernels' node records, made on this device from the f32 ones the first time such a kernel is chosen.
     int ensure_quant4(const FlatScene& f) {
         if (nodes4q.p) return 0;
+        {
+            const char* e = getenv("RTTNW_INTERLEAVE"); // (0: the separate arrays of rounds 1-5, for A/B runs and tests)
+            if (f.sphere_mat_is_index && f.insts.empty() && f.moving.empty() && f.media.empty() && !(e && e[0] == '0')) return build_interleaved(f);
+        }
         const uint32_t n = f.total_nodes4();
         HIP_TRY(hipMalloc((void**)&nodes4q.p, std::max<size_t>(n, 1) * sizeof(Bvh4QNode)));
         nodes4q.n = n;
@@ -121,6 +135,83 @@ template <typename R> struct DeviceScene {
         return 0;
     }
 
+
+    // A big cloud (FlatScene::sphere_mat_is_index: >= 65 536 spheres, slot i holds i, no instance, medium or moving sphere): the quantised node
+    // records and the spheres of their leaves in ONE buffer.  Per-record sphere counts come from the device (the tree may live only there), the
+    // layout is a sequential pass on the host (a record with sphere leaves starts on a 128-byte line, any other on a 64-byte boundary), the
+    // records are written by one kernel.  tests/hostsim/cache_model.hpp priced it: nodes + spheres 73.9 -> 64.7 read-miss lines per sample in
+    // f32 (all four 16-byte spheres of a record share its line), 80.1 -> 73.7 in f64.
+    int build_interleaved(const FlatScene& f) {
+        const uint32_t n4 = f.total_nodes4();
+        std::string err;
+        uint8_t* d_cnt = nullptr;
+        uint32_t* d_off = nullptr;
+        struct Free { uint8_t*& a; uint32_t*& b; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } free_tmp{d_cnt, d_off};
+        HIP_TRY(hipMalloc((void**)&d_cnt, std::max<uint32_t>(n4, 1)));
+        if (int rc = interleave_count_device(nodes.p, n4, d_cnt, err)) { set_last_error(err); return rc; }
+        std::vector<uint8_t> cnt(n4);
+        if (n4) HIP_TRY(hipMemcpy(cnt.data(), d_cnt, n4, hipMemcpyDeviceToHost));
+        constexpr uint32_t su = uint32_t(sizeof(SphereRec<R>) / 16);
+        std::vector<uint32_t> off(n4);
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < n4; ++i) {
+            const uint32_t align = cnt[i] ? 8u : 4u;
+            at = (at + align - 1) / align * align;
+            off[i] = uint32_t(at);
+            at += 4u + uint32_t(cnt[i]) * su;
+        }
+        at = (at + 7) / 8 * 8;
+        const uint64_t n_sparse = at / su;               // sphere indices of the buffer run up to here
+        if (at >= (1ull << 32) || n_sparse >= (1ull << 26)) return ensure_quant4_plain(f); // (beyond the leaf bits' 26-bit record index: the separate arrays)
+        HIP_TRY(hipMalloc((void**)&d_off, std::max<size_t>(n4, 1) * 4));
+        if (n4) HIP_TRY(hipMemcpy(d_off, off.data(), size_t(n4) * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void**)&nodes4q.p, size_t(at) * 16));
+        nodes4q.n = size_t(at) / 4;
+        HIP_TRY(hipMemset(nodes4q.p, 0, size_t(at) * 16));
+        HIP_TRY(hipMalloc((void**)&seq_q.p, size_t(n_sparse) * 4)); seq_q.n = size_t(n_sparse);
+        HIP_TRY(hipMemset(seq_q.p, 0, size_t(n_sparse) * 4));
+        const size_t nm = f.mats.size();
+        HIP_TRY(hipMalloc((void**)&mats_q.p, (size_t(n_sparse) + nm) * sizeof(MaterialRec<R>))); mats_q.n = size_t(n_sparse) + nm;
+        HIP_TRY(hipMemset(mats_q.p, 0, size_t(n_sparse) * sizeof(MaterialRec<R>)));
+        if (nm) HIP_TRY(hipMemcpy(mats_q.p + n_sparse, mats.p, nm * sizeof(MaterialRec<R>), hipMemcpyDeviceToDevice)); // the scene's materials, behind the spheres'
+        InterleaveArgs a{};
+        a.nodes4 = nodes.p; a.n4 = n4; a.noff = d_off; a.spheres = spheres.p; a.sphere_bytes = uint32_t(sizeof(SphereRec<R>)); a.sphere_seq = sphere_seq.p;
+        a.mats = mats.p; a.mat_bytes = uint32_t(sizeof(MaterialRec<R>)); a.buffer = nodes4q.p; a.seq_out = seq_q.p; a.mats_out = mats_q.p;
+        if (int rc = interleave_build_device(a, err)) { set_last_error(err); return rc; }
+        // the other kinds' records keep their places; their material references move behind the sparse block
+        std::vector<RectRec<R>> rq;
+        for (auto& r : f.rects) rq.push_back({R(r.a0), R(r.a1), R(r.b0), R(r.b1), R(r.k), r.plane, r.mat + int32_t(n_sparse), r.seq});
+        std::vector<BoxRec<R>> bq;
+        for (auto& b : f.boxes) {
+            BoxRec<R> o{};
+            for (int k = 0; k < 3; ++k) { o.mn[k] = R(b.mn[k]); o.mx[k] = R(b.mx[k]); }
+            o.mat = b.mat + int32_t(n_sparse); o.seq = b.seq;
+            bq.push_back(o);
+        }
+        if (int rc = rects_q.upload(rq)) return rc;
+        if (int rc = boxes_q.upload(bq)) return rc;
+        view_q = view;
+        view_q.nodes4q = nodes4q.p;
+        view_q.spheres = reinterpret_cast<const SphereRec<R>*>(nodes4q.p);
+        view_q.sphere_mat = nullptr;
+        view_q.sphere_seq = seq_q.p;
+        view_q.mats = mats_q.p;
+        view_q.rects = rects_q.p;
+        view_q.boxes = boxes_q.p;
+        view_q.top_root = int32_t(off[size_t(f.top_root)] >> 2);
+        view.nodes4q = nodes4q.p; // (never walked through `view`: the records' child slots are the interleaved buffer's)
+        interleaved = true;
+        return 0;
+    }
+    int ensure_quant4_plain(const FlatScene& f) {
+        const uint32_t n = f.total_nodes4();
+        HIP_TRY(hipMalloc((void**)&nodes4q.p, std::max<size_t>(n, 1) * sizeof(Bvh4QNode)));
+        nodes4q.n = n;
+        std::string err;
+        if (int rc = quant4_build_device(nodes.p, n, nodes4q.p, err)) { set_last_error(err); nodes4q.release(); return rc; }
+        view.nodes4q = nodes4q.p;
+        return 0;
+    }
 
     int upload(const FlatScene& f) {
         std::vector<SphereRec<R>> sp;
@@ -179,6 +270,7 @@ template <typename R> struct DeviceScene {
         return 0;
     }
     void release() {
+        seq_q.release(); mats_q.release(); rects_q.release(); boxes_q.release(); interleaved = false;
         nodes.release(); nodes4q.release(); spheres.release(); sphere_mat.release(); sphere_seq.release(); moving.release(); rects.release();
         boxes.release(); insts.release(); media.release(); medium_refs.release(); mats.release(); texs.release(); images.release();
         texels.release(); perlin_vec.release(); perlin_perm.release();

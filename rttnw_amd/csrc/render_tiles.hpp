@@ -222,7 +222,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
             if (int g = grow(&d->pool_u, &d->pool_u_bytes, n_slots * PU_COUNT * sizeof(uint32_t))) return g;
             if (int g = grow_spill(grid * size_t(wblock), wave_stack_entries<R>())) return g;
             if (n_jobs > 0 && !prepare_only) {
-                hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(uint32_t(wblock)), lds_bytes, stream, ds.view, camr, rc, R(p->background[0]),
+                hipLaunchKernelGGL(kernel, dim3(uint32_t(grid)), dim3(uint32_t(wblock)), lds_bytes, stream, ds.decoupled_view(), camr, rc, R(p->background[0]),
                                    R(p->background[1]), R(p->background[2]), R(p->t_min), (R*)d->partial, d->job_counter, dc, (R*)d->pool_r,
                                    (uint32_t*)d->pool_u, uint32_t(n_slots), (int32_t*)d->spill);
                 HIP_TRY(hipGetLastError());
@@ -278,6 +278,7 @@ int render_tiles_t(::rttnw_scene* s, DeviceState* d, const rttnw_camera_desc* ca
         stats->reserved = (plain ? 0u : 1u) | (plain && rc.lds_nodes != 0u ? 2u : 0u) | (plain && three_steps ? 4u : 0u) | (!flat.needs_general && (plain ? !flat.walk_changes_frames && rc.lds_nodes != 0u : !flat.has_instance_leaves) ? 8u : 0u) |
                           (!flat.needs_general && plain && !flat.walk_changes_frames && rc.lds_nodes != 0u && flat.has_instance_leaves ? 16u : 0u);
         if ((stats->reserved & 8u) != 0u && flat.lean()) stats->reserved |= 32u; // bit 5: ... in the LEAN flavour (rt_core.hpp SHAPES_*_NT)
+        if (!plain && ds.interleaved) stats->reserved |= 64u;                      // bit 6: the decoupled kernel walked the interleaved node + sphere buffer (render_common.hpp)
     }
     return RTTNW_OK;
 }

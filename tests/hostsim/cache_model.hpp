@@ -72,7 +72,7 @@ struct Params {
     uint32_t batch_offset;
     uint32_t cold_words;     // words of a slot's bookkeeping read when its path ends: 5 (pixel, sample, sample end, 64-bit sum index); 2 = the job as its index (measured: slower)
     uint32_t leaf_threshold; // 0: a leaf step ends every trip (the kernel's); T: also inside the trip, after any node step that leaves >= T lanes at a leaf
-    uint32_t unified;        // 1: node and sphere records share ONE buffer — node_perm / sphere_perm are positions in 32-byte units of it
+    uint32_t unified;        // 1: node and sphere records share ONE buffer — node_perm / sphere_perm are positions in units of a sphere record (sphere_bytes) of it
     uint32_t node_bytes;     // 64 (quantised records) / 128
 };
 
@@ -146,13 +146,13 @@ static void run(rttnw_scene* s, const rttnw_camera_desc* cam, const rttnw_params
     };
     auto node_access = [&](int32_t idx) {
         const uint64_t at = node_perm ? node_perm[idx] : uint32_t(idx);
-        const bool hit = l2.touch(S_NODE, P.unified ? at * 32u >> 7 : at * P.node_bytes >> 7, false);
+        const bool hit = l2.touch(S_NODE, P.unified ? at * P.sphere_bytes >> 7 : at * P.node_bytes >> 7, false);
         ++node_visits;
         const uint32_t d = depth[size_t(idx)];
         ++dacc[d];
         if (!hit) ++dmiss[d];
     };
-    auto sphere_line = [&](uint32_t idx) { return (uint64_t(sphere_perm ? sphere_perm[idx] : idx) * (P.unified ? 32u : P.sphere_bytes)) >> 7; };
+    auto sphere_line = [&](uint32_t idx) { return (uint64_t(sphere_perm ? sphere_perm[idx] : idx) * P.sphere_bytes) >> 7; };
     const uint32_t S_SPH = P.unified ? uint32_t(S_NODE) : uint32_t(S_SPHERE);
 
     uint32_t live = P.n_waves;

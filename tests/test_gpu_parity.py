@@ -232,7 +232,7 @@ def test_config5_spheres_1m_at_its_size_vs_oracle(gpu, oracle, scenes_lib):
     for name, prec in (("strict", abi.F64_STRICT), ("f64", abi.F64), ("f32", abi.F32)):
         cam, p = util.params_for(setup, w, h, spp, precision=prec)
         lin, rgba, st = gpu_render(gpu, sg, cam, p)
-        assert st.samples == w * h * spp and st.reserved == 41 and np.isfinite(lin).all(), name   # the decoupled kernel (bit 0), the instantiation without instance code (bit 3) in its LEAN flavour (bit 5: no moving sphere, no medium, solid colours)
+        assert st.samples == w * h * spp and st.reserved == 105 and np.isfinite(lin).all(), name   # the decoupled kernel (bit 0), the instantiation without instance code (bit 3) in its LEAN flavour (bit 5: no moving sphere, no medium, solid colours), over the interleaved node + sphere buffer (bit 6)
         out[name] = (lin, rgba)
     cam, p64 = util.params_for(setup, w, h, spp, precision=abi.F64)
     n_px = n_bound32 = n_lsb64 = 0
@@ -394,6 +394,17 @@ def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib, precision):
     lin, rgba, st = gpu_render(gpu, sc, cam, p)
     assert (st.reserved & 1) == 1 and st.n_nodes >= 65536
     import os
+    # a big cloud is walked through the INTERLEAVED buffer (round 6: a node record followed by the sphere records of its leaves, rttnw_stats.reserved
+    # bit 6) — layout only: the separate arrays of rounds 1-5 (RTTNW_INTERLEAVE=0, decided when a scene's quantised records are first made) give the
+    # same bytes, in every precision (the same kernel runs the same steps)
+    assert (st.reserved & 64) == 64, st.reserved
+    os.environ["RTTNW_INTERLEAVE"] = "0"
+    try:
+        sc0, _ = util.build(gpu, scenes_lib, "spheres_1m", param=150000)
+        lin0, rgba0, st0 = gpu_render(gpu, sc0, cam, p)
+    finally:
+        del os.environ["RTTNW_INTERLEAVE"]
+    assert (st0.reserved & 65) == 1 and np.array_equal(lin0, lin) and np.array_equal(rgba0, rgba)
     os.environ["RTTNW_KERNEL"] = "plain"
     try:
         lin2, rgba2, st2 = gpu_render(gpu, sc, cam, p)

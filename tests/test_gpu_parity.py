@@ -383,16 +383,19 @@ def test_kernel_forms_agree(gpu, scenes_lib, earth, scene, precision, monkeypatc
     same((lin, rgba), out["wave"], "timed wave")
 
 
+@pytest.mark.parametrize("builder", [None, abi.BVH_HOST_SAH], ids=["auto", "hostsah"])
 @pytest.mark.parametrize("precision", [abi.F64_STRICT, abi.F32], ids=["f64strict", "f32"])
-def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib, precision):
+def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib, precision, builder):
     """A scene beyond the measured crossover (5 000 four-wide nodes in f32, 9 000 in f64: render_tiles.hpp) selects the decoupled kernel by itself; it
     must agree with the forced lane-owns-path form: bit for bit in the strict build; in f32 (-ffp-contract=fast: the two kernels may fuse a
     multiply-add differently, and this scene multiplies a last-place difference ~100x per bounce) as two renders of the same image — the pixels
     whose paths never left the first bounce identical, the frame's mean within 1 %."""
-    sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=150000)
+    # (auto: the device builder — one record per leaf, records in creation order; hostsah: the host builder — up to four records per leaf, records and
+    # with them the materials reordered: both layouts of the interleaved buffer)
+    sc, setup = util.build(gpu, scenes_lib, "spheres_1m", param=150000, bvh=builder)
     cam, p = util.params_for(setup, 64, 64, 4, precision=precision, seed=3)
     lin, rgba, st = gpu_render(gpu, sc, cam, p)
-    assert (st.reserved & 1) == 1 and st.n_nodes >= 65536
+    assert (st.reserved & 1) == 1 and st.n_nodes >= (65536 if builder is None else 30000)
     import os
     # a big cloud is walked through the INTERLEAVED buffer (round 6: a node record followed by the sphere records of its leaves, rttnw_stats.reserved
     # bit 6) — layout only: the separate arrays of rounds 1-5 (RTTNW_INTERLEAVE=0, decided when a scene's quantised records are first made) give the
@@ -400,7 +403,7 @@ def test_decoupled_kernel_is_what_large_scenes_run(gpu, scenes_lib, precision):
     assert (st.reserved & 64) == 64, st.reserved
     os.environ["RTTNW_INTERLEAVE"] = "0"
     try:
-        sc0, _ = util.build(gpu, scenes_lib, "spheres_1m", param=150000)
+        sc0, _ = util.build(gpu, scenes_lib, "spheres_1m", param=150000, bvh=builder)
         lin0, rgba0, st0 = gpu_render(gpu, sc0, cam, p)
     finally:
         del os.environ["RTTNW_INTERLEAVE"]

@@ -486,3 +486,36 @@ def test_rays_nothing_can_cull_stay_inside_the_stack_bound(hostsim, scenes_lib, 
             # (final_scene: the fog's boundary test accepts NaN roots as Sphere::hit does, hittable.rs:100-107 — such a path bounces inside the
             # medium to the depth limit and returns black, in the reference as here)
             assert (np.isnan(lin) | (lin == 0)).all() and (name != "cornell_box" or np.isnan(lin).all()), (name, degenerate)
+
+
+def test_l2_model_of_the_decoupled_kernel_runs_and_adds_up(hostsim, scenes_lib):
+    """tests/hostsim/cache_model.hpp — the host model config 5's layouts were priced on (one XCD's waves of the decoupled kernel, the product's own walk
+    steps, against an LRU cache) — on a small cloud with a small cache: every stream's misses are at most its accesses, node visits and sphere tests
+    per ray are those of the walk, a layout that puts every node record on a line of its own costs lines, and a bigger cache misses less."""
+    import ctypes as C
+    sc, setup = util.build(hostsim, scenes_lib, "spheres_1m", None, 20000)
+    cam, p = util.params_for(setup, 256, 256, 16, precision=abi.F64, seed=1)
+    dims = (C.c_uint32 * 8)()
+    hostsim.lib.hostsim_scene_dims(sc.handle, dims)
+    n4 = dims[0]
+
+    def run(cache_bytes, node_perm=None, node_bytes=64):
+        prm = np.zeros(20, dtype=np.uint32)
+        prm[:] = [8, 16, 5, 8, 2, 2, cache_bytes, 0, 32, 40, 0, 8, 0, 5, 0, node_bytes, 0, 0, 0, 5]
+        out = np.zeros(192, dtype=np.uint64)
+        hostsim.lib.hostsim_cache_model(sc.handle, C.byref(cam), C.byref(p), prm.ctypes.data_as(C.c_void_p),
+                                        node_perm.ctypes.data_as(C.c_void_p) if node_perm is not None else None, None, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    small = run(64 << 10)
+    rays, nodes, tests = int(small[1]), int(small[2]), int(small[3])
+    assert rays > 1000 and 5 * rays < nodes < 60 * rays and 0 < tests < 10 * rays
+    for s in range(7):
+        acc, miss = int(small[8 + 4 * s]), int(small[9 + 4 * s])
+        assert miss <= acc
+    assert int(small[8]) == nodes and sum(int(small[64 + d]) for d in range(32)) == nodes      # node accesses = node visits, by depth too
+    big = run(8 << 20)
+    assert int(big[9]) < int(small[9])                                                         # a cache that holds the tree misses less
+    spread = run(64 << 10, np.arange(n4, dtype=np.uint32) * 2)                                 # every record on a line of its own
+    assert int(spread[9]) > int(small[9])
+    assert int(small[128]) > 0 and int(small[129]) <= 64 * int(small[128]) and int(small[132]) > 0   # step executions and the lanes they served
